@@ -1,0 +1,315 @@
+"""Host-side mirror of gokalman's filter interface over a batch of N filters.
+
+Names and argument meaning follow the reference (kalman.go:35-72): `update(measurement,
+control)`, `set_state_transition`, `set_measurement_matrix`, `set_noise`, `reset`, and an
+`Estimate` with `state() / measurement() / innovation() / covariance() / pred_covariance()
+/ is_within_nsigma()`.  Every call goes straight to the C ABI (include/gokalman_amd.h);
+nothing is computed here.  Arrays are numpy, shaped `[N, ...]` per filter or `[...]` for a
+model shared by every filter (broadcast).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as k
+
+_dp = C.POINTER(C.c_double)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Estimate:
+    """The Estimate interface (kalman.go:64-72) for every filter of the batch at one step.
+
+    Getters download from HBM on demand (the reference's SquareRoot / Information / SRIF
+    estimates are lazy in the same way)."""
+
+    def __init__(self, batch):
+        self._b = batch
+
+    def state(self):
+        return self._b.get(k.STATE)
+
+    def measurement(self):
+        return self._b.get(k.MEASUREMENT)
+
+    def innovation(self):
+        return self._b.get(k.INNOVATION)
+
+    def covariance(self):
+        return self._b.get(k.COVAR)
+
+    def pred_covariance(self):
+        return self._b.get(k.PRED_COVAR)
+
+    def gain(self):
+        return self._b.get(k.GAIN)
+
+    def is_within_nsigma(self, nsigma):
+        return self._b.is_within_nsigma(nsigma)
+
+    def is_within_2sigma(self):
+        return self.is_within_nsigma(2.0)
+
+
+class FilterBatch:
+    """N independent filters of one kind on one MI355X (a `kb_batch`)."""
+
+    def __init__(self, kind, n, p, m=0, nfilters=1, dtype=k.F64, device=0, flags=0):
+        self._h = C.c_void_p()
+        self.kind, self.n, self.pmax, self.m, self.N, self.dtype = kind, n, p, m, int(nfilters), dtype
+        k.check(k.lib().kb_create(C.byref(self._h), kind, n, p, m, int(nfilters), dtype, device, flags))
+
+    # ---- constructors mirroring NewVanilla / NewPurePredictorVanilla / NewSquareRoot /
+    # ---- NewInformation / NewInformationFromState (x0, P0, F, G, H, noise)
+    @classmethod
+    def new_ldkf(cls, kind, x0, P0, F, G, H, Q, R, nfilters=None, dtype=k.F64, device=0, flags=0,
+                 noise=k.NOISE_NOISELESS, seed=0, pmax=None):
+        """pmax: largest measurement dimension a later set_measurement_matrix may use."""
+        x0, P0, F, H, Q, R = [_f64(v) for v in (x0, P0, F, H, Q, R)]
+        n = x0.shape[-1]
+        H = H.reshape(H.shape[:-2] + H.shape[-2:]) if H.ndim >= 2 else H.reshape(1, n)
+        p = H.shape[-2]
+        if R.ndim < 2:
+            R = R.reshape(-1, p, p) if R.size != p * p else R.reshape(p, p)
+        Gm = None if G is None else _f64(G)
+        m = 0 if Gm is None else (Gm.shape[-1] if Gm.ndim >= 2 else 1)
+        if Gm is not None and Gm.ndim == 1:
+            Gm = Gm.reshape(n, 1)
+        # the reference's constructor checks (vanilla.go:23-31), same messages
+        if P0.shape[-1] != n:
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: x0(%dx...) Covar0(...x%d)" % (n, P0.shape[-1]))
+        if F.shape[-2] != P0.shape[-1]:
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: F(%dx...) Covar0(...x%d)" % (F.shape[-2], P0.shape[-1]))
+        if H.shape[-1] != n:
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: H(...x%d) x0(%dx...)" % (H.shape[-1], n))
+        if nfilters is None:
+            nfilters = x0.shape[0] if x0.ndim == 2 else 1
+        b = cls(kind, n, max(p, pmax or p), m, nfilters, dtype, device, flags)
+        b.set(k.X, x0, 1)
+        b.set(k.P, P0, 2)
+        b.set(k.F, F, 2)
+        if Gm is not None and m > 0:
+            b.set(k.G, Gm, 2)
+        b.set(k.H, H, 2, p_rows=p)
+        b.set(k.Q, Q, 2)
+        b.set(k.R, R, 2, p_rows=p)
+        if noise != k.NOISE_NOISELESS:
+            b.set_noise_kind(noise, seed)
+        b.init()
+        return b
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                k.lib().kb_destroy(h)
+            except Exception:  # interpreter shutdown: module globals already torn down
+                pass
+            self._h = C.c_void_p()
+
+    # ---- uploads -------------------------------------------------------------------
+    def set(self, field, arr, item_ndim, p_rows=0):
+        """kb_set: arr is [N, ...item] per filter or [...item] shared (broadcast)."""
+        arr = _f64(arr)
+        if arr.ndim == item_ndim:
+            count, bcast = 1, 1
+        elif arr.ndim == item_ndim + 1:
+            count, bcast = arr.shape[0], 0
+            if count == 1 and self.N != 1:
+                bcast = 1
+        else:
+            raise ValueError("array rank %d does not match field rank %d" % (arr.ndim, item_ndim))
+        k.check(k.lib().kb_set(self._h, field, _ptr(arr), count, bcast, p_rows))
+
+    def set_dev(self, field, ptr, ld, p_rows=0):
+        k.check(k.lib().kb_set_dev(self._h, field, C.c_void_p(ptr), ld, p_rows))
+
+    def init(self):
+        k.check(k.lib().kb_init(self._h))
+
+    # ---- LDKF setters (kalman.go:41-44) ----------------------------------------------
+    def set_state_transition(self, F):
+        self.set(k.F, F, 2)
+
+    def set_input_control(self, G):
+        self.set(k.G, G, 2)
+
+    def set_measurement_matrix(self, H):
+        H = _f64(H)
+        self.set(k.H, H, 2, p_rows=H.shape[-2])
+
+    def set_noise(self, Q, R):
+        """SetNoise(Noiseless/AWGN{Q,R})."""
+        R = _f64(R)
+        if R.ndim < 2:
+            R = R.reshape(1, 1)
+        self.set(k.Q, Q, 2)
+        self.set(k.R, R, 2, p_rows=R.shape[-1])
+
+    def set_noise_kind(self, kind, seed=0):
+        k.check(k.lib().kb_set_noise_kind(self._h, kind, seed))
+
+    def reset(self):
+        k.check(k.lib().kb_reset(self._h))
+
+    # ---- the hot path ----------------------------------------------------------------
+    def update(self, measurement, control=None):
+        """LDKF.Update(measurement, control) for every filter; returns the batch Estimate."""
+        y = _f64(measurement)
+        if y.ndim == 1:
+            y = np.broadcast_to(y, (self.N, y.shape[0]))
+        y = _f64(y)
+        u, urows = None, 0
+        if control is not None:
+            u = _f64(control)
+            if u.ndim == 1:
+                u = np.broadcast_to(u, (self.N, u.shape[0]))
+            u = _f64(u)
+            urows = u.shape[1]
+        k.check(k.lib().kb_update(self._h, _ptr(y), y.shape[1], None if u is None else _ptr(u), urows))
+        return Estimate(self)
+
+    def update_dev(self, meas_ptr, ld_meas, ctrl_ptr=None, ld_ctrl=0):
+        k.check(k.lib().kb_update_dev(self._h, C.c_void_p(meas_ptr), ld_meas,
+                                      C.c_void_p(ctrl_ptr) if ctrl_ptr else None, ld_ctrl))
+
+    def update_steps_dev(self, meas_ptr, ld_meas, nsteps, ctrl_ptr=None, ld_ctrl=0):
+        k.check(k.lib().kb_update_steps_dev(self._h, C.c_void_p(meas_ptr), ld_meas,
+                                            C.c_void_p(ctrl_ptr) if ctrl_ptr else None, ld_ctrl, nsteps))
+
+    # ---- NLDKF (kalman.go:51-60) -------------------------------------------------------
+    def prepare(self, phi, htilde):
+        phi, htilde = _f64(phi), _f64(htilde)
+        bcast = 1 if phi.ndim == 2 else 0
+        k.check(k.lib().kb_prepare(self._h, _ptr(phi), _ptr(htilde), 1 if bcast else phi.shape[0], bcast))
+
+    def prepare_pnt(self, gamma):
+        gamma = _f64(gamma)
+        bcast = 1 if gamma.ndim == 2 else 0
+        k.check(k.lib().kb_prepare_pnt(self._h, _ptr(gamma), 1 if bcast else gamma.shape[0], bcast))
+
+    def enable_ekf(self):
+        k.check(k.lib().kb_set_ekf(self._h, 1))
+
+    def disable_ekf(self):
+        k.check(k.lib().kb_set_ekf(self._h, 0))
+
+    def ekf_enabled(self):
+        return bool(k.lib().kb_ekf_enabled(self._h))
+
+    def update_nl(self, real_obs, computed_obs):
+        r, c = _f64(real_obs), _f64(computed_obs)
+        if r.ndim == 1:
+            r = _f64(np.broadcast_to(r, (self.N, r.shape[0])))
+        if c.ndim == 1:
+            c = _f64(np.broadcast_to(c, (self.N, c.shape[0])))
+        k.check(k.lib().kb_update_nl(self._h, _ptr(r), r.shape[1], _ptr(c), c.shape[1]))
+        return Estimate(self)
+
+    def predict_nl(self):
+        k.check(k.lib().kb_predict_nl(self._h))
+        return Estimate(self)
+
+    # ---- results -----------------------------------------------------------------------
+    def _shape(self, field):
+        n, p = self.n, self.meas_dim()
+        info = self.kind in (k.INFORMATION, k.SRIF)
+        return {
+            k.STATE: (n,), k.RAW_VEC: (n,), k.X: (n,),
+            k.COVAR: (n, n), k.PRED_COVAR: (n, n), k.RAW_MAT: (n, n), k.RAW_PRED_MAT: (n, n), k.P: (n, n),
+            k.GAIN: (n, p), k.INNOVATION: (n,) if info else (p,), k.MEASUREMENT: (p,),
+            k.F: (n, n), k.H: (p, n), k.G: (n, self.m), k.R: (p, p),
+            k.Q: (self.m, self.m) if self.kind == k.HYBRID else (n, n),
+        }[field]
+
+    def get(self, field, first=0, count=None):
+        count = self.N - first if count is None else count
+        out = np.zeros((count,) + self._shape(field), dtype=np.float64)
+        k.check(k.lib().kb_get(self._h, field, _ptr(out), first, count))
+        return out
+
+    def status(self, first=0, count=None):
+        count = self.N - first if count is None else count
+        out = np.zeros(count, dtype=np.uint32)
+        k.check(k.lib().kb_get_status(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), first, count))
+        return out
+
+    def clear_status(self):
+        k.check(k.lib().kb_clear_status(self._h))
+
+    def is_within_nsigma(self, nsigma, first=0, count=None):
+        count = self.N - first if count is None else count
+        out = np.zeros(count, dtype=np.uint8)
+        k.check(k.lib().kb_is_within_nsigma(self._h, float(nsigma), out.ctypes.data_as(C.POINTER(C.c_uint8)), first, count))
+        return out.astype(bool)
+
+    def estimate(self):
+        return Estimate(self)
+
+    def step(self):
+        return int(k.lib().kb_step(self._h))
+
+    def need_ctrl(self):
+        return bool(k.lib().kb_need_ctrl(self._h))
+
+    def meas_dim(self):
+        return int(k.lib().kb_meas_dim(self._h))
+
+    def stream(self):
+        return int(k.lib().kb_stream(self._h) or 0)
+
+    def synchronize(self):
+        k.check(k.lib().kb_synchronize(self._h))
+
+    def noise_sample(self, filt, epoch, step, which, size):
+        out = np.zeros(size, dtype=np.float64)
+        k.check(k.lib().kb_noise_sample(self._h, filt, epoch, step, which, _ptr(out)))
+        return out
+
+
+class MonteCarloRuns:
+    """MonteCarloRuns (montecarlo.go:12-59): per-step mean / unbiased stddev over runs."""
+
+    def __init__(self, runs, steps, n, sums):
+        self.runs, self.steps, self.n = runs, steps, n
+        self.sums = sums  # [steps, 2, n]: sum and sum of squares over runs
+        mean = np.zeros((steps, n))
+        std = np.zeros((steps, n))
+        k.check(k.lib().kb_mc_stats(_ptr(_f64(sums)), steps, n, runs, _ptr(mean), _ptr(std)))
+        self._mean, self._std = mean, std
+
+    def mean(self, step):
+        return self._mean[step]
+
+    def stddev(self, step):
+        return self._std[step]
+
+
+def new_monte_carlo_runs(samples, steps, rows_h, controls, kf, first_run=0, reduce=None):
+    """NewMonteCarloRuns(samples, steps, rowsH, controls, kf) (montecarlo.go:92-119).
+
+    `kf` is a pure-predictor Vanilla FilterBatch with N == samples.  `reduce`, when given,
+    is applied to the per-shard sums (e.g. a torch.distributed all-reduce) and `samples`
+    is then the global number of runs."""
+    if kf.kind != k.VANILLA_PREDICT:
+        raise k.KalmanError(k.ERR_INVALID, "the Kalman filter needed for the Monte Carlo runs must be a pure predictor")
+    controls = _f64(controls)
+    if controls.ndim == 1:
+        controls = controls.reshape(1, -1)
+    if controls.shape[0] != 1 and controls.shape[0] != steps:
+        raise k.KalmanError(k.ERR_INVALID, "must provide as much control vectors as steps, or just one control vector")
+    sums = np.zeros((steps, 2, kf.n), dtype=np.float64)
+    k.check(k.lib().kb_mc_run(kf._h, steps, _ptr(controls), controls.shape[0], first_run, _ptr(sums)))
+    if reduce is not None:
+        sums = reduce(sums)
+    return MonteCarloRuns(samples, steps, kf.n, sums)

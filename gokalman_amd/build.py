@@ -1,0 +1,62 @@
+"""Builds libgokalman_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+`python -m gokalman_amd.build` or gokalman_amd.build.build().  Objects are compiled in
+parallel (one hipcc per translation unit) and cached by source mtime under csrc/_obj/.
+"""
+import concurrent.futures
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libgokalman_amd.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast", "-fno-fast-math"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build the gfx950 kernels")
+
+
+def _deps_mtime():
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+            and os.path.getmtime(obj) > _deps_mtime()):
+        return obj
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    if (force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % res.stderr[-4000:])
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,644 @@
+// kb_api.hip -- the C ABI (include/gokalman_amd.h): handle lifetime, uploads, the
+// Update entry points, Estimate getters.  Host-side control only; all arithmetic on
+// filter data happens in the HIP kernels (there is no CPU path).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "kb_internal.h"
+
+namespace kb {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int hip_fail(hipError_t e, const char *what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return KB_ERR_HIP;
+}
+
+static bool is_ldkf(int k) { return k == KB_VANILLA || k == KB_VANILLA_PREDICT || k == KB_SQUAREROOT || k == KB_INFORMATION; }
+static bool is_nldkf(int k) { return k == KB_SRIF || k == KB_HYBRID; }
+
+static Layout make_layout(int kind, int n, int pmax, int m, unsigned flags) {
+    Layout L;
+    L.n = n; L.pmax = pmax; L.m = m;
+    L.st_vec = 0; L.st_mat = n;
+    L.st_mat_full = (kind == KB_SRIF);
+    L.st_elems = n + (L.st_mat_full ? n * n : tri(n));
+    int o = 0;
+    L.es_ppred = o; o += L.st_mat_full ? n * n : tri(n);
+    L.es_gain = o;  o += n * pmax;
+    L.es_innov = o; o += pmax;
+    L.es_yhat = o;  o += pmax;
+    L.es_dobs = o;  o += pmax;
+    L.es_elems = o;
+    (void)flags;
+    o = 0;
+    L.nq = (kind == KB_HYBRID) ? m : 0;
+    L.mo_F = o; o += n * n;
+    L.mo_H = o; o += pmax * n;
+    L.mo_Q = o; o += (kind == KB_HYBRID) ? tri(m > 0 ? m : 1) : tri(n);
+    L.mo_R = o; o += tri(pmax);
+    L.mo_G = o; o += n * (m > 0 ? m : 0);
+    L.mo_LQ = o; o += tri(n);
+    L.mo_LR = o; o += tri(pmax);
+    if (kind == KB_INFORMATION) {
+        L.mo_Finv = o; o += n * n;
+        L.mo_Qinv = o; o += n * n;
+        L.mo_Rinv = o; o += pmax * pmax;
+    }
+    L.mo_elems = o;
+    return L;
+}
+
+static int ensure_stage(Batch &b, size_t bytes) {
+    if (b.stage_bytes >= bytes) return KB_OK;
+    if (b.d_stage) KB_HIP(hipFree(b.d_stage));
+    b.d_stage = nullptr; b.stage_bytes = 0;
+    KB_HIP(hipMalloc(&b.d_stage, bytes));
+    b.stage_bytes = bytes;
+    return KB_OK;
+}
+
+static int use_device(const Batch &b) {
+    KB_HIP(hipSetDevice(b.device));
+    return KB_OK;
+}
+
+// element maps ---------------------------------------------------------------------
+// full row-major n x n -> packed symmetric (upper triangle only is taken)
+static void map_sym_in(int n, int dst_off, int16_t *map) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) map[i * n + j] = (j >= i) ? (int16_t)(dst_off + symi(i, j)) : (int16_t)-1;
+}
+// packed symmetric -> full row-major (mirror)
+static void map_sym_out(int n, int src_off, int16_t *map) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) map[i * n + j] = (int16_t)(src_off + symi(i, j));
+}
+static void map_dense(int rows, int cols, int off, int ld, int16_t *map) {
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++) map[i * cols + j] = (int16_t)(off + i * ld + j);
+}
+// lower-triangular factor stored packed (L[i][k], k<=i at symi(k,i)) -> full
+static void map_lower_out(int n, int src_off, int16_t *map) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) map[i * n + j] = (j <= i) ? (int16_t)(src_off + symi(j, i)) : (int16_t)-1;
+}
+static void map_upper_out(int n, int src_off, int16_t *map) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) map[i * n + j] = (j >= i) ? (int16_t)(src_off + symi(i, j)) : (int16_t)-1;
+}
+
+struct FieldTarget { void *block; int block_elems; int src_elems; int16_t map[KB_MAX_DIM * KB_MAX_DIM]; };
+
+// where an INPUT field lands; p_rows = rows the caller's H/R has
+static int input_target(Batch &b, int field, int p_rows, FieldTarget &t) {
+    const int n = b.n, m = b.m;
+    const Layout &L = b.L;
+    switch (field) {
+    case KB_X:
+        t.block = b.d_state; t.block_elems = L.st_elems; t.src_elems = n;
+        map_dense(1, n, L.st_vec, n, t.map);
+        return KB_OK;
+    case KB_P:
+        t.block = b.d_state; t.block_elems = L.st_elems; t.src_elems = n * n;
+        if (L.st_mat_full) map_dense(n, n, L.st_mat, n, t.map); else map_sym_in(n, L.st_mat, t.map);
+        return KB_OK;
+    case KB_F:
+        t.block = b.d_model; t.block_elems = L.mo_elems; t.src_elems = n * n;
+        map_dense(n, n, L.mo_F, n, t.map);
+        return KB_OK;
+    case KB_G:
+        if (m <= 0) { set_error("batch was created with m = 0: no input control"); return KB_ERR_INVALID; }
+        t.block = b.d_model; t.block_elems = L.mo_elems; t.src_elems = n * m;
+        map_dense(n, m, L.mo_G, m, t.map);
+        return KB_OK;
+    case KB_H:
+        if (p_rows < 1 || p_rows > b.pmax) { set_error("H has %d rows; the batch was created for at most %d", p_rows, b.pmax); return KB_ERR_DIMS; }
+        t.block = b.d_model; t.block_elems = L.mo_elems; t.src_elems = p_rows * n;
+        map_dense(p_rows, n, L.mo_H, n, t.map);
+        return KB_OK;
+    case KB_Q: {
+        const int q = (b.kind == KB_HYBRID) ? m : n;
+        if (q <= 0) { set_error("no process noise dimension"); return KB_ERR_INVALID; }
+        t.block = b.d_model; t.block_elems = L.mo_elems; t.src_elems = q * q;
+        map_sym_in(q, L.mo_Q, t.map);
+        return KB_OK;
+    }
+    case KB_R:
+        if (p_rows < 1 || p_rows > b.pmax) { set_error("R is %dx%d; the batch was created for at most %d", p_rows, p_rows, b.pmax); return KB_ERR_DIMS; }
+        t.block = b.d_model; t.block_elems = L.mo_elems; t.src_elems = p_rows * p_rows;
+        map_sym_in(p_rows, L.mo_R, t.map);
+        return KB_OK;
+    }
+    set_error("field %d is not an input field", field);
+    return KB_ERR_INVALID;
+}
+
+template <typename T>
+__global__ void pack_planar_kernel(const T *__restrict__ src, int64_t ld, int src_elems, int64_t N,
+                                   T *__restrict__ dst, int dst_elems, const int16_t *__restrict__ map) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    T *d = dst + (i / KB_TILE) * ((int64_t)KB_TILE * dst_elems) + (i % KB_TILE);
+    for (int e = 0; e < src_elems; e++) {
+        const int de = map[e];
+        if (de >= 0) d[(int64_t)de * KB_TILE] = src[(int64_t)e * ld + i];
+    }
+}
+
+static void fill_step_args(const Batch &b, StepArgs &a) {
+    memset(&a, 0, sizeof(a));
+    a.state = b.d_state; a.pred = b.d_pred; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status;
+    a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
+    a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
+    a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p;
+    a.ekf = b.ekf; a.snc = b.snc; a.predict = (b.kind == KB_VANILLA_PREDICT);
+    a.noise_kind = b.noise_kind; a.seed = b.seed; a.epoch = b.epoch; a.step0 = b.step; a.first_filter = 0;
+}
+
+static int launch_step(Batch &b, const StepArgs &a, bool fused) {
+    switch (b.kind) {
+    case KB_VANILLA:
+    case KB_VANILLA_PREDICT: return launch_vanilla(b, a, fused);
+    case KB_SQUAREROOT: return launch_squareroot(b, a);
+    case KB_INFORMATION: return launch_information(b, a);
+    }
+    set_error("kind %d has no LDKF update", b.kind);
+    return KB_ERR_UNSUPPORTED;
+}
+
+// host [N][rows] -> AoSoA staging block with `rows` elements per filter
+static int stage_host_vec(Batch &b, const double *host, int rows, void **dblock) {
+    const size_t bytes = (size_t)b.N * rows * sizeof(double);
+    int rc = ensure_stage(b, bytes);
+    if (rc) return rc;
+    KB_HIP(hipMemcpyAsync(b.d_stage, host, bytes, hipMemcpyHostToDevice, b.stream));
+    if (!*dblock) {
+        KB_HIP(hipMalloc(dblock, b.block_bytes(KB_MAX_DIM)));
+        KB_HIP(hipMemsetAsync(*dblock, 0, b.block_bytes(KB_MAX_DIM), b.stream));
+    }
+    int16_t map[KB_MAX_DIM * KB_MAX_DIM];
+    map_dense(1, rows, 0, rows, map);
+    return launch_pack(b, b.d_stage, rows, b.N, false, *dblock, rows, map);
+}
+
+}  // namespace kb
+
+using namespace kb;
+
+// =====================================================================================
+// lifetime
+// =====================================================================================
+extern "C" {
+
+const char *kb_last_error(void) { return g_err; }
+const char *kb_version(void) { return "gokalman_amd 0.1 (gfx950)"; }
+
+int kb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, int dtype, int device, unsigned flags) {
+    if (!out) { set_error("out is NULL"); return KB_ERR_INVALID; }
+    *out = nullptr;
+    if (kind < KB_VANILLA || kind > KB_HYBRID) { set_error("unknown filter kind %d", kind); return KB_ERR_INVALID; }
+    if (n < 1 || n > KB_MAX_DIM || p < 1 || p > KB_MAX_DIM || m < 0 || m > KB_MAX_DIM) {
+        set_error("dimensions out of range: n=%d p=%d m=%d (1..%d)", n, p, m, KB_MAX_DIM);
+        return KB_ERR_DIMS;
+    }
+    if (nfilters < 1) { set_error("nfilters must be >= 1"); return KB_ERR_INVALID; }
+    if (dtype != KB_F64 && dtype != KB_F32) { set_error("unknown dtype %d", dtype); return KB_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device visible: gokalman_amd has no CPU fallback");
+        return KB_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d visible)", device, ndev); return KB_ERR_INVALID; }
+    kb_batch *b = new kb_batch();
+    b->kind = kind; b->n = n; b->pmax = p; b->p = p; b->m = m; b->dtype = dtype; b->device = device; b->flags = flags;
+    b->N = nfilters; b->ntiles = (nfilters + KB_TILE - 1) / KB_TILE;
+    b->L = make_layout(kind, n, p, m, flags);
+    b->locked = is_nldkf(kind) ? 1 : 0;
+    int rc = KB_OK;
+    auto fail = [&](int code) { kb_destroy(b); return code; };
+    if ((rc = use_device(*b))) return fail(rc);
+#define KB_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call)); } while (0)
+    KB_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    KB_TRY(hipMalloc(&b->d_state, b->block_bytes(b->L.st_elems)));
+    KB_TRY(hipMalloc(&b->d_state0, b->block_bytes(b->L.st_elems)));
+    KB_TRY(hipMalloc(&b->d_model, b->block_bytes(b->L.mo_elems)));
+    KB_TRY(hipMalloc((void **)&b->d_status, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
+    KB_TRY(hipMemsetAsync(b->d_state, 0, b->block_bytes(b->L.st_elems), b->stream));
+    KB_TRY(hipMemsetAsync(b->d_state0, 0, b->block_bytes(b->L.st_elems), b->stream));
+    KB_TRY(hipMemsetAsync(b->d_model, 0, b->block_bytes(b->L.mo_elems), b->stream));
+    KB_TRY(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
+    if (flags & KB_FLAG_FULL_ESTIMATE) {
+        KB_TRY(hipMalloc(&b->d_est, b->block_bytes(b->L.es_elems)));
+        KB_TRY(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
+    }
+    KB_TRY(hipStreamSynchronize(b->stream));
+#undef KB_TRY
+    *out = b;
+    return KB_OK;
+}
+
+void kb_destroy(kb_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    void *ptrs[] = {b->d_state, b->d_state0, b->d_pred, b->d_pred0, b->d_est, b->d_model, b->d_status,
+                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+// =====================================================================================
+// inputs
+// =====================================================================================
+static int after_set(kb_batch *b, int field, int p_rows, const double *host_for_nil, int64_t host_elems) {
+    if (field <= KB_R) b->have[field] = true;
+    if (field == KB_H) b->p = p_rows;
+    if (field == KB_R) b->sqrt_p = b->sqrt_p;  // refreshed below when initialised
+    if (field == KB_G && !b->initialized && host_for_nil) {
+        // needCtrl = !IsNil(G) at construction (vanilla.go:39, helper.go:49-62); the setter does not refresh it
+        int nz = 0;
+        for (int64_t i = 0; i < host_elems; i++) if (host_for_nil[i] != 0.0) { nz = 1; break; }
+        b->need_ctrl = nz;
+    }
+    if (b->initialized && (field == KB_F || field == KB_Q || field == KB_R)) {
+        int not_pd = 0;
+        int rc = launch_refresh(*b, field, &not_pd);
+        if (rc) return rc;
+        if (field == KB_R && b->kind == KB_SQUAREROOT) b->sqrt_p = p_rows;
+        if (not_pd) { set_error("matrix is not positive definite (Cholesky failed for %d filter(s))", not_pd); return KB_ERR_NOT_PD; }
+    }
+    return KB_OK;
+}
+
+static int r_rows_of(kb_batch *b) { return b->L.pmax; }
+
+int kb_set(kb_batch *b, int field, const double *host, int64_t count, int broadcast, int p_rows) {
+    if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (broadcast ? count != 1 : count != b->N) {
+        set_error("count must be 1 with broadcast or N=%lld without (got %lld)", (long long)b->N, (long long)count);
+        return KB_ERR_INVALID;
+    }
+    if (b->initialized && (field == KB_X || field == KB_P)) {
+        set_error("x0/P0 are constructor arguments: set them before kb_init");
+        return KB_ERR_INVALID;
+    }
+    FieldTarget t;
+    if ((rc = input_target(*b, field, p_rows, t))) return rc;
+    const size_t bytes = (size_t)count * t.src_elems * sizeof(double);
+    if ((rc = ensure_stage(*b, bytes))) return rc;
+    KB_HIP(hipMemcpyAsync(b->d_stage, host, bytes, hipMemcpyHostToDevice, b->stream));
+    if ((rc = launch_pack(*b, b->d_stage, t.src_elems, count, broadcast != 0, t.block, t.block_elems, t.map))) return rc;
+    if (field == KB_R) b->rinv_p = b->initialized ? b->rinv_p : p_rows;
+    if (field == KB_R && !b->initialized) b->sqrt_p = p_rows;
+    if ((rc = after_set(b, field, p_rows, host, count * t.src_elems))) { (void)hipStreamSynchronize(b->stream); return rc; }
+    KB_HIP(hipStreamSynchronize(b->stream));
+    (void)r_rows_of;
+    return KB_OK;
+}
+
+int kb_set_dev(kb_batch *b, int field, const void *src, int64_t ld, int p_rows) {
+    if (!b || !src) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (ld < b->N) { set_error("ld (%lld) < N (%lld)", (long long)ld, (long long)b->N); return KB_ERR_INVALID; }
+    if (b->initialized && (field == KB_X || field == KB_P)) {
+        set_error("x0/P0 are constructor arguments: set them before kb_init");
+        return KB_ERR_INVALID;
+    }
+    FieldTarget t;
+    if ((rc = input_target(*b, field, p_rows, t))) return rc;
+    // the element map travels through the staging buffer (device-visible)
+    if ((rc = ensure_stage(*b, sizeof(t.map)))) return rc;
+    KB_HIP(hipMemcpyAsync(b->d_stage, t.map, sizeof(t.map), hipMemcpyHostToDevice, b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));  // t.map is on the stack
+    const unsigned blocks = (unsigned)((b->N + 255) / 256);
+    if (b->dtype == KB_F64)
+        hipLaunchKernelGGL(pack_planar_kernel<double>, dim3(blocks), dim3(256), 0, b->stream, (const double *)src, ld,
+                           t.src_elems, b->N, (double *)t.block, t.block_elems, (const int16_t *)b->d_stage);
+    else
+        hipLaunchKernelGGL(pack_planar_kernel<float>, dim3(blocks), dim3(256), 0, b->stream, (const float *)src, ld,
+                           t.src_elems, b->N, (float *)t.block, t.block_elems, (const int16_t *)b->d_stage);
+    KB_HIP(hipGetLastError());
+    if (field == KB_R && !b->initialized) { b->rinv_p = p_rows; b->sqrt_p = p_rows; }
+    if (field == KB_G && !b->initialized) b->need_ctrl = 1;  // device-side G: assumed non-nil
+    if ((rc = after_set(b, field, p_rows, nullptr, 0))) return rc;
+    KB_HIP(hipStreamSynchronize(b->stream));  // the map buffer may be reused by the next call
+    return KB_OK;
+}
+
+int kb_init(kb_batch *b) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (b->initialized) { set_error("kb_init called twice"); return KB_ERR_INVALID; }
+    const bool need_fh = is_ldkf(b->kind);
+    const char *names[] = {"x0", "P0", "F", "G", "H", "Q", "R"};
+    for (int f = KB_X; f <= KB_R; f++) {
+        bool required = (f == KB_X || f == KB_P || f == KB_R);
+        if (need_fh && (f == KB_F || f == KB_H || f == KB_Q)) required = true;
+        if (required && !b->have[f]) { set_error("kb_init: %s has not been set", names[f]); return KB_ERR_INVALID; }
+    }
+    if (b->kind == KB_SRIF || b->kind == KB_HYBRID) b->rinv_p = b->pmax;
+    int not_pd = 0;
+    if ((rc = launch_init(*b, &not_pd))) return rc;
+    if (not_pd) {
+        set_error("constructor: matrix is not positive definite (Cholesky failed for %d filter(s))", not_pd);
+        return KB_ERR_NOT_PD;
+    }
+    KB_HIP(hipMemcpyAsync(b->d_state0, b->d_state, b->block_bytes(b->L.st_elems), hipMemcpyDeviceToDevice, b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));
+    b->initialized = true;
+    b->step = 0;
+    return KB_OK;
+}
+
+int kb_reset(kb_batch *b) {
+    if (!b || !b->initialized) { set_error("batch not initialised"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    KB_HIP(hipMemcpyAsync(b->d_state, b->d_state0, b->block_bytes(b->L.st_elems), hipMemcpyDeviceToDevice, b->stream));
+    if (b->d_est) KB_HIP(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
+    KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));
+    b->step = 0;
+    b->epoch++;  // AWGN.Reset re-seeds (noise.go:145-146)
+    if (is_nldkf(b->kind)) { b->locked = 1; b->snc = 0; }
+    return KB_OK;
+}
+
+// =====================================================================================
+// the hot path
+// =====================================================================================
+static int check_update_dims(kb_batch *b, int meas_rows, int ctrl_rows, bool have_ctrl) {
+    // vanilla.go:129-135 (same in squareroot.go:131-136, information.go:154-160)
+    if (b->need_ctrl) {
+        if (!have_ctrl) ctrl_rows = 0;
+        if (ctrl_rows != b->m) {
+            set_error("dimensions must agree: control (u)(%dx...) G(...x%d)", ctrl_rows, b->m);
+            return KB_ERR_DIMS;
+        }
+    }
+    if (meas_rows != b->p) {
+        set_error("dimensions must agree: measurement (y)(%dx...) H(%dx...)", meas_rows, b->p);
+        return KB_ERR_DIMS;
+    }
+    return KB_OK;
+}
+
+static int ready_ldkf(kb_batch *b) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
+    if (!is_ldkf(b->kind)) { set_error("kb_update is the LDKF entry point; use kb_update_nl for SRIF / Hybrid"); return KB_ERR_INVALID; }
+    return use_device(*b);
+}
+
+int kb_update(kb_batch *b, const double *meas, int meas_rows, const double *ctrl, int ctrl_rows) {
+    int rc = ready_ldkf(b);
+    if (rc) return rc;
+    if (!meas) { set_error("measurement is NULL"); return KB_ERR_INVALID; }
+    if ((rc = check_update_dims(b, meas_rows, ctrl_rows, ctrl != nullptr))) return rc;
+    if ((rc = stage_host_vec(*b, meas, meas_rows, &b->d_y))) return rc;
+    if (b->need_ctrl) {
+        // the staging buffer is reused: order the two packs on the stream
+        if ((rc = stage_host_vec(*b, ctrl, ctrl_rows, &b->d_u))) return rc;
+    }
+    StepArgs a;
+    fill_step_args(*b, a);
+    a.y = b->d_y; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * meas_rows; a.y_step = 0;
+    if (b->need_ctrl) { a.u = b->d_u; a.u_es = KB_TILE; a.u_ts = (int64_t)KB_TILE * ctrl_rows; a.u_step = 0; }
+    if ((rc = launch_step(*b, a, false))) return rc;
+    KB_HIP(hipStreamSynchronize(b->stream));
+    b->step++;
+    return KB_OK;
+}
+
+static int update_dev_common(kb_batch *b, const void *meas, int64_t ld_meas, const void *ctrl, int64_t ld_ctrl,
+                             int nsteps, bool fused) {
+    int rc = ready_ldkf(b);
+    if (rc) return rc;
+    if (!meas && b->kind != KB_VANILLA_PREDICT) { set_error("measurement is NULL"); return KB_ERR_INVALID; }
+    if (ld_meas < b->N) { set_error("ld_meas (%lld) < N (%lld)", (long long)ld_meas, (long long)b->N); return KB_ERR_INVALID; }
+    if (b->need_ctrl && (!ctrl || ld_ctrl < b->N)) { set_error("control required (needCtrl) with ld_ctrl >= N"); return KB_ERR_DIMS; }
+    if (nsteps < 1) { set_error("nsteps must be >= 1"); return KB_ERR_INVALID; }
+    StepArgs a;
+    fill_step_args(*b, a);
+    a.nsteps = nsteps;
+    a.y = meas; a.y_es = ld_meas; a.y_ts = KB_TILE; a.y_step = (int64_t)b->p * ld_meas;
+    if (b->need_ctrl) { a.u = ctrl; a.u_es = ld_ctrl; a.u_ts = KB_TILE; a.u_step = (int64_t)b->m * ld_ctrl; }
+    if ((rc = launch_step(*b, a, fused))) return rc;
+    b->step += nsteps;
+    return KB_OK;
+}
+
+int kb_update_dev(kb_batch *b, const void *meas, int64_t ld_meas, const void *ctrl, int64_t ld_ctrl) {
+    return update_dev_common(b, meas, ld_meas, ctrl, ld_ctrl, 1, false);
+}
+
+int kb_update_steps_dev(kb_batch *b, const void *meas, int64_t ld_meas, const void *ctrl, int64_t ld_ctrl, int nsteps) {
+    return update_dev_common(b, meas, ld_meas, ctrl, ld_ctrl, nsteps, true);
+}
+
+// =====================================================================================
+// results
+// =====================================================================================
+int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
+    if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || first + count > b->N) { set_error("range [%lld,+%lld) outside the batch", (long long)first, (long long)count); return KB_ERR_INVALID; }
+    if (count == 0) return KB_OK;
+    const int n = b->n, p = b->p;
+    const Layout &L = b->L;
+    int16_t map[KB_MAX_DIM * KB_MAX_DIM];
+    const void *block = nullptr; int block_elems = 0, out_elems = 0;
+    const bool full = (b->flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF);
+    auto need_full = [&]() -> int {
+        if (!full) { set_error("field %d needs a batch created with KB_FLAG_FULL_ESTIMATE", field); return KB_ERR_INVALID; }
+        return KB_OK;
+    };
+    void *tmp = nullptr;
+    switch (field) {
+    case KB_X: case KB_RAW_VEC: case KB_STATE:
+        if (field == KB_STATE && (b->kind == KB_INFORMATION || b->kind == KB_SRIF)) {
+            KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
+            if ((rc = launch_materialise(*b, b->d_state, false, tmp))) { (void)hipFree(tmp); return rc; }
+            block = tmp; block_elems = n + tri(n); out_elems = n; map_dense(1, n, 0, n, map);
+        } else {
+            block = b->d_state; block_elems = L.st_elems; out_elems = n; map_dense(1, n, L.st_vec, n, map);
+        }
+        break;
+    case KB_P: case KB_COVAR: case KB_PRED_COVAR:
+        if (field == KB_PRED_COVAR && (rc = need_full())) return rc;
+        if (lazy) {
+            KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
+            const bool pred = field == KB_PRED_COVAR;
+            if ((rc = launch_materialise(*b, pred ? b->d_est : b->d_state, pred, tmp))) { (void)hipFree(tmp); return rc; }
+            block = tmp; block_elems = n + tri(n); out_elems = n * n; map_sym_out(n, n, map);
+        } else if (field == KB_PRED_COVAR) {
+            block = b->d_est; block_elems = L.es_elems; out_elems = n * n; map_sym_out(n, L.es_ppred, map);
+        } else {
+            block = b->d_state; block_elems = L.st_elems; out_elems = n * n; map_sym_out(n, L.st_mat, map);
+        }
+        break;
+    case KB_RAW_MAT: case KB_RAW_PRED_MAT: {
+        const bool pred = field == KB_RAW_PRED_MAT;
+        if (pred && (rc = need_full())) return rc;
+        block = pred ? b->d_est : b->d_state; block_elems = pred ? L.es_elems : L.st_elems; out_elems = n * n;
+        const int off = pred ? L.es_ppred : L.st_mat;
+        if (L.st_mat_full) map_dense(n, n, off, n, map);
+        else if (b->kind == KB_SQUAREROOT) { if (pred) map_upper_out(n, off, map); else map_lower_out(n, off, map); }
+        else map_sym_out(n, off, map);
+        break;
+    }
+    case KB_GAIN:
+        if ((rc = need_full())) return rc;
+        block = b->d_est; block_elems = L.es_elems; out_elems = n * p; map_dense(n, p, L.es_gain, b->pmax, map);
+        break;
+    case KB_INNOVATION:
+        if (b->kind == KB_INFORMATION || b->kind == KB_SRIF) {
+            block = b->d_state; block_elems = L.st_elems; out_elems = n; map_dense(1, n, L.st_vec, n, map);
+        } else {
+            if ((rc = need_full())) return rc;
+            block = b->d_est; block_elems = L.es_elems; out_elems = p; map_dense(1, p, L.es_innov, p, map);
+        }
+        break;
+    case KB_MEASUREMENT:
+        if ((rc = need_full())) return rc;
+        block = b->d_est; block_elems = L.es_elems; out_elems = p; map_dense(1, p, L.es_yhat, p, map);
+        break;
+    case KB_F: block = b->d_model; block_elems = L.mo_elems; out_elems = n * n; map_dense(n, n, L.mo_F, n, map); break;
+    case KB_H: block = b->d_model; block_elems = L.mo_elems; out_elems = p * n; map_dense(p, n, L.mo_H, n, map); break;
+    case KB_G:
+        if (b->m <= 0) { set_error("no input control"); return KB_ERR_INVALID; }
+        block = b->d_model; block_elems = L.mo_elems; out_elems = n * b->m; map_dense(n, b->m, L.mo_G, b->m, map); break;
+    case KB_Q: {
+        const int q = b->kind == KB_HYBRID ? b->m : n;
+        block = b->d_model; block_elems = L.mo_elems; out_elems = q * q; map_sym_out(q, L.mo_Q, map); break;
+    }
+    case KB_R: block = b->d_model; block_elems = L.mo_elems; out_elems = p * p; map_sym_out(p, L.mo_R, map); break;
+    default:
+        set_error("unknown field %d", field);
+        return KB_ERR_INVALID;
+    }
+    const size_t bytes = (size_t)count * out_elems * sizeof(double);
+    if ((rc = ensure_stage(*b, bytes))) { if (tmp) (void)hipFree(tmp); return rc; }
+    rc = launch_unpack(*b, block, block_elems, map, out_elems, (double *)b->d_stage, first, count);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(host, b->d_stage, bytes, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "kb_get copy");
+    }
+    if (tmp) (void)hipFree(tmp);
+    return rc;
+}
+
+int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld) {
+    if (!b || !dst) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (ld < b->N) { set_error("ld < N"); return KB_ERR_INVALID; }
+    const int n = b->n;
+    int16_t map[KB_MAX_DIM * KB_MAX_DIM];
+    if (field == KB_RAW_VEC || (field == KB_STATE && b->kind != KB_INFORMATION && b->kind != KB_SRIF)) {
+        map_dense(1, n, b->L.st_vec, n, map);
+        return launch_unpack_planar(*b, b->d_state, b->L.st_elems, map, n, dst, ld);
+    }
+    if ((field == KB_COVAR || field == KB_RAW_MAT) && !b->L.st_mat_full &&
+        (field == KB_RAW_MAT ? b->kind != KB_SQUAREROOT : (b->kind == KB_VANILLA || b->kind == KB_VANILLA_PREDICT || b->kind == KB_HYBRID))) {
+        map_sym_out(n, b->L.st_mat, map);
+        return launch_unpack_planar(*b, b->d_state, b->L.st_elems, map, n * n, dst, ld);
+    }
+    set_error("kb_get_dev: field %d not available on the device path for kind %d", field, b->kind);
+    return KB_ERR_UNSUPPORTED;
+}
+
+int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count) {
+    if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || first + count > b->N) { set_error("range outside the batch"); return KB_ERR_INVALID; }
+    KB_HIP(hipMemcpyAsync(host, b->d_status + first, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));
+    return KB_OK;
+}
+
+int kb_clear_status(kb_batch *b) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));
+    return KB_OK;
+}
+
+int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first, int64_t count) {
+    if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || first + count > b->N) { set_error("range outside the batch"); return KB_ERR_INVALID; }
+    const int n = b->n;
+    void *tmp = nullptr;
+    const void *xp = b->d_state;
+    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF);
+    if (lazy) {
+        KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
+        if ((rc = launch_materialise(*b, b->d_state, false, tmp))) { (void)hipFree(tmp); return rc; }
+        xp = tmp;
+    }
+    uint8_t *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)b->ntiles * KB_TILE);
+    if (e != hipSuccess) { if (tmp) (void)hipFree(tmp); return hip_fail(e, "hipMalloc"); }
+    rc = launch_within_nsigma(*b, xp, nsigma, d_out);
+    if (!rc) {
+        e = hipMemcpyAsync(host, d_out + first, (size_t)count, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "copy");
+    }
+    (void)hipFree(d_out);
+    if (tmp) (void)hipFree(tmp);
+    return rc;
+}
+
+int64_t kb_step(const kb_batch *b) { return b ? b->step : -1; }
+int kb_need_ctrl(const kb_batch *b) { return b ? b->need_ctrl : 0; }
+int kb_meas_dim(const kb_batch *b) { return b ? b->p : 0; }
+int64_t kb_num_filters(const kb_batch *b) { return b ? b->N : 0; }
+void *kb_stream(const kb_batch *b) { return b ? (void *)b->stream : nullptr; }
+int kb_synchronize(kb_batch *b) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    KB_HIP(hipStreamSynchronize(b->stream));
+    return KB_OK;
+}
+
+int kb_set_ekf(kb_batch *b, int enabled) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    if (b->kind == KB_HYBRID) b->ekf = enabled ? 1 : 0;  // srif.go:62-72: no-ops for SRIF
+    return KB_OK;
+}
+int kb_ekf_enabled(const kb_batch *b) { return (b && b->kind == KB_HYBRID) ? b->ekf : 0; }
+
+}  // extern "C"

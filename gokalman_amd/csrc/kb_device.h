@@ -1,0 +1,221 @@
+// kb_device.h -- device-side building blocks shared by the filter kernels.
+//
+// Execution model: ONE FILTER PER LANE.  A wavefront (64 lanes) owns one "tile" of
+// 64 consecutive filters; every per-filter quantity lives in that lane's VGPRs.
+// HBM layout is AoSoA-64: element e of the filter in lane l of tile t sits at
+//     block[t * (64 * elems) + e * 64 + l]
+// so every wave-level load/store is one fully coalesced 512-byte (f64) row, and a
+// tile's whole working set is one contiguous stream (DRAM-page and TLB friendly).
+// Symmetric matrices are stored packed (upper triangle, column-major order of the
+// triangle: idx(i,j) = j(j+1)/2 + i for i <= j), which is exactly what the
+// reference's mat64.SymDense keeps meaningful (helper.go:65-84).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KB_TILE 64
+
+namespace kb {
+
+__host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
+// packed index of symmetric element (i,j), any order of i,j
+__host__ __device__ constexpr int symi(int i, int j) { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
+
+template <typename T> struct Eps;
+template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };
+template <> struct Eps<float>  { static constexpr float  tiny = 1.17549435e-38f; };
+
+// floats.EqualWithinAbsOrRel(a, b, 1e-6, 1e-2) as used by AsSymDense (helper.go:75)
+template <typename T>
+__device__ __forceinline__ bool sym_close(T a, T b) {
+    if (a == b) return true;
+    T d = fabs(a - b);
+    if (d <= T(1e-6)) return true;
+    if (d <= Eps<T>::tiny) return d <= T(1e-2) * Eps<T>::tiny;
+    return d / fmax(fabs(a), fabs(b)) <= T(1e-2);
+}
+
+// ---------------------------------------------------------------------------
+// mat64.Dense.Inverse restated for a register-resident P x P matrix:
+// LU with partial pivoting (row exchanges by select, no dynamic indexing),
+// then forward/back substitution against the identity.  Returns true when the
+// reference would return a Condition error: exact zero pivot, or
+// cond_inf = |A|_inf |A^-1|_inf > 1e16 (gonum matrix.ConditionTolerance), or NaN.
+// ---------------------------------------------------------------------------
+template <typename T, int P>
+__device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P]) {
+    T a[P * P], b[P * P];
+    T anorm = T(0);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            a[i * P + j] = Ain[i * P + j];
+            b[i * P + j] = (i == j) ? T(1) : T(0);
+            s += fabs(Ain[i * P + j]);
+        }
+        anorm = (s > anorm || s != s) ? s : anorm;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        // bring the largest |a[r][j]|, r >= j, to row j
+#pragma unroll
+        for (int r = j + 1; r < P; r++) {
+            const bool sw = fabs(a[r * P + j]) > fabs(a[j * P + j]);
+#pragma unroll
+            for (int c = 0; c < P; c++) {
+                if (c >= j) {
+                    const T t0 = a[j * P + c], t1 = a[r * P + c];
+                    a[j * P + c] = sw ? t1 : t0;
+                    a[r * P + c] = sw ? t0 : t1;
+                }
+                const T u0 = b[j * P + c], u1 = b[r * P + c];
+                b[j * P + c] = sw ? u1 : u0;
+                b[r * P + c] = sw ? u0 : u1;
+            }
+        }
+        const T piv = a[j * P + j];
+        bad = bad || (piv == T(0));
+        const T rp = T(1) / piv;
+#pragma unroll
+        for (int r = j + 1; r < P; r++) {
+            const T l = a[r * P + j] * rp;
+#pragma unroll
+            for (int c = j + 1; c < P; c++) a[r * P + c] -= l * a[j * P + c];
+#pragma unroll
+            for (int c = 0; c < P; c++) b[r * P + c] -= l * b[j * P + c];
+        }
+    }
+    // back substitution U X = b
+    T inorm = T(0);
+#pragma unroll
+    for (int i = P - 1; i >= 0; i--) {
+        const T rd = T(1) / a[i * P + i];
+#pragma unroll
+        for (int c = 0; c < P; c++) {
+            T s = b[i * P + c];
+#pragma unroll
+            for (int k = i + 1; k < P; k++) s -= a[i * P + k] * X[k * P + c];
+            X[i * P + c] = s * rd;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int c = 0; c < P; c++) s += fabs(X[i * P + c]);
+        inorm = (s > inorm || s != s) ? s : inorm;
+    }
+    const T cond = anorm * inorm;
+    return bad || !(cond <= T(1e16));
+}
+
+// Runtime-dimension version on a private array with leading dimension LD
+// (generic kernels).  Same algorithm; `a` is destroyed, X receives the inverse.
+template <typename T, int LD>
+__device__ inline bool inverse_lu_rt(int p, T *a, T *X) {
+    T b[LD * LD];
+    T anorm = T(0);
+    for (int i = 0; i < p; i++) {
+        T s = T(0);
+        for (int j = 0; j < p; j++) {
+            b[i * LD + j] = (i == j) ? T(1) : T(0);
+            s += fabs(a[i * LD + j]);
+        }
+        anorm = (s > anorm || s != s) ? s : anorm;
+    }
+    bool bad = false;
+    for (int j = 0; j < p; j++) {
+        int jp = j;
+        T best = fabs(a[j * LD + j]);
+        for (int r = j + 1; r < p; r++)
+            if (fabs(a[r * LD + j]) > best) { best = fabs(a[r * LD + j]); jp = r; }
+        if (jp != j)
+            for (int c = 0; c < p; c++) {
+                T t = a[j * LD + c]; a[j * LD + c] = a[jp * LD + c]; a[jp * LD + c] = t;
+                t = b[j * LD + c]; b[j * LD + c] = b[jp * LD + c]; b[jp * LD + c] = t;
+            }
+        const T piv = a[j * LD + j];
+        bad = bad || (piv == T(0));
+        const T rp = T(1) / piv;
+        for (int r = j + 1; r < p; r++) {
+            const T l = a[r * LD + j] * rp;
+            for (int c = j + 1; c < p; c++) a[r * LD + c] -= l * a[j * LD + c];
+            for (int c = 0; c < p; c++) b[r * LD + c] -= l * b[j * LD + c];
+        }
+    }
+    T inorm = T(0);
+    for (int i = p - 1; i >= 0; i--) {
+        const T rd = T(1) / a[i * LD + i];
+        for (int c = 0; c < p; c++) {
+            T s = b[i * LD + c];
+            for (int k = i + 1; k < p; k++) s -= a[i * LD + k] * X[k * LD + c];
+            X[i * LD + c] = s * rd;
+        }
+    }
+    for (int i = 0; i < p; i++) {
+        T s = T(0);
+        for (int c = 0; c < p; c++) s += fabs(X[i * LD + c]);
+        inorm = (s > inorm || s != s) ? s : inorm;
+    }
+    const T cond = anorm * inorm;
+    return bad || !(cond <= T(1e16));
+}
+
+// ---------------------------------------------------------------------------
+// Counter-based RNG for AWGN (noise.go:109-164): Philox4x32-10.
+// key = (seed_lo, seed_hi); counter = (filter_lo, filter_hi, step, epoch<<8 | draw).
+// ---------------------------------------------------------------------------
+struct Philox {
+    uint32_t c[4];
+    __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+        const uint64_t p = (uint64_t)a * b;
+        hi = (uint32_t)(p >> 32);
+        lo = (uint32_t)p;
+    }
+    __host__ __device__ static inline void round4(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo(0xD2511F53u, c[0], hi0, lo0);
+        mulhilo(0xCD9E8D57u, c[2], hi1, lo1);
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __host__ __device__ static inline void gen(uint64_t seed, uint64_t filter, uint32_t step, uint32_t stream, uint32_t (&out)[4]) {
+        uint32_t c[4] = {(uint32_t)filter, (uint32_t)(filter >> 32), step, stream};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            round4(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+
+// two standard normals from one Philox block (Box-Muller on two 53-bit... here 32-bit uniforms each
+// widened to (0,1] doubles with 32 bits of resolution per uniform; two u32 per uniform -> 53 bits)
+__host__ __device__ inline void box_muller(const uint32_t (&r)[4], double &z0, double &z1) {
+    const double two53 = 1.0 / 9007199254740992.0;
+    const uint64_t a = (((uint64_t)r[0] << 32) | r[1]) >> 11;
+    const uint64_t b = (((uint64_t)r[2] << 32) | r[3]) >> 11;
+    const double u1 = ((double)a + 1.0) * two53;  // (0,1]
+    const double u2 = (double)b * two53;          // [0,1)
+    const double rad = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    z0 = rad * cos(ang);
+    z1 = rad * sin(ang);
+}
+
+// standard normal number `k` (k = 0,1,2,...) of the vector drawn by filter `filter` at (step, stream)
+__host__ __device__ inline double normal_at(uint64_t seed, uint64_t filter, uint32_t step, uint32_t stream, int k) {
+    uint32_t r[4];
+    Philox::gen(seed, filter, step, (stream << 8) | (uint32_t)(k >> 1), r);
+    double z0, z1;
+    box_muller(r, z0, z1);
+    return (k & 1) ? z1 : z0;
+}
+
+}  // namespace kb

@@ -1,0 +1,122 @@
+// kb_internal.h -- host-side handle, HBM layout description and kernel launch entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/gokalman_amd.h"
+#include "kb_device.h"
+
+namespace kb {
+
+// ---------------------------------------------------------------------------
+// HBM layout of one batch (all blocks AoSoA-64, see kb_device.h).
+//
+//   state block : raw vector [n] | raw matrix (packed sym or full, per kind)
+//   pred  block : predicted matrix (P- / S- / I- / Rbar)        -- kinds that keep it
+//   est   block : P- (packed) | K [n][pmax] | innovation [pmax] | yhat [pmax]   (FULL_ESTIMATE)
+//   model block : F [n*n] | H [pmax*n] | Q packed | R packed(pmax) | G [n*m] | kind-specific
+// ---------------------------------------------------------------------------
+struct Layout {
+    int n = 0, pmax = 0, m = 0;
+    // state block
+    int st_vec = 0, st_mat = 0, st_elems = 0;
+    bool st_mat_full = false;  // full n*n (S, R factors) vs packed symmetric
+    // est block
+    int es_ppred = 0, es_gain = 0, es_innov = 0, es_yhat = 0, es_dobs = 0, es_elems = 0;
+    // model block
+    int mo_F = 0, mo_H = 0, mo_Q = 0, mo_R = 0, mo_G = 0;
+    // derived (constructor / SetNoise / SetStateTransition products)
+    int mo_LQ = 0, mo_LR = 0;                   // chol_L(Q) packed [tri(n)], chol_L(R) packed [tri(pmax)]  (AWGN, SQUAREROOT, SRIF)
+    int mo_Finv = 0, mo_Qinv = 0, mo_Rinv = 0;  // INFORMATION: full n*n, n*n, pmax*pmax
+    int nq = 0;                                  // HYBRID: dimension of the SNC noise (Q is q x q, Gamma n x q)
+    int mo_elems = 0;
+};
+
+struct Batch {
+    int kind = 0, n = 0, pmax = 0, p = 0, m = 0, dtype = 0, device = 0;
+    unsigned flags = 0;
+    int64_t N = 0, ntiles = 0;
+    Layout L;
+    hipStream_t stream = nullptr;
+    void *d_state = nullptr, *d_state0 = nullptr;  // current / initial estimate
+    void *d_pred = nullptr, *d_pred0 = nullptr;
+    void *d_est = nullptr;
+    void *d_model = nullptr;
+    uint32_t *d_status = nullptr;
+    void *d_stage = nullptr;   // AoS staging for host <-> device transfers
+    size_t stage_bytes = 0;
+    void *d_y = nullptr, *d_u = nullptr;  // AoSoA staging of host measurements / controls
+    void *d_y2 = nullptr;
+    double *d_mc = nullptr; size_t mc_bytes = 0;
+    bool initialized = false;
+    bool have[8] = {false, false, false, false, false, false, false, false};  // KB_X..KB_R staged
+    int need_ctrl = 0;
+    int64_t step = 0;
+    int rinv_p = 0;        // KB_INFORMATION: dimension R^-1 was computed for (stale-Rinv quirk)
+    int sqrt_p = 0;        // KB_SQUAREROOT: dimension of chol(R)
+    // NLDKF
+    int ekf = 0, locked = 1, snc = 0;
+    // noise
+    int noise_kind = KB_NOISE_NOISELESS;
+    uint64_t seed = 0;
+    int64_t epoch = 0;
+    size_t esize() const { return dtype == KB_F64 ? 8 : 4; }
+    size_t block_bytes(int elems) const { return (size_t)ntiles * KB_TILE * (size_t)elems * esize(); }
+};
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+#define KB_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return ::kb::hip_fail(e__, #call);             \
+    } while (0)
+
+// Arguments common to the step kernels (kept POD so it travels as kernarg).
+struct StepArgs {
+    void *state, *pred, *est, *model;
+    uint32_t *status;
+    const void *y; int64_t y_es, y_ts, y_step;   // element stride, tile stride, step stride (elements)
+    const void *y2; int64_t y2_es, y2_ts;        // NLDKF: computed observation
+    const void *u; int64_t u_es, u_ts, u_step;
+    int64_t N, ntiles;
+    int nsteps;
+    int n, p, m, pmax;
+    Layout L;
+    unsigned flags;
+    int need_ctrl;
+    int rinv_p, sqrt_p;
+    int ekf, snc, predict;
+    int noise_kind; uint64_t seed; int64_t epoch; int64_t step0; int64_t first_filter;
+};
+
+// kb_pack.hip
+int launch_pack(const Batch &b, const void *src_aos, int src_elems, int64_t count, bool broadcast,
+                void *dst_block, int dst_elems, const int16_t *map /* [src_elems] -> dst elem or -1 */);
+int launch_unpack(const Batch &b, const void *src_block, int src_elems, const int16_t *map /* [dst_elems] -> src elem or -1 (0.0) */,
+                  int dst_elems, double *dst_aos, int64_t first, int64_t count);
+int launch_unpack_planar(const Batch &b, const void *src_block, int src_elems, const int16_t *map, int dst_elems,
+                         void *dst, int64_t ld);
+int launch_pack_u(const Batch &b);
+
+// kb_vanilla.hip
+int launch_vanilla(const Batch &b, const StepArgs &a, bool fused);
+// kb_getters.hip (materialise State/Covariance for the kinds with a lazy getter)
+int launch_materialise(const Batch &b, const void *state_block, bool pred, void *out_block /* x[n] | P packed */);
+int launch_within_nsigma(const Batch &b, const void *xp_block, double nsigma, uint8_t *d_out);
+// kb_init.hip (constructor arithmetic per kind)
+int launch_init(Batch &b, int *not_pd);
+int launch_refresh(Batch &b, int field, int *not_pd);
+// other kinds
+int launch_squareroot(const Batch &b, const StepArgs &a);
+int launch_information(const Batch &b, const StepArgs &a);
+int launch_srif(const Batch &b, const StepArgs &a);
+int launch_hybrid(const Batch &b, const StepArgs &a);
+int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums);
+
+inline dim3 tile_grid(int64_t ntiles) { return dim3((unsigned)((ntiles + 3) / 4)); }
+
+}  // namespace kb
+
+struct kb_batch : kb::Batch {};

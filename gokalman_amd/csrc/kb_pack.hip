@@ -1,0 +1,103 @@
+// kb_pack.hip -- host-layout (per-filter row-major) <-> AoSoA-64 block transposition.
+// Set-up / read-back path only; the step kernels never touch the host layout.
+#include "kb_internal.h"
+
+namespace kb {
+
+struct MapArg { int16_t m[KB_MAX_DIM * KB_MAX_DIM]; };
+
+// src: AoS [count][src_elems] (always float64, converted to T here), one thread per filter.  dst elem = map[e] (or skip if < 0).
+template <typename T>
+__global__ void pack_kernel(const double *__restrict__ src, int src_elems, int broadcast, int64_t N,
+                            T *__restrict__ dst, int dst_elems, MapArg map) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double *s = src + (broadcast ? 0 : i * src_elems);
+    T *d = dst + (i / KB_TILE) * ((int64_t)KB_TILE * dst_elems) + (i % KB_TILE);
+    for (int e = 0; e < src_elems; e++) {
+        const int de = map.m[e];
+        if (de >= 0) d[(int64_t)de * KB_TILE] = (T)s[e];
+    }
+}
+
+// dst: AoS double [count][dst_elems]; src elem = map[e] (or 0.0 if < 0)
+template <typename T>
+__global__ void unpack_kernel(const T *__restrict__ src, int src_elems, int64_t first, int64_t count,
+                              double *__restrict__ dst, int dst_elems, MapArg map) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t i = first + k;
+    const T *s = src + (i / KB_TILE) * ((int64_t)KB_TILE * src_elems) + (i % KB_TILE);
+    double *d = dst + k * dst_elems;
+    for (int e = 0; e < dst_elems; e++) {
+        const int se = map.m[e];
+        d[e] = se >= 0 ? (double)s[(int64_t)se * KB_TILE] : 0.0;
+    }
+}
+
+template <typename T>
+__global__ void unpack_planar_kernel(const T *__restrict__ src, int src_elems, int64_t N,
+                                     T *__restrict__ dst, int64_t ld, int dst_elems, MapArg map) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const T *s = src + (i / KB_TILE) * ((int64_t)KB_TILE * src_elems) + (i % KB_TILE);
+    for (int e = 0; e < dst_elems; e++) {
+        const int se = map.m[e];
+        dst[(int64_t)e * ld + i] = se >= 0 ? s[(int64_t)se * KB_TILE] : T(0);
+    }
+}
+
+static MapArg make_map(const int16_t *map, int n) {
+    MapArg m;
+    for (int i = 0; i < KB_MAX_DIM * KB_MAX_DIM; i++) m.m[i] = i < n ? map[i] : (int16_t)-1;
+    return m;
+}
+
+int launch_pack(const Batch &b, const void *src_aos, int src_elems, int64_t count, bool broadcast,
+                void *dst_block, int dst_elems, const int16_t *map) {
+    (void)count;
+    const MapArg m = make_map(map, src_elems);
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((b.N + threads - 1) / threads);
+    if (b.dtype == KB_F64)
+        hipLaunchKernelGGL(pack_kernel<double>, dim3(blocks), dim3(threads), 0, b.stream, (const double *)src_aos,
+                           src_elems, broadcast ? 1 : 0, b.N, (double *)dst_block, dst_elems, m);
+    else
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(threads), 0, b.stream, (const double *)src_aos,
+                           src_elems, broadcast ? 1 : 0, b.N, (float *)dst_block, dst_elems, m);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+int launch_unpack(const Batch &b, const void *src_block, int src_elems, const int16_t *map, int dst_elems,
+                  double *dst_aos, int64_t first, int64_t count) {
+    const MapArg m = make_map(map, dst_elems);
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((count + threads - 1) / threads);
+    if (count <= 0) return KB_OK;
+    if (b.dtype == KB_F64)
+        hipLaunchKernelGGL(unpack_kernel<double>, dim3(blocks), dim3(threads), 0, b.stream, (const double *)src_block,
+                           src_elems, first, count, dst_aos, dst_elems, m);
+    else
+        hipLaunchKernelGGL(unpack_kernel<float>, dim3(blocks), dim3(threads), 0, b.stream, (const float *)src_block,
+                           src_elems, first, count, dst_aos, dst_elems, m);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+int launch_unpack_planar(const Batch &b, const void *src_block, int src_elems, const int16_t *map, int dst_elems,
+                         void *dst, int64_t ld) {
+    const MapArg m = make_map(map, dst_elems);
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((b.N + threads - 1) / threads);
+    if (b.dtype == KB_F64)
+        hipLaunchKernelGGL(unpack_planar_kernel<double>, dim3(blocks), dim3(threads), 0, b.stream,
+                           (const double *)src_block, src_elems, b.N, (double *)dst, ld, dst_elems, m);
+    else
+        hipLaunchKernelGGL(unpack_planar_kernel<float>, dim3(blocks), dim3(threads), 0, b.stream,
+                           (const float *)src_block, src_elems, b.N, (float *)dst, ld, dst_elems, m);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+}  // namespace kb

@@ -1,0 +1,544 @@
+// kb_vanilla.hip -- Vanilla / pure-predictor Vanilla step kernels (vanilla.go:128-220).
+//
+// Two implementations of the same arithmetic:
+//   vanilla_reg_kernel : dimensions are template parameters, every matrix lives in
+//                        VGPRs, all loops fully unrolled.  HBM-bound: per filter-step it
+//                        streams x, P(packed), F, H, Q(packed), R(packed), y in and x, P out.
+//   vanilla_gen_kernel : run-time dimensions (n, p, m <= 16), per-lane private arrays.
+//                        Covers every other shape, STRICT_SYMCHECK and AWGN noise.
+// One filter per lane, one tile of 64 filters per wavefront (kb_device.h).
+//
+// Operation order follows the reference: x- = F x [+ G u] + w; P- = F P F^T + Q;
+// yhat = H x_prev + v; K = P- H^T (H P- H^T + R)^-1 with an LU-pivoted explicit inverse;
+// innov = y - H x-; x+ = x- + K innov + w'; Joseph form P+ = (I-KH) P- (I-KH)^T + K R K^T;
+// "symmetrisation" = keep the upper triangle (AsSymDense, helper.go:65-84).
+// A filter whose S is singular / ill-conditioned or whose result is non-finite keeps its
+// previous estimate and gets a status bit, as the reference's (nil, err) return does.
+#include "kb_internal.h"
+
+namespace kb {
+
+template <typename T>
+__device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+template <typename T>
+__device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+
+// ---------------------------------------------------------------------------------
+// register-resident kernel
+// ---------------------------------------------------------------------------------
+template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED>
+__global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
+    constexpr int TR = tri(NS);
+    constexpr int TM = tri(NM);
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const bool active = tile * KB_TILE + lane < a.N;
+
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *yp = (const T *)a.y + tile * a.y_ts + lane;
+    const T *up = NC > 0 ? (const T *)a.u + tile * a.u_ts + lane : nullptr;
+
+    // ---- state + transition model
+    T x[NS], P[TR], F[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
+#pragma unroll
+    for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) F[e] = ldt(mo, a.L.mo_F + e);
+
+    [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1];
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int e = 0; e < NM * NS; e++) H[e] = ldt(mo, a.L.mo_H + e);
+#pragma unroll
+        for (int e = 0; e < TR; e++) Q[e] = ldt(mo, a.L.mo_Q + e);
+#pragma unroll
+        for (int e = 0; e < TM; e++) R[e] = ldt(mo, a.L.mo_R + e);
+        if constexpr (NC > 0) {
+#pragma unroll
+            for (int e = 0; e < NS * NC; e++) G[e] = ldt(mo, a.L.mo_G + e);
+        }
+    }
+
+    unsigned err_acc = 0;
+    const int nsteps = FUSED ? a.nsteps : 1;
+    for (int t = 0; t < nsteps; t++) {
+        // ---- x- = F x [+ G u]
+        T xm[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += F[i * NS + l] * x[l];
+            xm[i] = s;
+        }
+        if constexpr (NC > 0) {
+            T u[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) u[c] = active ? up[(int64_t)t * a.u_step + (int64_t)c * a.u_es] : T(0);
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T s = T(0);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const T g = FUSED ? G[i * NC + c] : ldt(mo, a.L.mo_G + i * NC + c);
+                    s += g * u[c];
+                }
+                xm[i] = xm[i] + s;
+            }
+        }
+        // ---- P- = F P F^T + Q   (upper triangle; row i of F P, then dot with rows j >= i of F)
+        T Pm[TR];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T fp[NS];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += F[i * NS + l] * P[symi(l, k)];
+                fp[k] = s;
+            }
+#pragma unroll
+            for (int j = i; j < NS; j++) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
+                const T q = FUSED ? Q[symi(i, j)] : ldt(mo, a.L.mo_Q + symi(i, j));
+                Pm[symi(i, j)] = s + q;
+            }
+        }
+        // ---- measurement model
+        if constexpr (!FUSED) {
+#pragma unroll
+            for (int e = 0; e < NM * NS; e++) H[e] = ldt(mo, a.L.mo_H + e);
+#pragma unroll
+            for (int e = 0; e < TM; e++) R[e] = ldt(mo, a.L.mo_R + e);
+        }
+        // ---- yhat = H x_prev (previous posterior, vanilla.go:155-157)
+        [[maybe_unused]] T yhat[NM];
+        if constexpr (FULL) {
+#pragma unroll
+            for (int r = 0; r < NM; r++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += H[r * NS + l] * x[l];
+                yhat[r] = s;
+            }
+        }
+        // ---- gain K = P- H^T (H P- H^T + R)^-1
+        T PHt[NS * NM];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += Pm[symi(i, l)] * H[c * NS + l];
+                PHt[i * NM + c] = s;
+            }
+        T S[NM * NM], Si[NM * NM];
+#pragma unroll
+        for (int r = 0; r < NM; r++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
+                S[r * NM + c] = s + R[symi(r, c)];
+            }
+        unsigned err = inverse_lu<T, NM>(S, Si) ? KB_ST_SINGULAR : 0u;
+        T K[NS * NM];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < NM; k++) s += PHt[i * NM + k] * Si[k * NM + c];
+                K[i * NM + c] = s;
+            }
+
+        T xn[NS], Pn[TR];
+        [[maybe_unused]] T innov[NM];
+        if constexpr (PREDICT) {
+            // vanilla.go:170-179: estimate = {x-, yhat, 0, sym(P-), sym(P-), K}
+#pragma unroll
+            for (int i = 0; i < NS; i++) xn[i] = xm[i];
+#pragma unroll
+            for (int e = 0; e < TR; e++) Pn[e] = Pm[e];
+#pragma unroll
+            for (int r = 0; r < NM; r++) innov[r] = T(0);
+        } else {
+            // ---- innovation and state update
+#pragma unroll
+            for (int r = 0; r < NM; r++) {
+                const T yv = active ? yp[(int64_t)t * a.y_step + (int64_t)r * a.y_es] : T(0);
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
+                innov[r] = yv - s;
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T s = T(0);
+#pragma unroll
+                for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
+                xn[i] = xm[i] + s;
+            }
+            // ---- Joseph form, upper triangle: P+ = K R K^T + A P- A^T,  A = I - K H
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T kr[NM];
+#pragma unroll
+                for (int c = 0; c < NM; c++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
+                    kr[c] = s;
+                }
+#pragma unroll
+                for (int j = i; j < NS; j++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
+                    Pn[symi(i, j)] = s;
+                }
+            }
+            T A[NS * NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
+                    A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
+                }
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T ap[NS];
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
+                    ap[k] = s;
+                }
+#pragma unroll
+                for (int j = i; j < NS; j++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
+                    Pn[symi(i, j)] = s + Pn[symi(i, j)];
+                }
+            }
+        }
+        // ---- non-finite screen (stands in for AsSymDense's NaN-failing comparison)
+        T chk = T(0);
+#pragma unroll
+        for (int i = 0; i < NS; i++) chk += xn[i] * T(0);
+#pragma unroll
+        for (int e = 0; e < TR; e++) chk += Pn[e] * T(0);
+        if (chk != chk) err |= KB_ST_NONFINITE;
+        if (err_acc) err = 0;  // already frozen: keep the first failure only
+        const bool ok = (err | err_acc) == 0;
+        err_acc |= err;
+
+        if constexpr (FULL) {
+            // Estimate extras of this step (only meaningful for the last fused step)
+            if (active && ok) {
+                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+#pragma unroll
+                for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
+#pragma unroll
+                for (int i = 0; i < NS; i++)
+#pragma unroll
+                    for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+#pragma unroll
+                for (int r = 0; r < NM; r++) {
+                    stt(es, a.L.es_innov + r, innov[r]);
+                    stt(es, a.L.es_yhat + r, yhat[r]);
+                }
+            }
+        }
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) x[i] = ok ? xn[i] : x[i];
+#pragma unroll
+            for (int e = 0; e < TR; e++) P[e] = ok ? Pn[e] : P[e];
+        } else {
+            if (active && ok) {
+#pragma unroll
+                for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
+#pragma unroll
+                for (int e = 0; e < TR; e++) stt(st, NS + e, Pn[e]);
+            }
+        }
+    }
+    if constexpr (FUSED) {
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) stt(st, i, x[i]);
+#pragma unroll
+            for (int e = 0; e < TR; e++) stt(st, NS + e, P[e]);
+        }
+    }
+    if (active && err_acc) atomicOr(a.status + tile * KB_TILE + lane, err_acc);
+}
+
+// ---------------------------------------------------------------------------------
+// generic run-time-dimension kernel (private arrays with leading dimension LD)
+// ---------------------------------------------------------------------------------
+template <typename T, int LD>
+__global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    if (fi >= a.N) return;
+    const int n = a.n, p = a.p, m = a.m;
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    const bool strict = (a.flags & KB_FLAG_STRICT_SYMCHECK) != 0;
+    const bool awgn = a.noise_kind == KB_NOISE_AWGN;
+
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * a.L.st_elems) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *yp = a.y ? (const T *)a.y + tile * a.y_ts + lane : nullptr;
+    const T *up = a.u ? (const T *)a.u + tile * a.u_ts + lane : nullptr;
+
+    T x[LD], P[LD * LD], F[LD * LD], H[LD * LD], Q[LD * LD], R[LD * LD];
+    for (int i = 0; i < n; i++) x[i] = ldt(st, a.L.st_vec + i);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            P[i * LD + j] = ldt(st, a.L.st_mat + symi(i, j));
+            F[i * LD + j] = ldt(mo, a.L.mo_F + i * n + j);
+            Q[i * LD + j] = ldt(mo, a.L.mo_Q + symi(i, j));
+        }
+    for (int r = 0; r < p; r++) {
+        for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
+        for (int c = 0; c < p; c++) R[r * LD + c] = ldt(mo, a.L.mo_R + symi(r, c));
+    }
+    unsigned err_acc = 0;
+    for (int t = 0; t < a.nsteps; t++) {
+        const uint32_t stepno = (uint32_t)(a.step0 + t);
+        // x- = F x [+ G u] + w
+        T xm[LD];
+        for (int i = 0; i < n; i++) {
+            T s = T(0);
+            for (int l = 0; l < n; l++) s += F[i * LD + l] * x[l];
+            xm[i] = s;
+        }
+        if (a.need_ctrl) {
+            for (int i = 0; i < n; i++) {
+                T s = T(0);
+                for (int c = 0; c < m; c++)
+                    s += ldt(mo, a.L.mo_G + i * m + c) * up[(int64_t)t * a.u_step + (int64_t)c * a.u_es];
+                xm[i] = xm[i] + s;
+            }
+        }
+        if (awgn) {  // Noise.Process(k): w = L_Q z  (noise.go:133-136)
+            T z[LD];
+            for (int k = 0; k < n; k++) z[k] = (T)normal_at(a.seed, (uint64_t)(a.first_filter + fi), stepno, (uint32_t)(a.epoch * 4 + 0), k);
+            for (int i = 0; i < n; i++) {
+                T s = T(0);
+                for (int k = 0; k <= i; k++) s += ldt(mo, a.L.mo_LQ + symi(k, i)) * z[k];
+                xm[i] += s;
+            }
+        }
+        // P- = F P F^T + Q (full matrix, as the reference computes it)
+        T FP[LD * LD], Pm[LD * LD];
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < n; k++) {
+                T s = T(0);
+                for (int l = 0; l < n; l++) s += F[i * LD + l] * P[l * LD + k];
+                FP[i * LD + k] = s;
+            }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                T s = T(0);
+                for (int k = 0; k < n; k++) s += FP[i * LD + k] * F[j * LD + k];
+                Pm[i * LD + j] = s + Q[i * LD + j];
+            }
+        // yhat = H x_prev + v
+        T yhat[LD];
+        for (int r = 0; r < p; r++) {
+            T s = T(0);
+            for (int l = 0; l < n; l++) s += H[r * LD + l] * x[l];
+            yhat[r] = s;
+        }
+        if (awgn) {
+            T z[LD];
+            for (int k = 0; k < p; k++) z[k] = (T)normal_at(a.seed, (uint64_t)(a.first_filter + fi), stepno, (uint32_t)(a.epoch * 4 + 1), k);
+            for (int r = 0; r < p; r++) {
+                T s = T(0);
+                for (int k = 0; k <= r; k++) s += ldt(mo, a.L.mo_LR + symi(k, r)) * z[k];
+                yhat[r] += s;
+            }
+        }
+        // gain
+        T PHt[LD * LD], S[LD * LD], Si[LD * LD], K[LD * LD];
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < p; c++) {
+                T s = T(0);
+                for (int l = 0; l < n; l++) s += Pm[i * LD + l] * H[c * LD + l];
+                PHt[i * LD + c] = s;
+            }
+        for (int r = 0; r < p; r++)
+            for (int c = 0; c < p; c++) {
+                T s = T(0);
+                for (int i = 0; i < n; i++) s += H[r * LD + i] * PHt[i * LD + c];
+                S[r * LD + c] = s + R[r * LD + c];
+            }
+        unsigned err = inverse_lu_rt<T, LD>(p, S, Si) ? KB_ST_SINGULAR : 0u;
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < p; c++) {
+                T s = T(0);
+                for (int k = 0; k < p; k++) s += PHt[i * LD + k] * Si[k * LD + c];
+                K[i * LD + c] = s;
+            }
+        T xn[LD], Pn[LD * LD], innov[LD];
+        if (a.predict) {
+            for (int i = 0; i < n; i++) xn[i] = xm[i];
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) Pn[i * LD + j] = Pm[i * LD + j];
+            for (int r = 0; r < p; r++) innov[r] = T(0);
+        } else {
+            for (int r = 0; r < p; r++) {
+                T s = T(0);
+                for (int l = 0; l < n; l++) s += H[r * LD + l] * xm[l];
+                innov[r] = yp[(int64_t)t * a.y_step + (int64_t)r * a.y_es] - s;
+            }
+            for (int i = 0; i < n; i++) {
+                T s = T(0);
+                for (int c = 0; c < p; c++) s += K[i * LD + c] * innov[c];
+                xn[i] = xm[i] + s;
+            }
+            if (awgn) {  // second Noise.Process(k) (vanilla.go:195)
+                T z[LD];
+                for (int k = 0; k < n; k++) z[k] = (T)normal_at(a.seed, (uint64_t)(a.first_filter + fi), stepno, (uint32_t)(a.epoch * 4 + 2), k);
+                for (int i = 0; i < n; i++) {
+                    T s = T(0);
+                    for (int k = 0; k <= i; k++) s += ldt(mo, a.L.mo_LQ + symi(k, i)) * z[k];
+                    xn[i] += s;
+                }
+            }
+            T A[LD * LD], AP[LD * LD], KR[LD * LD];
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) {
+                    T s = T(0);
+                    for (int c = 0; c < p; c++) s += K[i * LD + c] * H[c * LD + j];
+                    A[i * LD + j] = (i == j ? T(1) : T(0)) - s;
+                }
+            for (int i = 0; i < n; i++)
+                for (int k = 0; k < n; k++) {
+                    T s = T(0);
+                    for (int l = 0; l < n; l++) s += A[i * LD + l] * Pm[l * LD + k];
+                    AP[i * LD + k] = s;
+                }
+            for (int i = 0; i < n; i++)
+                for (int c = 0; c < p; c++) {
+                    T s = T(0);
+                    for (int k = 0; k < p; k++) s += K[i * LD + k] * R[k * LD + c];
+                    KR[i * LD + c] = s;
+                }
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) {
+                    T s = T(0);
+                    for (int k = 0; k < n; k++) s += AP[i * LD + k] * A[j * LD + k];
+                    T s2 = T(0);
+                    for (int c = 0; c < p; c++) s2 += KR[i * LD + c] * K[j * LD + c];
+                    Pn[i * LD + j] = s + s2;
+                }
+        }
+        // AsSymDense on P- and P+ (helper.go:65-84): strict = the reference's tolerance test,
+        // default = non-finite screen.  Predict-only ignores the error (vanilla.go:173).
+        bool finite = true;
+        for (int i = 0; i < n; i++) finite = finite && (xn[i] * T(0) == T(0));
+        for (int i = 0; i < n; i++)
+            for (int j = i; j < n; j++) finite = finite && (Pn[i * LD + j] * T(0) == T(0));
+        if (!finite) err |= KB_ST_NONFINITE;
+        if (strict && !a.predict) {
+            bool sym = true;
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++)
+                    if (i != j) {
+                        sym = sym && sym_close(Pm[j * LD + i], Pm[i * LD + j]);
+                        sym = sym && sym_close(Pn[j * LD + i], Pn[i * LD + j]);
+                    }
+            if (!sym) err |= KB_ST_ASYMMETRIC;
+        }
+        if (err_acc) err = 0;
+        const bool ok = (err | err_acc) == 0;
+        err_acc |= err;
+        if (ok) {
+            if (full) {
+                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+                for (int i = 0; i < n; i++)
+                    for (int j = i; j < n; j++) stt(es, a.L.es_ppred + symi(i, j), Pm[i * LD + j]);
+                for (int i = 0; i < n; i++)
+                    for (int c = 0; c < p; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * LD + c]);
+                for (int r = 0; r < p; r++) {
+                    stt(es, a.L.es_innov + r, innov[r]);
+                    stt(es, a.L.es_yhat + r, yhat[r]);
+                }
+            }
+            for (int i = 0; i < n; i++) x[i] = xn[i];
+            for (int i = 0; i < n; i++)
+                for (int j = i; j < n; j++) { P[i * LD + j] = Pn[i * LD + j]; P[j * LD + i] = Pn[i * LD + j]; }
+        }
+    }
+    for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, x[i]);
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), P[i * LD + j]);
+    if (err_acc) atomicOr(a.status + fi, err_acc);
+}
+
+// ---------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------
+template <typename T, int NS, int NM, int NC>
+static bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
+    if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC) return false;
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    const dim3 grid = tile_grid(a.ntiles), block(256);
+#define KB_GO(FULL_, PRED_, FUSED_) \
+    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_>), grid, block, 0, b.stream, a)
+    if (a.predict) {
+        if (full) { if (fused) KB_GO(true, true, true); else KB_GO(true, true, false); }
+        else      { if (fused) KB_GO(false, true, true); else KB_GO(false, true, false); }
+    } else {
+        if (full) { if (fused) KB_GO(true, false, true); else KB_GO(true, false, false); }
+        else      { if (fused) KB_GO(false, false, true); else KB_GO(false, false, false); }
+    }
+#undef KB_GO
+    return true;
+}
+
+template <typename T>
+static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
+    const bool special = !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS;
+    bool done = false;
+    if (special) {
+        done = try_reg<T, 6, 3, 0>(b, a, fused) || try_reg<T, 4, 2, 0>(b, a, fused);
+    }
+    if (!done) {
+        const int d = a.n > a.p ? (a.n > a.m ? a.n : a.m) : (a.p > a.m ? a.p : a.m);
+        const dim3 grid((unsigned)a.ntiles), block(64);
+        if (d <= 4) hipLaunchKernelGGL((vanilla_gen_kernel<T, 4>), grid, block, 0, b.stream, a);
+        else if (d <= 8) hipLaunchKernelGGL((vanilla_gen_kernel<T, 8>), grid, block, 0, b.stream, a);
+        else hipLaunchKernelGGL((vanilla_gen_kernel<T, 16>), grid, block, 0, b.stream, a);
+    }
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+int launch_vanilla(const Batch &b, const StepArgs &a, bool fused) {
+    if (b.dtype == KB_F64) return launch_vanilla_t<double>(b, a, fused);
+    return launch_vanilla_t<float>(b, a, fused);
+}
+
+}  // namespace kb

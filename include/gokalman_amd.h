@@ -1,0 +1,230 @@
+/*
+ * gokalman_amd.h -- C ABI of the MI355X-native batched Kalman engine.
+ *
+ * This is the drop-in boundary for gokalman's predict/update hot path.  The
+ * reference has no FFI of its own: its seam is the Go interfaces LDKF / NLDKF /
+ * Estimate (kalman.go:35-72), Noise (noise.go:13-20) and the constructors.  A
+ * cgo shim (go/gokalman_amd.go) implements those interfaces by
+ * binding exactly the entry points declared here; each entry point cites the
+ * reference method it replaces.
+ *
+ * One `kb_batch` = N independent filters of one kind and one shape resident in
+ * the HBM of one MI355X.  A reference filter object is a batch with N == 1; the
+ * reference's caller loop over many filter objects is a batch with N == many.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types.
+ *  - HOST arrays are per-filter row-major ("AoS"): a field with E elements per
+ *    filter is `[count][E]` (count == N, or 1 when `broadcast` != 0).  Symmetric
+ *    matrices (P, Q, R) are passed and returned as FULL n x n row-major; only the
+ *    upper triangle is read (mat64.SymDense semantics, helper.go:65-84).
+ *  - DEVICE arrays handed to the `*_dev` entry points are planar ("SoA"):
+ *    element e of filter i at `ptr[e * ld + i]`, `ld >= N` given by the caller.
+ *  - every function returns KB_OK (0) or a negative kb_status; kb_last_error()
+ *    gives the thread-local message (for dimension errors, the reference's own
+ *    "dimensions must agree: ..." string, helper.go:99-130).
+ *  - numerical failures never abort a batch: they set bits in a per-filter
+ *    status word (kb_get_status) and leave that filter's estimate untouched, as
+ *    the reference does when Update returns (nil, err).
+ *  - a handle is not thread-safe (neither is a reference filter); distinct
+ *    handles may be driven from distinct threads.  All work is enqueued on the
+ *    handle's HIP stream; host-facing calls synchronise that stream before
+ *    returning, `*_dev` calls do not.
+ *  - there is NO CPU fallback: every entry point that touches filter data
+ *    returns KB_ERR_NO_DEVICE when no gfx950 device is visible.
+ */
+#ifndef GOKALMAN_AMD_H
+#define GOKALMAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KB_MAX_DIM 16 /* max state / measurement / control dimension */
+
+typedef struct kb_batch kb_batch;
+
+/* Filter kinds = the reference's constructors. */
+typedef enum {
+    KB_VANILLA = 1,         /* NewVanilla               vanilla.go:21-40      */
+    KB_VANILLA_PREDICT = 2, /* NewPurePredictorVanilla  vanilla.go:43-62      */
+    KB_SQUAREROOT = 3,      /* NewSquareRoot            squareroot.go:21-50   */
+    KB_INFORMATION = 4,     /* NewInformation / NewInformationFromState information.go:20-81 */
+    KB_SRIF = 5,            /* NewSRIF                  srif.go:14-49         */
+    KB_HYBRID = 6           /* NewHybridKF              hybrid.go:23-34       */
+} kb_kind;
+
+typedef enum { KB_F64 = 0, KB_F32 = 1 } kb_dtype;
+
+/* kb_create flags */
+#define KB_FLAG_FULL_ESTIMATE 0x1u /* materialise every Estimate member each step (P-, K, innovation, yhat); off = state-only outputs (x+, P+) */
+#define KB_FLAG_STRICT_SYMCHECK 0x2u /* compute both triangles and run AsSymDense's |M_ij-M_ji| test (helper.go:75) instead of the non-finite test */
+#define KB_FLAG_INFO_FROM_STATE 0x4u /* KB_INFORMATION: X/P given to kb_set are (x0,P0) as in NewInformationFromState, not (i0,I0) */
+#define KB_FLAG_SRIF_NON_TRI_R 0x8u  /* NewSRIF(nonTriR = true) (srif.go:13); both settings run the same arithmetic, see srif.go:121-132 */
+
+typedef enum {
+    KB_OK = 0,
+    KB_ERR_INVALID = -1,     /* bad argument / call order                      */
+    KB_ERR_DIMS = -2,        /* "dimensions must agree: ..." (helper.go:99-130) */
+    KB_ERR_NO_DEVICE = -3,   /* no MI355X visible; there is no CPU fallback     */
+    KB_ERR_HIP = -4,         /* a HIP runtime call failed                       */
+    KB_ERR_UNSUPPORTED = -5, /* shape/kind/dtype combination has no kernel      */
+    KB_ERR_LOCKED = -6,      /* "kf is locked (call Prepare() first)" srif.go:102, hybrid.go:105 */
+    KB_ERR_NOT_PD = -7       /* Cholesky of a non positive definite matrix at construction / SetNoise */
+} kb_status;
+
+/* Per-filter status bits (sticky until kb_reset / kb_clear_status). */
+#define KB_ST_SINGULAR 0x1u   /* inverse failed or cond > 1e16: vanilla.go:164-167, hybrid.go:150-152, srif.go:112-114 */
+#define KB_ST_ASYMMETRIC 0x2u /* AsSymDense failure: vanilla.go:207-215, information.go:214-222 (a panic there)        */
+#define KB_ST_NONFINITE 0x4u  /* NaN/Inf reached the estimate                                                          */
+#define KB_ST_INFO_NOT_INVERTIBLE 0x8u /* getter-side: information/SRIF matrix not (yet) invertible, covariance reported as zeros (information.go:284-288) */
+
+/* Fields for kb_set / kb_get. */
+typedef enum {
+    /* inputs (constructor arguments and Set* of kalman.go:35-47) */
+    KB_X = 0,        /* x0 [n]       (KB_INFORMATION without INFO_FROM_STATE: i0)  */
+    KB_P = 1,        /* P0 [n][n]    (KB_INFORMATION without INFO_FROM_STATE: I0)  */
+    KB_F = 2,        /* F  [n][n]    SetStateTransition                            */
+    KB_G = 3,        /* G  [n][m]    SetInputControl                               */
+    KB_H = 4,        /* H  [p][n]    SetMeasurementMatrix                          */
+    KB_Q = 5,        /* Q  [n][n]    Noise.ProcessMatrix  (KB_HYBRID: [q][q])       */
+    KB_R = 6,        /* R  [p][p]    Noise.MeasurementMatrix                        */
+    /* outputs = the Estimate interface (kalman.go:64-72) */
+    KB_STATE = 16,       /* Estimate.State()          [n]                           */
+    KB_COVAR = 17,       /* Estimate.Covariance()     [n][n] full symmetric         */
+    KB_PRED_COVAR = 18,  /* Estimate.PredCovariance() [n][n] (needs FULL_ESTIMATE, except SQRT/INFO/SRIF which keep it) */
+    KB_GAIN = 19,        /* Gain()                    [n][p] (needs FULL_ESTIMATE)  */
+    KB_INNOVATION = 20,  /* Estimate.Innovation()     [p]  (INFO/SRIF: the information vector [n], information.go:272, srif.go:237) */
+    KB_MEASUREMENT = 21, /* Estimate.Measurement()    [p]  (needs FULL_ESTIMATE)    */
+    KB_RAW_VEC = 22,     /* internal vector: x | i | b                              */
+    KB_RAW_MAT = 23,     /* internal matrix: P | S | I | R  [n][n]                  */
+    KB_RAW_PRED_MAT = 24 /* internal predicted matrix: P- | S- | I- | Rbar          */
+} kb_field;
+
+/* ---- lifetime ------------------------------------------------------------- */
+/* Allocates device-resident storage for N filters (n states, up to p measurements,
+ * m controls; m may be 0) on HIP device `device`.  For KB_HYBRID `m` is the
+ * dimension q of the SNC process noise (Gamma is n x q).  Replaces the
+ * allocation half of the constructors (vanilla.go:21, squareroot.go:21,
+ * information.go:20, srif.go:14, hybrid.go:23). */
+int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters,
+              int dtype, int device, unsigned flags);
+void kb_destroy(kb_batch *b);
+const char *kb_last_error(void);
+const char *kb_version(void);
+int kb_device_count(void);
+
+/* ---- model / initial conditions ------------------------------------------- */
+/* Host -> device upload of one input field.  `count` = 1 with broadcast != 0
+ * (one model for every filter: the reference's usual use) or N.  `p_rows` is
+ * the measurement dimension the array is shaped for (KB_H, KB_R; ignored
+ * otherwise): it may differ from the creation `p` as long as it is <= it --
+ * jerkcar swaps a 1-row and a 2-row H between steps (examples/jerkcar/main.go:141-159).
+ * Before kb_init this stages constructor arguments; after kb_init it has the
+ * semantics of the matching setter, including the reference's side effects:
+ *   KB_F  SetStateTransition: KB_INFORMATION refreshes F^-1 (information.go:117-123)
+ *   KB_Q/KB_R  SetNoise: KB_SQUAREROOT recomputes chol(Q), chol(R) (squareroot.go:100-114);
+ *              KB_INFORMATION does NOT refresh Q^-1 / R^-1 (information.go:136-138, bug-compatible)
+ *   KB_G  SetInputControl: needCtrl is not recomputed (vanilla.go:101-103)
+ * Data is converted to the batch dtype on the way in. */
+int kb_set(kb_batch *b, int field, const double *host, int64_t count, int broadcast, int p_rows);
+/* Same from HBM: planar input in the batch dtype, element e of filter i at src[e*ld + i],
+ * full (unpacked) matrices.  Asynchronous on the handle's stream. */
+int kb_set_dev(kb_batch *b, int field, const void *src, int64_t ld, int p_rows);
+
+/* Runs the constructor arithmetic on the device (Cholesky of P0/Q/R, F^-1, Q^-1,
+ * R^-1, I0 = P0^-1, b0 = R0 x0 ...), checks needCtrl = !IsNil(G) (vanilla.go:39),
+ * snapshots the initial estimate for kb_reset and unlocks kb_update. */
+int kb_init(kb_batch *b);
+
+/* LDKF.Reset (vanilla.go:121-125): restore the initial estimate, step = 0,
+ * clear status words, advance the noise stream (AWGN re-seeds on Reset). */
+int kb_reset(kb_batch *b);
+
+/* ---- the hot path ----------------------------------------------------------- */
+/* LDKF.Update(measurement, control) for every filter of the batch
+ * (vanilla.go:128, squareroot.go:129, information.go:153).
+ * meas: host [N][meas_rows]; ctrl: host [N][ctrl_rows] or NULL.  meas_rows / ctrl_rows are the
+ * lengths of the caller's vectors: a mismatch with H / G returns KB_ERR_DIMS with the
+ * reference's message (vanilla.go:129-135); the control is only checked and used when
+ * needCtrl (vanilla.go:129). */
+int kb_update(kb_batch *b, const double *meas, int meas_rows, const double *ctrl, int ctrl_rows);
+/* Same, measurements already in HBM (planar, batch dtype): element e of filter
+ * i at meas[e*ld_meas + i].  Asynchronous on the handle's stream. */
+int kb_update_dev(kb_batch *b, const void *meas, int64_t ld_meas,
+                  const void *ctrl, int64_t ld_ctrl);
+/* The caller loop `for k { kf.Update(y_k, u_k) }` fused into one launch:
+ * meas is planar [T][p][ld] on the device (step t at meas + t*p*ld elements).
+ * x, P and the model stay in registers across the T steps. */
+int kb_update_steps_dev(kb_batch *b, const void *meas, int64_t ld_meas,
+                        const void *ctrl, int64_t ld_ctrl, int nsteps);
+
+/* NLDKF (kalman.go:51-60).  Prepare(Phi, Htilde) (srif.go:82, hybrid.go:78):
+ * host [count][n][n] and [count][p][n]; unlocks the next update. */
+int kb_prepare(kb_batch *b, const double *phi, const double *htilde, int64_t count, int broadcast);
+int kb_prepare_dev(kb_batch *b, const void *phi, const void *htilde, int64_t ld);
+/* PreparePNT(Gamma) (hybrid.go:86-89): enables SNC for the next update only. */
+int kb_prepare_pnt(kb_batch *b, const double *gamma, int64_t count, int broadcast);
+/* EnableEKF / DisableEKF / EKFEnabled (hybrid.go:48-60). */
+int kb_set_ekf(kb_batch *b, int enabled);
+int kb_ekf_enabled(const kb_batch *b);
+/* NLDKF.Update(realObservation, computedObservation) (srif.go:90, hybrid.go:93). */
+int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs, int computed_rows);
+int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs, int64_t ld);
+/* NLDKF.Predict() (srif.go:96, hybrid.go:99). */
+int kb_predict_nl(kb_batch *b);
+
+/* ---- results ---------------------------------------------------------------- */
+/* Device -> host download of one Estimate member for filters [first, first+count),
+ * always as float64, host layout.  KB_COVAR of SQRT / INFORMATION / SRIF batches is
+ * materialised by a small kernel (S S^T, I^-1, R^-1 R^-T) exactly like the
+ * reference's lazy getters (squareroot.go:317, information.go:277, srif.go:253). */
+int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count);
+/* Planar device-side variant: writes element e of filter i to dst[e*ld + i] in the batch dtype. */
+int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld);
+int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count);
+int kb_clear_status(kb_batch *b);
+/* Estimate.IsWithinNsigma(N) (vanilla.go:231-239): out[i] = 1/0. */
+int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first, int64_t count);
+int64_t kb_step(const kb_batch *b);       /* kf.step */
+int kb_need_ctrl(const kb_batch *b);      /* kf.needCtrl (vanilla.go:39) */
+int kb_meas_dim(const kb_batch *b);       /* current rows of H */
+int64_t kb_num_filters(const kb_batch *b);
+void *kb_stream(const kb_batch *b);       /* the hipStream_t work is enqueued on */
+int kb_synchronize(kb_batch *b);
+
+/* ---- noise (noise.go:13-164) -------------------------------------------------- */
+typedef enum {
+    KB_NOISE_NOISELESS = 0, /* Noiseless (noise.go:23-64): w = v = 0               */
+    KB_NOISE_AWGN = 1       /* AWGN (noise.go:109-164): w ~ N(0,Q), v ~ N(0,R), device Philox4x32-10 + Box-Muller, x = L z with L = chol */
+} kb_noise_kind;
+/* Selects the Noise implementation; AWGN fails with KB_ERR_NOT_PD when Q or R is
+ * not positive definite (the reference panics, noise.go:148-156).  `seed` replaces
+ * the reference's wall-clock seed; every kb_reset moves to a fresh sub-stream. */
+int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed);
+/* Draws the AWGN vectors the filter with global index `i` would use at (epoch, step,
+ * draw) -- for tests that replay the device's samples through the oracle.
+ * which: 0 = Process (first call), 1 = Measurement, 2 = Process (second call). */
+int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, int which, double *out);
+
+/* ---- Monte-Carlo fan-out (montecarlo.go:92-119, 18-59) --------------------------- */
+/* NewMonteCarloRuns(samples = N of the batch, steps, rowsH, controls, kf): `b` must be a
+ * KB_VANILLA_PREDICT batch (the reference panics otherwise, montecarlo.go:93-95) with
+ * AWGN noise.  controls: host [steps][m], or [1][m] meaning zero controls for every step
+ * (montecarlo.go:98-104), anything else is an error (a panic there).  Runs all N runs x
+ * `steps` steps in one launch and accumulates, per step, sum and sum of squares of each
+ * state component over this batch's runs:  sums[steps][2][n]  (host, float64).
+ * first_run = global index of this batch's first run (sharding across GPUs: the noise
+ * stream of a run depends only on its global index). */
+int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols,
+              int64_t first_run, double *sums);
+/* MonteCarloRuns.Mean / StdDev (montecarlo.go:18-59) from (all-reduced) sums over
+ * `runs` runs: mean[steps][n], stddev[steps][n] (unbiased, n-1, as gonum stat.StdDev). */
+int kb_mc_stats(const double *sums, int steps, int n, int64_t runs, double *mean, double *stddev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOKALMAN_AMD_H */

@@ -1,0 +1,139 @@
+"""Parity of the HIP Vanilla path (through the C ABI) against the CPU oracle and the
+reference's jerkcar fixture.  Tolerance: 1e-9 relative Frobenius on state and covariance
+(BASELINE.json north_star), 5.1e-7 abs against the %f-printed CSV."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from gokalman_amd import synth
+from oracle import oracle as orc
+from tests import jerkcar as jc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _oracle_steps(d, kind, steps, want_extras=False):
+    N = d["x0"].shape[0]
+    xs, Ps, ex = [], [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(kind, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i])
+        for t in range(steps):
+            assert f.update(d["y"][t, i]) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+        if want_extras:
+            ex.append((f.pred_covariance(), f.gain(), f.innovation(), f.measurement()))
+    return np.array(xs), np.array(Ps), ex
+
+
+@pytest.mark.parametrize("N", [1, 64, 100, 4096])
+def test_vanilla_6x3_host_path_vs_oracle(N):
+    steps = 20
+    d = synth.linear_batch(N, 6, 3, steps)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    for t in range(steps):
+        b.update(d["y"][t])
+    Nc = min(N, 256)
+    sub = {kk: (v[:Nc] if kk != "y" else v[:, :Nc]) for kk, v in d.items()}
+    xo, Po, _ = _oracle_steps(sub, orc.VANILLA, steps)
+    assert synth.rel_frobenius(b.get(k.STATE, 0, Nc), xo) <= TOL
+    assert synth.rel_frobenius(b.get(k.COVAR, 0, Nc), Po) <= TOL
+    assert b.step() == steps
+    assert not b.status().any()
+
+
+def test_vanilla_6x3_full_estimate_extras():
+    N, steps = 128, 5
+    d = synth.linear_batch(N, 6, 3, steps)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"],
+                                flags=k.FLAG_FULL_ESTIMATE)
+    for t in range(steps):
+        est = b.update(d["y"][t])
+    xo, Po, ex = _oracle_steps(d, orc.VANILLA, steps, want_extras=True)
+    assert synth.rel_frobenius(est.state(), xo) <= TOL
+    assert synth.rel_frobenius(est.covariance(), Po) <= TOL
+    assert synth.rel_frobenius(est.pred_covariance(), np.array([e[0] for e in ex])) <= TOL
+    assert synth.rel_frobenius(est.gain(), np.array([e[1] for e in ex])) <= TOL
+    assert np.max(np.abs(est.innovation() - np.array([e[2] for e in ex]))) <= 1e-9
+    assert synth.rel_frobenius(est.measurement(), np.array([e[3] for e in ex])) <= TOL
+
+
+def test_vanilla_generic_shapes_vs_oracle():
+    for (n, p) in [(2, 1), (4, 1), (4, 2), (8, 3), (12, 6)]:
+        N, steps = 70, 6
+        d = synth.linear_batch(N, n, p, steps)
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"],
+                                    flags=k.FLAG_FULL_ESTIMATE | k.FLAG_STRICT_SYMCHECK)
+        for t in range(steps):
+            est = b.update(d["y"][t])
+        xo, Po, ex = _oracle_steps(d, orc.VANILLA, steps, want_extras=True)
+        assert synth.rel_frobenius(est.state(), xo) <= TOL, (n, p)
+        assert synth.rel_frobenius(est.covariance(), Po) <= TOL, (n, p)
+        assert synth.rel_frobenius(est.gain(), np.array([e[1] for e in ex])) <= TOL, (n, p)
+        assert not b.status().any()
+
+
+def test_vanilla_jerkcar_fixture_on_gpu():
+    """The reference's 2000-step golden run, H/noise swapped every 10th step, control input."""
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, jc.X0, jc.P0, jc.F, jc.G, jc.H2, jc.Q, jc.R2, nfilters=3, pmax=2)
+    assert b.need_ctrl()
+
+    def row():
+        return jc.export_row(b.get(k.STATE, 1, 1)[0], b.get(k.COVAR, 1, 1)[0])
+
+    got = jc.run_protocol(lambda y, u: b.update(y, u), b.set_measurement_matrix, b.set_noise, row)
+    exp = jc.load_expected("vanilla")
+    assert np.max(np.abs(got - exp)) <= 5.1e-7
+    f = orc.Filter.ldkf(orc.VANILLA, jc.X0, jc.P0, jc.F, jc.G, jc.H2, jc.Q, jc.R2)
+    ref = jc.run_protocol(lambda y, u: f.update(y, u), f.set_measurement_matrix, f.set_noise,
+                          lambda: jc.export_row(f.state(), f.covariance()))
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 1e-9
+
+
+def test_vanilla_device_path_and_fused_steps():
+    import torch
+    N, steps = 4096 + 37, 12
+    d = synth.linear_batch(N, 6, 3, steps)
+    xo, Po, _ = _oracle_steps({kk: (v[:128] if kk != "y" else v[:, :128]) for kk, v in d.items()}, orc.VANILLA, steps)
+    y_planar = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()  # [T][p][N]
+    for fused in (False, True):
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        if fused:
+            b.update_steps_dev(y_planar.data_ptr(), N, steps)
+        else:
+            for t in range(steps):
+                b.update_dev(y_planar[t].data_ptr(), N)
+        b.synchronize()
+        assert b.step() == steps
+        assert synth.rel_frobenius(b.get(k.STATE, 0, 128), xo) <= TOL
+        assert synth.rel_frobenius(b.get(k.COVAR, 0, 128), Po) <= TOL
+
+
+def test_vanilla_singular_innovation_sets_status_and_keeps_estimate():
+    """H = 0 and R = 0 make H P- H^T + R exactly singular: the reference returns (nil, err)
+    (vanilla.go:164-167) and leaves prevEst alone."""
+    N = 70
+    d = synth.linear_batch(N, 6, 3, 1)
+    d["H"][5] = 0.0
+    d["R"][5] = 0.0
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    b.update(d["y"][0])
+    st = b.status()
+    assert st[5] & k.ST_SINGULAR and not st[np.arange(N) != 5].any()
+    assert np.array_equal(b.get(k.STATE, 5, 1)[0], d["x0"][5])
+    f = orc.Filter.ldkf(orc.VANILLA, d["x0"][5], d["P0"][5], d["F"][5], None, d["H"][5], d["Q"][5], d["R"][5])
+    assert f.update(d["y"][0, 5]) == orc.ERR_SINGULAR
+    b.reset()
+    assert not b.status().any() and b.step() == 0
+
+
+def test_vanilla_dimension_errors_match_reference_strings():
+    d = synth.linear_batch(4, 4, 2, 1)
+    G = np.array([[0.0], [1e-4], [1e-2], [0.0]])
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], G, d["H"], d["Q"], d["R"])
+    with pytest.raises(ga.KalmanError, match=r"dimensions must agree: measurement \(y\)\(3x\.\.\.\) H\(2x\.\.\.\)"):
+        b.update(np.zeros((4, 3)), np.zeros((4, 1)))
+    with pytest.raises(ga.KalmanError, match=r"dimensions must agree: control \(u\)\(2x\.\.\.\) G\(\.\.\.x1\)"):
+        b.update(np.zeros((4, 2)), np.zeros((4, 2)))
+    assert b.step() == 0
