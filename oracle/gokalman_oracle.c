@@ -364,13 +364,18 @@ static int sqrt_set_noise(orc_filter *f, int p, const double *Q, const double *R
     return e1 ? e1 : e2;
 }
 
-orc_filter *orc_new_ldkf(int kind, int n, int p, int m,
-                         const double *x0, const double *P0,
-                         const double *F, const double *G, const double *H,
-                         const double *Q, const double *R) {
-    if (n < 1 || n > ORC_MAXN || p < 1 || p > ORC_MAXN || m < 0 || m > ORC_MAXN) return NULL;
-    orc_filter *f = (orc_filter *)calloc(1, sizeof(*f));
+/* constructor body on caller-provided storage; returns 0 on success */
+static int ldkf_init(orc_filter *f, int kind, int n, int p, int m,
+                     const double *x0, const double *P0,
+                     const double *F, const double *G, const double *H,
+                     const double *Q, const double *R) {
+    if (n < 1 || n > ORC_MAXN || p < 1 || p > ORC_MAXN || m < 0 || m > ORC_MAXN) return 1;
     f->kind = kind; f->n = n; f->p = p; f->m = m;
+    f->step = 0; f->have_gain = 0; f->locked = 0; f->snc = 0; f->ekf = 0;
+    memset(f->G, 0, sizeof(double) * n * (m > 0 ? m : 1));
+    memset(f->innov, 0, sizeof(f->innov));
+    memset(f->meas, 0, sizeof(f->meas));
+    memset(f->Mpred, 0, sizeof(double) * n * n);
     memcpy(f->F, F, sizeof(double) * n * n);
     if (G && m > 0) memcpy(f->G, G, sizeof(double) * n * m);
     memcpy(f->H, H, sizeof(double) * p * n);
@@ -388,8 +393,8 @@ orc_filter *orc_new_ldkf(int kind, int n, int p, int m,
     case ORC_SQUAREROOT: { /* squareroot.go:33-49 */
         double P0s[NN];
         sym_from_upper(n, P0, P0s);
-        if (orc_cholesky_lower(n, P0s, f->M) != ORC_OK) { free(f); return NULL; }
-        if (sqrt_set_noise(f, p, f->Q, f->R) != ORC_OK) { free(f); return NULL; }
+        if (orc_cholesky_lower(n, P0s, f->M) != ORC_OK) return 1;
+        if (sqrt_set_noise(f, p, f->Q, f->R) != ORC_OK) return 1;
         break;
     }
     case ORC_INFORMATION: { /* information.go:20-53; x0,P0 are i0,I0 */
@@ -401,11 +406,32 @@ orc_filter *orc_new_ldkf(int kind, int n, int p, int m,
         break;
     }
     default:
-        free(f);
-        return NULL;
+        return 1;
     }
     save_init(f);
+    return 0;
+}
+
+orc_filter *orc_new_ldkf(int kind, int n, int p, int m,
+                         const double *x0, const double *P0,
+                         const double *F, const double *G, const double *H,
+                         const double *Q, const double *R) {
+    orc_filter *f = (orc_filter *)calloc(1, sizeof(*f));
+    if (ldkf_init(f, kind, n, p, m, x0, P0, F, G, H, Q, R) != 0) { free(f); return NULL; }
     return f;
+}
+
+/* information.go:65-81 NewInformationFromState (x0,P0 -> i0,I0) */
+static int info_from_state(int n, const double *x0, const double *P0, double *i0, double *I0) {
+    double P0s[NN], I0t[NN];
+    sym_from_upper(n, P0, P0s);
+    if (orc_inverse(n, P0s, I0t, NULL) != 0) {
+        memset(I0, 0, sizeof(double) * n * n);
+    } else if (orc_as_sym_dense(n, I0t, I0) != ORC_OK) {
+        return 1; /* reference would carry a nil SymDense and crash */
+    }
+    mv(n, n, I0, x0, i0);
+    return 0;
 }
 
 /* information.go:65-81 NewInformationFromState */
@@ -413,14 +439,8 @@ orc_filter *orc_information_from_state(int n, int p, int m,
                          const double *x0, const double *P0,
                          const double *F, const double *G, const double *H,
                          const double *Q, const double *R) {
-    double P0s[NN], I0t[NN], I0[NN], i0[ORC_MAXN];
-    sym_from_upper(n, P0, P0s);
-    if (orc_inverse(n, P0s, I0t, NULL) != 0) {
-        memset(I0, 0, sizeof(I0));
-    } else if (orc_as_sym_dense(n, I0t, I0) != ORC_OK) {
-        return NULL; /* reference would carry a nil SymDense and crash */
-    }
-    mv(n, n, I0, x0, i0);
+    double I0[NN], i0[ORC_MAXN];
+    if (info_from_state(n, x0, P0, i0, I0)) return NULL;
     return orc_new_ldkf(ORC_INFORMATION, n, p, m, i0, I0, F, G, H, Q, R);
 }
 
@@ -998,29 +1018,38 @@ int orc_max_threads(void) {
 
 long orc_ldkf_batch(int kind, long N, int T, int n, int p,
                     double *x, double *P, const double *F, const double *H,
-                    const double *Q, const double *R, const double *y,
+                    const double *Q, const double *R, const double *y, int ypool,
                     int threads) {
     long nerr = 0;
     if (threads < 1) threads = 1;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(threads) reduction(+ : nerr) schedule(static)
+#pragma omp parallel num_threads(threads) reduction(+ : nerr)
 #endif
-    for (long i = 0; i < N; i++) {
-        orc_filter *f;
-        if (kind == ORC_INFORMATION)
-            f = orc_information_from_state(n, p, 0, x + i * n, P + i * n * n, F + i * n * n, NULL,
-                                           H + i * p * n, Q + i * n * n, R + i * p * p);
-        else
-            f = orc_new_ldkf(kind, n, p, 0, x + i * n, P + i * n * n, F + i * n * n, NULL,
-                             H + i * p * n, Q + i * n * n, R + i * p * p);
-        if (!f) { nerr++; continue; }
-        int bad = 0;
-        for (int k = 0; k < T && !bad; k++)
-            if (orc_update(f, y + ((long)k * N + i) * p, NULL, NULL, NULL, NULL) != ORC_OK) bad = 1;
-        nerr += bad;
-        orc_get(f, ORC_GET_STATE, x + i * n);
-        orc_get(f, ORC_GET_COVAR, P + i * n * n);
-        orc_free(f);
+    {
+        orc_filter *f = (orc_filter *)calloc(1, sizeof(*f)); /* one object per thread, re-initialised per filter */
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (long i = 0; i < N; i++) {
+            int rc;
+            if (kind == ORC_INFORMATION) {
+                double I0[NN], i0[ORC_MAXN];
+                rc = info_from_state(n, x + i * n, P + i * n * n, i0, I0);
+                if (!rc) rc = ldkf_init(f, kind, n, p, 0, i0, I0, F + i * n * n, NULL,
+                                        H + i * p * n, Q + i * n * n, R + i * p * p);
+            } else {
+                rc = ldkf_init(f, kind, n, p, 0, x + i * n, P + i * n * n, F + i * n * n, NULL,
+                               H + i * p * n, Q + i * n * n, R + i * p * p);
+            }
+            if (rc) { nerr++; continue; }
+            int bad = 0;
+            for (int k = 0; k < T && !bad; k++)
+                if (orc_update(f, y + ((long)(k % ypool) * N + i) * p, NULL, NULL, NULL, NULL) != ORC_OK) bad = 1;
+            nerr += bad;
+            orc_get(f, ORC_GET_STATE, x + i * n);
+            orc_get(f, ORC_GET_COVAR, P + i * n * n);
+        }
+        free(f);
     }
     return nerr;
 }
@@ -1029,7 +1058,7 @@ long orc_vanilla_batch(long N, int T, int n, int p,
                        double *x, double *P, const double *F, const double *H,
                        const double *Q, const double *R, const double *y,
                        int threads) {
-    return orc_ldkf_batch(ORC_VANILLA, N, T, n, p, x, P, F, H, Q, R, y, threads);
+    return orc_ldkf_batch(ORC_VANILLA, N, T, n, p, x, P, F, H, Q, R, y, T, threads);
 }
 
 /* montecarlo.go:18-59 with gonum stat.Mean / stat.StdDev (two-pass, n-1). */

@@ -137,10 +137,11 @@ long orc_vanilla_batch(long N, int T, int n, int p,
                        int threads);
 /* same for the other LDKF kinds (kind = ORC_SQUAREROOT / ORC_INFORMATION);
  * x,P are (x,P) on input and output (covariance form), the filter's internal
- * form is built by the constructor as in the reference. */
+ * form is built by the constructor as in the reference.  y holds `ypool` steps,
+ * step k uses y[k % ypool]. */
 long orc_ldkf_batch(int kind, long N, int T, int n, int p,
                     double *x, double *P, const double *F, const double *H,
-                    const double *Q, const double *R, const double *y,
+                    const double *Q, const double *R, const double *y, int ypool,
                     int threads);
 int orc_max_threads(void);
 

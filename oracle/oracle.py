@@ -71,7 +71,7 @@ def lib():
         L.orc_householder_transf.argtypes = [_dp, C.c_int, C.c_int]
         L.orc_measurement_srif_update.argtypes = [C.c_int, C.c_int] + [_dp] * 7
         L.orc_ldkf_batch.restype = C.c_long
-        L.orc_ldkf_batch.argtypes = [C.c_int, C.c_long, C.c_int, C.c_int, C.c_int] + [_dp] * 7 + [C.c_int]
+        L.orc_ldkf_batch.argtypes = [C.c_int, C.c_long, C.c_int, C.c_int, C.c_int] + [_dp] * 7 + [C.c_int, C.c_int]
         L.orc_vanilla_batch.restype = C.c_long
         L.orc_vanilla_batch.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int] + [_dp] * 7 + [C.c_int]
         L.orc_max_threads.restype = C.c_int
@@ -277,8 +277,9 @@ def measurement_srif_update(R, H, b, y):
     return Rk, bk, ek
 
 
-def ldkf_batch(kind, x, P, F, H, Q, R, y, threads=None):
-    """N independent LDKF filters x T steps (AoS inputs); returns (x, P, nerr)."""
+def ldkf_batch(kind, x, P, F, H, Q, R, y, threads=None, steps=None):
+    """N independent LDKF filters x T steps (AoS inputs); returns (x, P, nerr).
+    steps > len(y) cycles through y (step k uses y[k % len(y)])."""
     x = np.array(x, dtype=np.float64, order="C")
     P = np.array(P, dtype=np.float64, order="C")
     N, n = x.shape
@@ -287,8 +288,9 @@ def ldkf_batch(kind, x, P, F, H, Q, R, y, threads=None):
     F, H, Q, R = [np.ascontiguousarray(v, dtype=np.float64) for v in (F, H, Q, R)]
     if threads is None:
         threads = lib().orc_max_threads()
-    nerr = lib().orc_ldkf_batch(kind, N, T, n, p, x.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
-                                _p(F), _p(H), _p(Q), _p(R), _p(y), int(threads))
+    nerr = lib().orc_ldkf_batch(kind, N, T if steps is None else int(steps), n, p,
+                                x.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
+                                _p(F), _p(H), _p(Q), _p(R), _p(y), T, int(threads))
     return x, P, nerr
 
 
