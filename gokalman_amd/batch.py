@@ -282,7 +282,7 @@ class MonteCarloRuns:
 
     def __init__(self, runs, steps, n, sums):
         self.runs, self.steps, self.n = runs, steps, n
-        self.sums = sums  # [steps, 2, n]: sum and sum of squares over runs
+        self.sums = sums  # [steps, 3, n]: sum(x-c), sum((x-c)^2), c
         mean = np.zeros((steps, n))
         std = np.zeros((steps, n))
         k.check(k.lib().kb_mc_stats(_ptr(_f64(sums)), steps, n, runs, _ptr(mean), _ptr(std)))
@@ -308,8 +308,8 @@ def new_monte_carlo_runs(samples, steps, rows_h, controls, kf, first_run=0, redu
         controls = controls.reshape(1, -1)
     if controls.shape[0] != 1 and controls.shape[0] != steps:
         raise k.KalmanError(k.ERR_INVALID, "must provide as much control vectors as steps, or just one control vector")
-    sums = np.zeros((steps, 2, kf.n), dtype=np.float64)
+    sums = np.zeros((steps, 3, kf.n), dtype=np.float64)
     k.check(k.lib().kb_mc_run(kf._h, steps, _ptr(controls), controls.shape[0], first_run, _ptr(sums)))
-    if reduce is not None:
-        sums = reduce(sums)
+    if reduce is not None:  # add the shards' partial sums (rows 0, 1); row 2 (the shift) is identical everywhere
+        sums[:, :2, :] = reduce(np.ascontiguousarray(sums[:, :2, :]))
     return MonteCarloRuns(samples, steps, kf.n, sums)

@@ -59,7 +59,7 @@ static Layout make_layout(int kind, int n, int pmax, int m, unsigned flags) {
     return L;
 }
 
-static int ensure_stage(Batch &b, size_t bytes) {
+int ensure_stage(Batch &b, size_t bytes) {
     if (b.stage_bytes >= bytes) return KB_OK;
     if (b.d_stage) KB_HIP(hipFree(b.d_stage));
     b.d_stage = nullptr; b.stage_bytes = 0;
@@ -68,7 +68,7 @@ static int ensure_stage(Batch &b, size_t bytes) {
     return KB_OK;
 }
 
-static int use_device(const Batch &b) {
+int use_device(const Batch &b) {
     KB_HIP(hipSetDevice(b.device));
     return KB_OK;
 }
@@ -156,7 +156,7 @@ __global__ void pack_planar_kernel(const T *__restrict__ src, int64_t ld, int sr
     }
 }
 
-static void fill_step_args(const Batch &b, StepArgs &a) {
+void fill_step_args(const Batch &b, StepArgs &a) {
     memset(&a, 0, sizeof(a));
     a.state = b.d_state; a.pred = b.d_pred; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status;
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
@@ -170,7 +170,7 @@ static int launch_step(Batch &b, const StepArgs &a, bool fused) {
     switch (b.kind) {
     case KB_VANILLA:
     case KB_VANILLA_PREDICT: return launch_vanilla(b, a, fused);
-    case KB_SQUAREROOT: return launch_squareroot(b, a);
+    case KB_SQUAREROOT: return launch_squareroot(b, a, fused);
     case KB_INFORMATION: return launch_information(b, a);
     }
     set_error("kind %d has no LDKF update", b.kind);
@@ -178,7 +178,7 @@ static int launch_step(Batch &b, const StepArgs &a, bool fused) {
 }
 
 // host [N][rows] -> AoSoA staging block with `rows` elements per filter
-static int stage_host_vec(Batch &b, const double *host, int rows, void **dblock) {
+int stage_host_vec(Batch &b, const double *host, int rows, void **dblock) {
     const size_t bytes = (size_t)b.N * rows * sizeof(double);
     int rc = ensure_stage(b, bytes);
     if (rc) return rc;
@@ -259,7 +259,7 @@ void kb_destroy(kb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_pred, b->d_pred0, b->d_est, b->d_model, b->d_status,
-                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc};
+                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc, b->d_ctrl};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -272,7 +272,7 @@ void kb_destroy(kb_batch *b) {
 static int after_set(kb_batch *b, int field, int p_rows, const double *host_for_nil, int64_t host_elems) {
     if (field <= KB_R) b->have[field] = true;
     if (field == KB_H) b->p = p_rows;
-    if (field == KB_R) b->sqrt_p = b->sqrt_p;  // refreshed below when initialised
+    if (field == KB_R) b->r_p = p_rows;
     if (field == KB_G && !b->initialized && host_for_nil) {
         // needCtrl = !IsNil(G) at construction (vanilla.go:39, helper.go:49-62); the setter does not refresh it
         int nz = 0;
@@ -283,13 +283,10 @@ static int after_set(kb_batch *b, int field, int p_rows, const double *host_for_
         int not_pd = 0;
         int rc = launch_refresh(*b, field, &not_pd);
         if (rc) return rc;
-        if (field == KB_R && b->kind == KB_SQUAREROOT) b->sqrt_p = p_rows;
         if (not_pd) { set_error("matrix is not positive definite (Cholesky failed for %d filter(s))", not_pd); return KB_ERR_NOT_PD; }
     }
     return KB_OK;
 }
-
-static int r_rows_of(kb_batch *b) { return b->L.pmax; }
 
 int kb_set(kb_batch *b, int field, const double *host, int64_t count, int broadcast, int p_rows) {
     if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
@@ -309,11 +306,8 @@ int kb_set(kb_batch *b, int field, const double *host, int64_t count, int broadc
     if ((rc = ensure_stage(*b, bytes))) return rc;
     KB_HIP(hipMemcpyAsync(b->d_stage, host, bytes, hipMemcpyHostToDevice, b->stream));
     if ((rc = launch_pack(*b, b->d_stage, t.src_elems, count, broadcast != 0, t.block, t.block_elems, t.map))) return rc;
-    if (field == KB_R) b->rinv_p = b->initialized ? b->rinv_p : p_rows;
-    if (field == KB_R && !b->initialized) b->sqrt_p = p_rows;
     if ((rc = after_set(b, field, p_rows, host, count * t.src_elems))) { (void)hipStreamSynchronize(b->stream); return rc; }
     KB_HIP(hipStreamSynchronize(b->stream));
-    (void)r_rows_of;
     return KB_OK;
 }
 
@@ -340,7 +334,6 @@ int kb_set_dev(kb_batch *b, int field, const void *src, int64_t ld, int p_rows) 
         hipLaunchKernelGGL(pack_planar_kernel<float>, dim3(blocks), dim3(256), 0, b->stream, (const float *)src, ld,
                            t.src_elems, b->N, (float *)t.block, t.block_elems, (const int16_t *)b->d_stage);
     KB_HIP(hipGetLastError());
-    if (field == KB_R && !b->initialized) { b->rinv_p = p_rows; b->sqrt_p = p_rows; }
     if (field == KB_G && !b->initialized) b->need_ctrl = 1;  // device-side G: assumed non-nil
     if ((rc = after_set(b, field, p_rows, nullptr, 0))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));  // the map buffer may be reused by the next call
@@ -359,7 +352,6 @@ int kb_init(kb_batch *b) {
         if (need_fh && (f == KB_F || f == KB_H || f == KB_Q)) required = true;
         if (required && !b->have[f]) { set_error("kb_init: %s has not been set", names[f]); return KB_ERR_INVALID; }
     }
-    if (b->kind == KB_SRIF || b->kind == KB_HYBRID) b->rinv_p = b->pmax;
     int not_pd = 0;
     if ((rc = launch_init(*b, &not_pd))) return rc;
     if (not_pd) {

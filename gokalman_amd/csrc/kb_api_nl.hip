@@ -1,0 +1,238 @@
+// kb_api_nl.hip -- C ABI, second half: the NLDKF interface (kalman.go:51-60) for SRIF and
+// Hybrid batches, the Noise selection (noise.go) and the Monte-Carlo fan-out (montecarlo.go).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "kb_internal.h"
+
+using namespace kb;
+
+namespace kb {
+int launch_squareroot(const Batch &b, const StepArgs &a, bool) { return launch_squareroot_gen(b, a); }
+int launch_srif(const Batch &b, const StepArgs &a) { return launch_srif_gen(b, a); }
+int launch_hybrid(const Batch &b, const StepArgs &a) { return launch_hybrid_gen(b, a); }
+}  // namespace kb
+
+static int ready_nl(kb_batch *b) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
+    if (b->kind != KB_SRIF && b->kind != KB_HYBRID) { set_error("not an NLDKF batch (SRIF / Hybrid)"); return KB_ERR_INVALID; }
+    return use_device(*b);
+}
+
+static int launch_nl(kb_batch *b, const StepArgs &a) {
+    return b->kind == KB_SRIF ? launch_srif(*b, a) : launch_hybrid(*b, a);
+}
+
+extern "C" {
+
+// Prepare(Phi, Htilde): srif.go:82-86, hybrid.go:78-82
+int kb_prepare(kb_batch *b, const double *phi, const double *htilde, int64_t count, int broadcast) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (!phi || !htilde) { set_error("null argument"); return KB_ERR_INVALID; }
+    if ((rc = kb_set(b, KB_F, phi, count, broadcast, 0))) return rc;
+    if ((rc = kb_set(b, KB_H, htilde, count, broadcast, b->pmax))) return rc;
+    b->locked = 0;
+    return KB_OK;
+}
+
+int kb_prepare_dev(kb_batch *b, const void *phi, const void *htilde, int64_t ld) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (!phi || !htilde) { set_error("null argument"); return KB_ERR_INVALID; }
+    if ((rc = kb_set_dev(b, KB_F, phi, ld, 0))) return rc;
+    if ((rc = kb_set_dev(b, KB_H, htilde, ld, b->pmax))) return rc;
+    b->locked = 0;
+    return KB_OK;
+}
+
+// PreparePNT(Gamma): hybrid.go:86-89 (a no-op for SRIF, srif.go:79)
+int kb_prepare_pnt(kb_batch *b, const double *gamma, int64_t count, int broadcast) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (b->kind != KB_HYBRID) return KB_OK;
+    if (!gamma) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (b->m <= 0) { set_error("batch was created with q = 0: no SNC"); return KB_ERR_INVALID; }
+    if (!b->have[KB_Q]) { set_error("SNC needs the process noise Q (kb_set KB_Q)"); return KB_ERR_INVALID; }
+    if ((rc = kb_set(b, KB_G, gamma, count, broadcast, 0))) return rc;
+    b->snc = 1;
+    return KB_OK;
+}
+
+static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
+    int rc;
+    if (b->locked) { set_error("kf is locked (call Prepare() first)"); return KB_ERR_LOCKED; }
+    a.predict = predict ? 1 : 0;
+    if ((rc = launch_nl(b, a))) return rc;
+    b->step++;
+    b->snc = 0;     // hybrid.go:201
+    b->locked = 1;  // srif.go:158, hybrid.go:202
+    return KB_OK;
+}
+
+// Update(realObservation, computedObservation): srif.go:90-92, hybrid.go:93-95
+int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs, int computed_rows) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (b->locked) { set_error("kf is locked (call Prepare() first)"); return KB_ERR_LOCKED; }
+    if (!real_obs || !computed_obs) { set_error("null observation"); return KB_ERR_INVALID; }
+    if (real_rows != computed_rows) {  // checkMatDims(..., rowsAndcols), srif.go:106, hybrid.go:109
+        set_error("dimensions must agree: real observation(%dx1) computed observation(%dx1)", real_rows, computed_rows);
+        return KB_ERR_DIMS;
+    }
+    if (real_rows != b->p) {
+        set_error("dimensions must agree: observation(%dx1) Htilde(%dx...)", real_rows, b->p);
+        return KB_ERR_DIMS;
+    }
+    if ((rc = stage_host_vec(*b, real_obs, real_rows, &b->d_y))) return rc;
+    if ((rc = stage_host_vec(*b, computed_obs, computed_rows, &b->d_y2))) return rc;
+    StepArgs a;
+    fill_step_args(*b, a);
+    a.y = b->d_y; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * real_rows;
+    a.y2 = b->d_y2; a.y2_es = KB_TILE; a.y2_ts = (int64_t)KB_TILE * real_rows;
+    if ((rc = nl_common(b, a, false))) return rc;
+    KB_HIP(hipStreamSynchronize(b->stream));
+    return KB_OK;
+}
+
+int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs, int64_t ld) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (!real_obs || !computed_obs) { set_error("null observation"); return KB_ERR_INVALID; }
+    if (ld < b->N) { set_error("ld < N"); return KB_ERR_INVALID; }
+    StepArgs a;
+    fill_step_args(*b, a);
+    a.y = real_obs; a.y_es = ld; a.y_ts = KB_TILE;
+    a.y2 = computed_obs; a.y2_es = ld; a.y2_ts = KB_TILE;
+    return nl_common(b, a, false);
+}
+
+// Predict(): srif.go:96-98, hybrid.go:99-101
+int kb_predict_nl(kb_batch *b) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    StepArgs a;
+    fill_step_args(*b, a);
+    if ((rc = nl_common(b, a, true))) return rc;
+    KB_HIP(hipStreamSynchronize(b->stream));
+    return KB_OK;
+}
+
+// ---- noise (noise.go) -------------------------------------------------------------------
+int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed) {
+    if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    if (noise_kind != KB_NOISE_NOISELESS && noise_kind != KB_NOISE_AWGN) { set_error("unknown noise kind %d", noise_kind); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    b->noise_kind = noise_kind;
+    b->seed = seed;
+    if (b->initialized && noise_kind == KB_NOISE_AWGN) {  // NewAWGN(Q, R) panics on non-PD input (noise.go:148-156)
+        int not_pd = 0, np2 = 0;
+        if ((rc = launch_refresh(*b, KB_Q, &not_pd))) return rc;
+        if ((rc = launch_refresh(*b, KB_R, &np2))) return rc;
+        if (not_pd + np2) { set_error("process / measurement noise invalid: not positive definite"); return KB_ERR_NOT_PD; }
+    }
+    return KB_OK;
+}
+
+// Standard normals behind the AWGN draw (filter, epoch, step, which): out[k], k < n (which 0,2) or p (which 1).
+// The noise vector is chol_L(Q or R) * out.
+int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, int which, double *out) {
+    if (!b || !out) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (which < 0 || which > 2) { set_error("which must be 0, 1 or 2"); return KB_ERR_INVALID; }
+    const int len = (which == 1) ? b->p : b->n;
+    for (int k = 0; k < len; k++)
+        out[k] = normal_at(b->seed, (uint64_t)filter, (uint32_t)step, (uint32_t)(epoch * 4 + which), k);
+    return KB_OK;
+}
+
+// ---- Monte-Carlo (montecarlo.go:92-119) ----------------------------------------------------
+int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols, int64_t first_run, double *sums) {
+    if (!b || !sums) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
+    if (b->kind != KB_VANILLA_PREDICT) {  // montecarlo.go:93-95 (a panic there)
+        set_error("the Kalman filter needed for the Monte Carlo runs must be a pure predictor");
+        return KB_ERR_INVALID;
+    }
+    if (steps < 1) { set_error("steps must be >= 1"); return KB_ERR_INVALID; }
+    if (ncontrols != 1 && ncontrols != steps) {  // montecarlo.go:105-107 (a panic there)
+        set_error("must provide as much control vectors as steps, or just one control vector");
+        return KB_ERR_INVALID;
+    }
+    if (b->noise_kind != KB_NOISE_AWGN) { set_error("Monte-Carlo runs need AWGN noise (kb_set_noise_kind)"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    const int n = b->n, m = b->m;
+    // controls -> device, batch dtype
+    if (b->need_ctrl) {
+        if (!controls) { set_error("controls required (needCtrl)"); return KB_ERR_INVALID; }
+        const size_t cnt = (size_t)ncontrols * m;
+        const size_t bytes = cnt * b->esize();
+        if (b->ctrl_bytes < bytes) {
+            if (b->d_ctrl) KB_HIP(hipFree(b->d_ctrl));
+            b->d_ctrl = nullptr; b->ctrl_bytes = 0;
+            KB_HIP(hipMalloc(&b->d_ctrl, bytes));
+            b->ctrl_bytes = bytes;
+        }
+        if (b->dtype == KB_F64) {
+            KB_HIP(hipMemcpyAsync(b->d_ctrl, controls, bytes, hipMemcpyHostToDevice, b->stream));
+            KB_HIP(hipStreamSynchronize(b->stream));
+        } else {
+            std::vector<float> tmp(cnt);
+            for (size_t i = 0; i < cnt; i++) tmp[i] = (float)controls[i];
+            KB_HIP(hipMemcpyAsync(b->d_ctrl, tmp.data(), bytes, hipMemcpyHostToDevice, b->stream));
+            KB_HIP(hipStreamSynchronize(b->stream));
+        }
+    }
+    const int repl = mc_repl();
+    const size_t ndbl = (size_t)repl * steps * 2 * n + (size_t)steps * n;
+    if (b->mc_bytes < ndbl * sizeof(double)) {
+        if (b->d_mc) KB_HIP(hipFree(b->d_mc));
+        b->d_mc = nullptr; b->mc_bytes = 0;
+        KB_HIP(hipMalloc((void **)&b->d_mc, ndbl * sizeof(double)));
+        b->mc_bytes = ndbl * sizeof(double);
+    }
+    KB_HIP(hipMemsetAsync(b->d_mc, 0, ndbl * sizeof(double), b->stream));
+    StepArgs a;
+    fill_step_args(*b, a);
+    a.nsteps = steps;
+    a.first_filter = first_run;
+    a.step0 = 0;
+    if ((rc = launch_mc(*b, a, b->d_ctrl, ncontrols, b->d_mc))) return rc;
+    std::vector<double> host(ndbl);
+    KB_HIP(hipMemcpyAsync(host.data(), b->d_mc, ndbl * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));
+    // sums[steps][3][n]: sum(d), sum(d^2), shift c
+    const double *shift = host.data() + (size_t)repl * steps * 2 * n;
+    for (int t = 0; t < steps; t++)
+        for (int i = 0; i < n; i++) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < repl; r++) {
+                s1 += host[(((size_t)r * steps + t) * 2 + 0) * n + i];
+                s2 += host[(((size_t)r * steps + t) * 2 + 1) * n + i];
+            }
+            sums[((size_t)t * 3 + 0) * n + i] = s1;
+            sums[((size_t)t * 3 + 1) * n + i] = s2;
+            sums[((size_t)t * 3 + 2) * n + i] = shift[(size_t)t * n + i];
+        }
+    b->epoch++;  // kf.Reset() after the sample (montecarlo.go:116): state untouched, noise re-seeded
+    return KB_OK;
+}
+
+// MonteCarloRuns.Mean / StdDev (montecarlo.go:18-59): stat.Mean, stat.StdDev (unbiased)
+int kb_mc_stats(const double *sums, int steps, int n, int64_t runs, double *mean, double *stddev) {
+    if (!sums || !mean || !stddev || steps < 1 || n < 1 || runs < 1) { set_error("bad argument"); return KB_ERR_INVALID; }
+    for (int t = 0; t < steps; t++)
+        for (int i = 0; i < n; i++) {
+            const double s1 = sums[((size_t)t * 3 + 0) * n + i], s2 = sums[((size_t)t * 3 + 1) * n + i];
+            const double c = sums[((size_t)t * 3 + 2) * n + i];
+            mean[(size_t)t * n + i] = c + s1 / (double)runs;
+            const double var = runs > 1 ? (s2 - s1 * s1 / (double)runs) / (double)(runs - 1) : NAN;
+            stddev[(size_t)t * n + i] = std::sqrt(var > 0.0 || var != var ? var : 0.0);
+        }
+    return KB_OK;
+}
+
+}  // extern "C"

@@ -55,6 +55,8 @@ struct Batch {
     int64_t step = 0;
     int rinv_p = 0;        // KB_INFORMATION: dimension R^-1 was computed for (stale-Rinv quirk)
     int sqrt_p = 0;        // KB_SQUAREROOT: dimension of chol(R)
+    int r_p = 0;           // dimension of the R last given to kb_set
+    void *d_ctrl = nullptr; size_t ctrl_bytes = 0;  // Monte-Carlo control sequence
     // NLDKF
     int ekf = 0, locked = 1, snc = 0;
     // noise
@@ -109,11 +111,21 @@ int launch_within_nsigma(const Batch &b, const void *xp_block, double nsigma, ui
 int launch_init(Batch &b, int *not_pd);
 int launch_refresh(Batch &b, int field, int *not_pd);
 // other kinds
-int launch_squareroot(const Batch &b, const StepArgs &a);
+int launch_squareroot_gen(const Batch &b, const StepArgs &a);
 int launch_information(const Batch &b, const StepArgs &a);
+int launch_srif_gen(const Batch &b, const StepArgs &a);
+int launch_hybrid_gen(const Batch &b, const StepArgs &a);
+int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)
 int launch_srif(const Batch &b, const StepArgs &a);
 int launch_hybrid(const Batch &b, const StepArgs &a);
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums);
+int mc_repl();
+// shared host helpers (kb_api.hip)
+int use_device(const Batch &b);
+int ensure_stage(Batch &b, size_t bytes);
+int stage_host_vec(Batch &b, const double *host, int rows, void **dblock);
+void fill_step_args(const Batch &b, StepArgs &a);
+int upload_field(Batch &b, int field, const double *host, int64_t count, int broadcast, int p_rows);
 
 inline dim3 tile_grid(int64_t ntiles) { return dim3((unsigned)((ntiles + 3) / 4)); }
 

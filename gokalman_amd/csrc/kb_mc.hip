@@ -1,0 +1,142 @@
+// kb_mc.hip -- Monte-Carlo fan-out (montecarlo.go:92-119) of a pure-predictor Vanilla filter
+// with AWGN process noise, and its per-step statistics (montecarlo.go:18-59).
+//
+// The reference runs `samples` runs sequentially on one filter object, Reset() between
+// runs (fresh noise seed), storing every Estimate; Mean(k)/StdDev(k) then gather state
+// component i over runs.  Here one lane = one run, all `steps` steps inside one launch:
+//   x_{k+1} = F x_k [+ G u_k] + L_Q z_k          (vanilla.go:138-146, predictionOnly)
+// and per step the wave reduces sum(d) and sum(d^2), d = x - c_k, with c_k the noise-free
+// trajectory (same for every run: it removes the mean before squaring, so the unbiased
+// variance does not cancel catastrophically when |mean| >> stddev, as in statOD5044).
+// Partial sums go to one of REPL replicas by float64 atomics; the host adds the replicas.
+// P is not propagated: it is identical for every run and does not influence x; the
+// batch is left Reset(), as the reference leaves its filter (montecarlo.go:116).
+#include "kb_internal.h"
+
+namespace kb {
+
+constexpr int MC_REPL = 32;
+
+template <typename T>
+__device__ __forceinline__ T ldm(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T, int NS, int NC>
+__global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__restrict__ controls, int ncontrols,
+                                                 double *__restrict__ sums /* [REPL][steps][2][NS] */,
+                                                 double *__restrict__ shift /* [steps][NS] */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    const T *st = (const T *)a.state + tile * ((int64_t)KB_TILE * a.L.st_elems) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    T x[NS], c[NS], F[NS * NS], LQ[tri(NS)];
+    [[maybe_unused]] T G[NC > 0 ? NS * NC : 1];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { x[i] = ldm(st, a.L.st_vec + i); c[i] = x[i]; }
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) F[e] = ldm(mo, a.L.mo_F + e);
+#pragma unroll
+    for (int e = 0; e < tri(NS); e++) LQ[e] = ldm(mo, a.L.mo_LQ + e);
+    if constexpr (NC > 0) {
+#pragma unroll
+        for (int e = 0; e < NS * NC; e++) G[e] = ldm(mo, a.L.mo_G + e);
+    }
+    double *my = sums + (size_t)(tile % MC_REPL) * a.nsteps * 2 * NS;
+    const uint64_t gfi = (uint64_t)(a.first_filter + fi);
+    for (int t = 0; t < a.nsteps; t++) {
+        T xn[NS], cn[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0), sc = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) { s += F[i * NS + l] * x[l]; sc += F[i * NS + l] * c[l]; }
+            xn[i] = s; cn[i] = sc;
+        }
+        if constexpr (NC > 0) {
+            const T *u = controls + (ncontrols == 1 ? 0 : (int64_t)t * NC);
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < NC; k++) s += G[i * NC + k] * (ncontrols == 1 ? T(0) : u[k]);
+                xn[i] = xn[i] + s; cn[i] = cn[i] + s;
+            }
+        }
+        // Noise.Process(k): w = L_Q z  (noise.go:133-136; distmv.Normal.Rand = mu + L z)
+        T z[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k += 2) {
+            uint32_t r[4];
+            Philox::gen(a.seed, gfi, (uint32_t)(a.step0 + t), ((uint32_t)(a.epoch * 4 + 0) << 8) | (uint32_t)(k >> 1), r);
+            double z0, z1;
+            box_muller(r, z0, z1);
+            z[k] = (T)z0;
+            if (k + 1 < NS) z[k + 1] = (T)z1;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k <= i; k++) s += LQ[symi(k, i)] * z[k];
+            x[i] = xn[i] + s;
+            c[i] = cn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const double dlt = active ? (double)x[i] - (double)c[i] : 0.0;
+            const double s1 = wave_sum(dlt), s2 = wave_sum(dlt * dlt);
+            if (lane == 0) {
+                atomicAdd(my + ((size_t)t * 2 + 0) * NS + i, s1);
+                atomicAdd(my + ((size_t)t * 2 + 1) * NS + i, s2);
+            }
+        }
+        if (tile == 0 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) shift[(size_t)t * NS + i] = (double)c[i];
+        }
+    }
+}
+
+template <typename T, int NS>
+static bool mc_try(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift) {
+    if (a.n != NS) return false;
+    const int nc = a.need_ctrl ? a.m : 0;
+    const dim3 grid = tile_grid(a.ntiles), block(256);
+    switch (nc) {
+    case 0: hipLaunchKernelGGL((mc_kernel<T, NS, 0>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift); return true;
+    case 1: hipLaunchKernelGGL((mc_kernel<T, NS, 1>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift); return true;
+    case 2: hipLaunchKernelGGL((mc_kernel<T, NS, 2>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift); return true;
+    }
+    return false;
+}
+
+template <typename T>
+static int launch_mc_t(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift) {
+    const bool ok = mc_try<T, 2>(b, a, d_controls, ncontrols, d_sums, d_shift) || mc_try<T, 3>(b, a, d_controls, ncontrols, d_sums, d_shift) ||
+                    mc_try<T, 4>(b, a, d_controls, ncontrols, d_sums, d_shift) || mc_try<T, 6>(b, a, d_controls, ncontrols, d_sums, d_shift);
+    if (!ok) {
+        set_error("kb_mc_run: no Monte-Carlo kernel for n=%d, m=%d (built: n in {2,3,4,6}, m <= 2)", a.n, a.need_ctrl ? a.m : 0);
+        return KB_ERR_UNSUPPORTED;
+    }
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+// d_sums: [MC_REPL][steps][2][n] followed by shift [steps][n]
+int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums) {
+    double *d_shift = d_sums + (size_t)MC_REPL * a.nsteps * 2 * a.n;
+    if (b.dtype == KB_F64) return launch_mc_t<double>(b, a, d_controls, ncontrols, d_sums, d_shift);
+    return launch_mc_t<float>(b, a, d_controls, ncontrols, d_sums, d_shift);
+}
+
+int mc_repl() { return MC_REPL; }
+
+}  // namespace kb

@@ -204,9 +204,10 @@ typedef enum {
  * not positive definite (the reference panics, noise.go:148-156).  `seed` replaces
  * the reference's wall-clock seed; every kb_reset moves to a fresh sub-stream. */
 int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed);
-/* Draws the AWGN vectors the filter with global index `i` would use at (epoch, step,
- * draw) -- for tests that replay the device's samples through the oracle.
- * which: 0 = Process (first call), 1 = Measurement, 2 = Process (second call). */
+/* The standard normals z behind the AWGN draw of the filter with global index `filter` at
+ * (epoch, step, which); the noise vector is chol_L(Q) z (which 0, 2; n values) or
+ * chol_L(R) z (which 1; p values).  For tests that replay the device's samples through the
+ * oracle.  which: 0 = Process (first call), 1 = Measurement, 2 = Process (second call). */
 int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, int which, double *out);
 
 /* ---- Monte-Carlo fan-out (montecarlo.go:92-119, 18-59) --------------------------- */
@@ -214,8 +215,11 @@ int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, in
  * KB_VANILLA_PREDICT batch (the reference panics otherwise, montecarlo.go:93-95) with
  * AWGN noise.  controls: host [steps][m], or [1][m] meaning zero controls for every step
  * (montecarlo.go:98-104), anything else is an error (a panic there).  Runs all N runs x
- * `steps` steps in one launch and accumulates, per step, sum and sum of squares of each
- * state component over this batch's runs:  sums[steps][2][n]  (host, float64).
+ * `steps` steps in one launch and accumulates, per step and state component, over this
+ * batch's runs:  sums[steps][3][n] (host, float64) = { sum(x - c), sum((x - c)^2), c }, where
+ * c is the noise-free trajectory (identical on every shard; subtracting it before squaring
+ * keeps the unbiased variance well conditioned).  Shards are combined by adding rows 0 and 1.
+ * The batch is left Reset() (montecarlo.go:116).
  * first_run = global index of this batch's first run (sharding across GPUs: the noise
  * stream of a run depends only on its global index). */
 int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols,
