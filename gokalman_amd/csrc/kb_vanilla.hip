@@ -22,6 +22,14 @@ template <typename T>
 __device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
 template <typename T>
 __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+// Streaming (read-once) operands -- the per-filter model F/H/Q/R/G and the measurements -- are
+// loaded non-temporally so that they do not displace the state block (x, P: re-read and
+// re-written every step, 226 MB at 1M filters) from the 256 MiB Infinity Cache.  Measured on
+// MI355X with the arithmetic removed: 0.208 ms -> 0.153 ms per 1M-filter step.
+template <typename T>
+__device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
+template <typename T>
+__device__ __forceinline__ T ldnt_at(const T *p) { return __builtin_nontemporal_load(p); }
 
 // ---------------------------------------------------------------------------------
 // register-resident kernel
@@ -47,19 +55,19 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
 #pragma unroll
     for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldt(mo, a.L.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(mo, a.L.mo_F + e);
 
     [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1];
     if constexpr (FUSED) {
 #pragma unroll
-        for (int e = 0; e < NM * NS; e++) H[e] = ldt(mo, a.L.mo_H + e);
+        for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
 #pragma unroll
-        for (int e = 0; e < TR; e++) Q[e] = ldt(mo, a.L.mo_Q + e);
+        for (int e = 0; e < TR; e++) Q[e] = ldnt(mo, a.L.mo_Q + e);
 #pragma unroll
-        for (int e = 0; e < TM; e++) R[e] = ldt(mo, a.L.mo_R + e);
+        for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
         if constexpr (NC > 0) {
 #pragma unroll
-            for (int e = 0; e < NS * NC; e++) G[e] = ldt(mo, a.L.mo_G + e);
+            for (int e = 0; e < NS * NC; e++) G[e] = ldnt(mo, a.L.mo_G + e);
         }
     }
 
@@ -78,13 +86,13 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
         if constexpr (NC > 0) {
             T u[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) u[c] = active ? up[(int64_t)t * a.u_step + (int64_t)c * a.u_es] : T(0);
+            for (int c = 0; c < NC; c++) u[c] = active ? ldnt_at(up + (int64_t)t * a.u_step + (int64_t)c * a.u_es) : T(0);
 #pragma unroll
             for (int i = 0; i < NS; i++) {
                 T s = T(0);
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    const T g = FUSED ? G[i * NC + c] : ldt(mo, a.L.mo_G + i * NC + c);
+                    const T g = FUSED ? G[i * NC + c] : ldnt(mo, a.L.mo_G + i * NC + c);
                     s += g * u[c];
                 }
                 xm[i] = xm[i] + s;
@@ -107,16 +115,16 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
                 T s = T(0);
 #pragma unroll
                 for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
-                const T q = FUSED ? Q[symi(i, j)] : ldt(mo, a.L.mo_Q + symi(i, j));
+                const T q = FUSED ? Q[symi(i, j)] : ldnt(mo, a.L.mo_Q + symi(i, j));
                 Pm[symi(i, j)] = s + q;
             }
         }
         // ---- measurement model
         if constexpr (!FUSED) {
 #pragma unroll
-            for (int e = 0; e < NM * NS; e++) H[e] = ldt(mo, a.L.mo_H + e);
+            for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
 #pragma unroll
-            for (int e = 0; e < TM; e++) R[e] = ldt(mo, a.L.mo_R + e);
+            for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
         }
         // ---- yhat = H x_prev (previous posterior, vanilla.go:155-157)
         [[maybe_unused]] T yhat[NM];
@@ -176,7 +184,7 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
             // ---- innovation and state update
 #pragma unroll
             for (int r = 0; r < NM; r++) {
-                const T yv = active ? yp[(int64_t)t * a.y_step + (int64_t)r * a.y_es] : T(0);
+                const T yv = active ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0);
                 T s = T(0);
 #pragma unroll
                 for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
