@@ -148,6 +148,10 @@ int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, in
     return KB_OK;
 }
 
+double kb_noise_normal(uint64_t seed, int64_t filter, int64_t epoch, int64_t step, int which, int k) {
+    return normal_at(seed, (uint64_t)filter, (uint32_t)step, (uint32_t)(epoch * 4 + which), k);
+}
+
 // ---- Monte-Carlo (montecarlo.go:92-119) ----------------------------------------------------
 int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols, int64_t first_run, double *sums) {
     if (!b || !sums) { set_error("null argument"); return KB_ERR_INVALID; }

@@ -209,6 +209,9 @@ int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed);
  * chol_L(R) z (which 1; p values).  For tests that replay the device's samples through the
  * oracle.  which: 0 = Process (first call), 1 = Measurement, 2 = Process (second call). */
 int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, int which, double *out);
+/* The same generator as a pure host function (no handle, no device): standard normal number k of
+ * the vector drawn by global filter index `filter` at (epoch, step, which) under `seed`. */
+double kb_noise_normal(uint64_t seed, int64_t filter, int64_t epoch, int64_t step, int which, int k);
 
 /* ---- Monte-Carlo fan-out (montecarlo.go:92-119, 18-59) --------------------------- */
 /* NewMonteCarloRuns(samples = N of the batch, steps, rowsH, controls, kf): `b` must be a

@@ -1,0 +1,310 @@
+// gokalman_amd.hpp -- header-only C++ host mirror of gokalman's filter interface over the C ABI
+// (gokalman_amd.h).  The reference's host language is Go; no Go toolchain exists in the build
+// image, so this is the compiled-language host layer: same type and method names, argument
+// meaning and error behaviour as kalman.go:35-72, noise.go:13-20 and the constructors, with every
+// object being a batch of N independent filters (N = 1 reproduces a reference filter object).
+//
+//   gokalman::Noiseless noise(Q, R);
+//   auto [kf, est0] = gokalman::NewVanilla(x0, P0, F, G, H, noise);      // vanilla.go:21
+//   gokalman::Estimate est = kf->Update(measurement, control);            // vanilla.go:128
+//   est.State(); est.Covariance(); est.IsWithinNσ(2);
+//
+// Matrices are row-major std::vector<double> wrapped in gokalman::Matrix {rows, cols, data};
+// for N > 1 `data` holds N matrices back to back (or one, shared by all filters).
+// Errors: the reference returns (nil, error) or panics; here every failure throws
+// gokalman::Error carrying the kb_status code and the reference's message.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gokalman_amd.h"
+
+namespace gokalman {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != KB_OK) throw Error(rc, kb_last_error());
+}
+
+struct Matrix {
+    int rows = 0, cols = 0;
+    std::vector<double> data;  // rows*cols (shared) or N*rows*cols (per filter)
+    Matrix() = default;
+    Matrix(int r, int c, std::vector<double> d) : rows(r), cols(c), data(std::move(d)) {}
+    Matrix(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0.0) {}
+    bool shared() const { return data.size() == (size_t)rows * cols; }
+    int64_t count() const { return rows * cols ? (int64_t)(data.size() / ((size_t)rows * cols)) : 0; }
+    double At(int i, int j, int64_t filter = 0) const { return data[(size_t)filter * rows * cols + (size_t)i * cols + j]; }
+};
+using Vector = Matrix;  // cols == 1
+inline Vector NewVector(int n, std::vector<double> d = {}) { return d.empty() ? Matrix(n, 1) : Matrix(n, 1, std::move(d)); }
+inline Matrix ScaledIdentity(int n, double s) {  // helper.go:13-23
+    Matrix m(n, n);
+    for (int i = 0; i < n; i++) m.data[(size_t)i * n + i] = s;
+    return m;
+}
+inline Matrix Identity(int n) { return ScaledIdentity(n, 1.0); }  // helper.go:44-46
+inline bool IsNil(const Matrix &m) {                               // helper.go:49-62
+    for (double v : m.data) if (v != 0.0) return false;
+    return true;
+}
+
+// noise.go:13-20.  Process/Measurement sampling happens on the device; the host object carries Q, R
+// and which implementation to use.
+struct Noise {
+    Matrix Q, R;
+    int kind = KB_NOISE_NOISELESS;
+    uint64_t seed = 0;
+    const Matrix &ProcessMatrix() const { return Q; }
+    const Matrix &MeasurementMatrix() const { return R; }
+};
+inline Noise NewNoiseless(Matrix Q, Matrix R) { return Noise{std::move(Q), std::move(R), KB_NOISE_NOISELESS, 0}; }       // noise.go:29-37
+inline Noise NewAWGN(Matrix Q, Matrix R, uint64_t seed = 0) { return Noise{std::move(Q), std::move(R), KB_NOISE_AWGN, seed}; }  // noise.go:117-121
+
+class Batch;  // owns the kb_batch
+
+// kalman.go:64-72.  Lazy: getters download from HBM (the reference's SquareRoot / Information /
+// SRIF estimates compute their covariance lazily as well).  Valid until the next Update.
+class Estimate {
+   public:
+    explicit Estimate(std::shared_ptr<Batch> b) : b_(std::move(b)) {}
+    Vector State() const;
+    Vector Measurement() const;
+    Vector Innovation() const;
+    Matrix Covariance() const;
+    Matrix PredCovariance() const;
+    Matrix Gain() const;
+    std::vector<uint8_t> IsWithinNσ(double N) const;
+    std::vector<uint8_t> IsWithin2σ() const { return IsWithinNσ(2); }
+
+   private:
+    std::shared_ptr<Batch> b_;
+};
+
+class Batch : public std::enable_shared_from_this<Batch> {
+   public:
+    Batch(int kind, int n, int p, int m, int64_t N, unsigned flags = KB_FLAG_FULL_ESTIMATE, int dtype = KB_F64, int device = 0)
+        : n_(n), N_(N) {
+        check(kb_create(&h_, kind, n, p, m, N, dtype, device, flags));
+    }
+    ~Batch() { kb_destroy(h_); }
+    Batch(const Batch &) = delete;
+    Batch &operator=(const Batch &) = delete;
+    kb_batch *handle() const { return h_; }
+    int n() const { return n_; }
+    int64_t N() const { return N_; }
+    void set(int field, const Matrix &m, int p_rows = 0) {
+        check(kb_set(h_, field, m.data.data(), m.shared() ? 1 : N_, m.shared() ? 1 : 0, p_rows));
+    }
+    Matrix get(int field, int rows, int cols) const {
+        Matrix out(rows, cols);
+        out.data.assign((size_t)N_ * rows * cols, 0.0);
+        check(kb_get(h_, field, out.data.data(), 0, N_));
+        return out;
+    }
+
+   private:
+    kb_batch *h_ = nullptr;
+    int n_;
+    int64_t N_;
+};
+
+inline Vector Estimate::State() const { return b_->get(KB_STATE, b_->n(), 1); }
+inline Vector Estimate::Measurement() const { return b_->get(KB_MEASUREMENT, kb_meas_dim(b_->handle()), 1); }
+inline Vector Estimate::Innovation() const { return b_->get(KB_INNOVATION, kb_meas_dim(b_->handle()), 1); }
+inline Matrix Estimate::Covariance() const { return b_->get(KB_COVAR, b_->n(), b_->n()); }
+inline Matrix Estimate::PredCovariance() const { return b_->get(KB_PRED_COVAR, b_->n(), b_->n()); }
+inline Matrix Estimate::Gain() const { return b_->get(KB_GAIN, b_->n(), kb_meas_dim(b_->handle())); }
+inline std::vector<uint8_t> Estimate::IsWithinNσ(double N) const {
+    std::vector<uint8_t> out((size_t)b_->N());
+    check(kb_is_within_nsigma(b_->handle(), N, out.data(), 0, b_->N()));
+    return out;
+}
+
+// kalman.go:35-47
+class LDKF {
+   public:
+    virtual ~LDKF() = default;
+    // Update(measurement, control *mat64.Vector) (Estimate, error)
+    Estimate Update(const Vector &measurement, const Vector &control) {
+        const std::vector<double> y = expand(measurement), u = expand(control);
+        check(kb_update(b_->handle(), y.data(), measurement.rows, control.rows ? u.data() : nullptr, control.rows));
+        return Estimate(b_);
+    }
+    const Noise &GetNoise() const { return noise_; }
+    const Matrix &GetStateTransition() const { return F_; }
+    const Matrix &GetInputControl() const { return G_; }
+    const Matrix &GetMeasurementMatrix() const { return H_; }
+    void SetStateTransition(const Matrix &F) { F_ = F; b_->set(KB_F, F); }
+    void SetInputControl(const Matrix &G) { G_ = G; b_->set(KB_G, G); }
+    void SetMeasurementMatrix(const Matrix &H) { H_ = H; b_->set(KB_H, H, H.rows); }
+    void SetNoise(const Noise &n) {
+        noise_ = n;
+        b_->set(KB_Q, n.Q);
+        b_->set(KB_R, n.R, n.R.rows);
+    }
+    void Reset() { check(kb_reset(b_->handle())); }
+    int64_t Step() const { return kb_step(b_->handle()); }
+    std::shared_ptr<Batch> batch() const { return b_; }
+
+   protected:
+    LDKF(int kind, const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &noise,
+         int64_t N, int pmax, unsigned flags)
+        : F_(F), G_(G), H_(H), noise_(noise) {
+        // checkMatDims at construction (vanilla.go:23-31), same messages
+        if (x0.rows != P0.cols) throw Error(KB_ERR_DIMS, dim2("x0", x0.rows, "Covar0", P0.cols));
+        if (F.rows != P0.cols) throw Error(KB_ERR_DIMS, dim2("F", F.rows, "Covar0", P0.cols));
+        if (H.cols != x0.rows) throw Error(KB_ERR_DIMS, "dimensions must agree: H(...x" + std::to_string(H.cols) + ") x0(" + std::to_string(x0.rows) + "x...)");
+        const int m = G.cols;  // needCtrl = !IsNil(G) is evaluated by kb_set(KB_G) (vanilla.go:39)
+        b_ = std::make_shared<Batch>(kind, x0.rows, pmax > H.rows ? pmax : H.rows, m, N, flags);
+        b_->set(KB_X, x0); b_->set(KB_P, P0); b_->set(KB_F, F);
+        if (m > 0) b_->set(KB_G, G);
+        b_->set(KB_H, H, H.rows); b_->set(KB_Q, noise.Q); b_->set(KB_R, noise.R, noise.R.rows);
+        if (noise.kind != KB_NOISE_NOISELESS) check(kb_set_noise_kind(b_->handle(), noise.kind, noise.seed));
+        check(kb_init(b_->handle()));
+    }
+    static std::string dim2(const char *a, int ra, const char *b, int cb) {
+        return std::string("dimensions must agree: ") + a + "(" + std::to_string(ra) + "x...) " + b + "(...x" + std::to_string(cb) + ")";
+    }
+    std::vector<double> expand(const Vector &v) const {  // one vector for every filter, or N vectors
+        if (v.rows == 0) return {};
+        if (!v.shared() || b_->N() == 1) return v.data;
+        std::vector<double> out;
+        out.reserve((size_t)b_->N() * v.rows);
+        for (int64_t i = 0; i < b_->N(); i++) out.insert(out.end(), v.data.begin(), v.data.end());
+        return out;
+    }
+    std::shared_ptr<Batch> b_;
+    Matrix F_, G_, H_;
+    Noise noise_;
+};
+
+struct Vanilla : LDKF {  // vanilla.go:65-74
+    Vanilla(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &n, bool predictOnly,
+            int64_t N, int pmax, unsigned flags)
+        : LDKF(predictOnly ? KB_VANILLA_PREDICT : KB_VANILLA, x0, P0, F, G, H, n, N, pmax, flags) {}
+};
+struct SquareRoot : LDKF {  // squareroot.go:53-63
+    SquareRoot(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &n, int64_t N, int pmax, unsigned flags)
+        : LDKF(KB_SQUAREROOT, x0, P0, F, G, H, n, N, pmax, flags) {}
+};
+struct Information : LDKF {  // information.go:84-95
+    Information(const Vector &i0, const Matrix &I0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &n, bool fromState,
+                int64_t N, int pmax, unsigned flags)
+        : LDKF(KB_INFORMATION, i0, I0, F, G, H, n, N, pmax, flags | (fromState ? KB_FLAG_INFO_FROM_STATE : 0u)) {}
+};
+
+using VanillaPair = std::pair<std::shared_ptr<Vanilla>, Estimate>;
+// NewVanilla(x0, Covar0, F, G, H, noise) (*Vanilla, *VanillaEstimate, error)   vanilla.go:21-40
+inline VanillaPair NewVanilla(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &noise,
+                              int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+    auto kf = std::make_shared<Vanilla>(x0, P0, F, G, H, noise, false, N, pmax, flags);
+    return {kf, Estimate(kf->batch())};
+}
+// NewPurePredictorVanilla   vanilla.go:43-62
+inline VanillaPair NewPurePredictorVanilla(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &noise,
+                                           int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+    auto kf = std::make_shared<Vanilla>(x0, P0, F, G, H, noise, true, N, pmax, flags);
+    return {kf, Estimate(kf->batch())};
+}
+// NewSquareRoot   squareroot.go:21-50
+inline std::pair<std::shared_ptr<SquareRoot>, Estimate> NewSquareRoot(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H,
+                                                                      const Noise &noise, int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+    auto kf = std::make_shared<SquareRoot>(x0, P0, F, G, H, noise, N, pmax, flags);
+    return {kf, Estimate(kf->batch())};
+}
+// NewInformation(i0, I0, ...)   information.go:20-53
+inline std::pair<std::shared_ptr<Information>, Estimate> NewInformation(const Vector &i0, const Matrix &I0, const Matrix &F, const Matrix &G, const Matrix &H,
+                                                                        const Noise &noise, int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+    auto kf = std::make_shared<Information>(i0, I0, F, G, H, noise, false, N, pmax, flags);
+    return {kf, Estimate(kf->batch())};
+}
+// NewInformationFromState(x0, P0, ...)   information.go:65-81
+inline std::pair<std::shared_ptr<Information>, Estimate> NewInformationFromState(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H,
+                                                                                 const Noise &noise, int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+    auto kf = std::make_shared<Information>(x0, P0, F, G, H, noise, true, N, pmax, flags);
+    return {kf, Estimate(kf->batch())};
+}
+
+// kalman.go:51-60
+class NLDKF {
+   public:
+    virtual ~NLDKF() = default;
+    void Prepare(const Matrix &Phi, const Matrix &Htilde) {
+        check(kb_prepare(b_->handle(), Phi.data.data(), Htilde.data.data(), Phi.shared() ? 1 : b_->N(), Phi.shared() ? 1 : 0));
+    }
+    Estimate Predict() { check(kb_predict_nl(b_->handle())); return Estimate(b_); }
+    Estimate Update(const Vector &realObservation, const Vector &computedObservation) {
+        const std::vector<double> r = expand(realObservation), c = expand(computedObservation);
+        check(kb_update_nl(b_->handle(), r.data(), realObservation.rows, c.data(), computedObservation.rows));
+        return Estimate(b_);
+    }
+    bool EKFEnabled() const { return kb_ekf_enabled(b_->handle()) != 0; }
+    void EnableEKF() { check(kb_set_ekf(b_->handle(), 1)); }
+    void DisableEKF() { check(kb_set_ekf(b_->handle(), 0)); }
+    void PreparePNT(const Matrix &Gamma) {
+        check(kb_prepare_pnt(b_->handle(), Gamma.data.data(), Gamma.shared() ? 1 : b_->N(), Gamma.shared() ? 1 : 0));
+    }
+    std::shared_ptr<Batch> batch() const { return b_; }
+
+   protected:
+    std::vector<double> expand(const Vector &v) const {
+        if (!v.shared() || b_->N() == 1) return v.data;
+        std::vector<double> out;
+        for (int64_t i = 0; i < b_->N(); i++) out.insert(out.end(), v.data.begin(), v.data.end());
+        return out;
+    }
+    std::shared_ptr<Batch> b_;
+};
+
+struct SRIF : NLDKF {  // NewSRIF(x0, P0, measSize, nonTriR, noise)   srif.go:14-49
+    SRIF(const Vector &x0, const Matrix &P0, int measSize, bool nonTriR, const Noise &n, int64_t N = 1, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+        if (x0.rows != P0.cols) throw Error(KB_ERR_DIMS, "dimensions must agree: x0(" + std::to_string(x0.rows) + "x...) P0(...x" + std::to_string(P0.cols) + ")");
+        (void)measSize;  // the reference only uses it to size Predict()'s zero vectors
+        b_ = std::make_shared<Batch>(KB_SRIF, x0.rows, n.R.rows, 0, N, flags | (nonTriR ? KB_FLAG_SRIF_NON_TRI_R : 0u));
+        b_->set(KB_X, x0); b_->set(KB_P, P0); b_->set(KB_R, n.R, n.R.rows);
+        check(kb_init(b_->handle()));
+    }
+    void SetNoise(const Noise &) { throw Error(KB_ERR_UNSUPPORTED, "noise not yet supported for SRIF"); }  // srif.go:76-78 (a panic there)
+};
+struct HybridKF : NLDKF {  // NewHybridKF(x0, P0, noise, measSize)   hybrid.go:23-34
+    HybridKF(const Vector &x0, const Matrix &P0, const Noise &n, int measSize, int64_t N = 1, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
+        if (x0.rows != P0.cols) throw Error(KB_ERR_DIMS, "dimensions must agree: x0(" + std::to_string(x0.rows) + "x...) Covar0(...x" + std::to_string(P0.cols) + ")");
+        b_ = std::make_shared<Batch>(KB_HYBRID, x0.rows, measSize, n.Q.rows, N, flags);
+        b_->set(KB_X, x0); b_->set(KB_P, P0); b_->set(KB_R, n.R, n.R.rows);
+        if (n.Q.rows > 0) b_->set(KB_Q, n.Q);
+        check(kb_init(b_->handle()));
+    }
+    void SetNoise(const Noise &n) { b_->set(KB_R, n.R, n.R.rows); if (n.Q.rows > 0) b_->set(KB_Q, n.Q); }  // hybrid.go:68-70
+};
+
+// montecarlo.go:12-59, :92-119
+struct MonteCarloRuns {
+    int64_t runs;
+    int steps, n;
+    std::vector<double> mean, stddev;  // [steps][n]
+    std::vector<double> Mean(int step) const { return {mean.begin() + (size_t)step * n, mean.begin() + (size_t)(step + 1) * n}; }
+    std::vector<double> StdDev(int step) const { return {stddev.begin() + (size_t)step * n, stddev.begin() + (size_t)(step + 1) * n}; }
+};
+inline MonteCarloRuns NewMonteCarloRuns(int64_t samples, int steps, int rowsH, const std::vector<Vector> &controls, Vanilla &kf) {
+    (void)rowsH;
+    if (kf.batch()->N() != samples) throw Error(KB_ERR_INVALID, "the batch must hold `samples` runs");
+    std::vector<double> ctrl;
+    for (const auto &c : controls) ctrl.insert(ctrl.end(), c.data.begin(), c.data.end());
+    const int n = kf.batch()->n();
+    std::vector<double> sums((size_t)steps * 3 * n);
+    check(kb_mc_run(kf.batch()->handle(), steps, ctrl.data(), (int)controls.size(), 0, sums.data()));
+    MonteCarloRuns r{samples, steps, n, std::vector<double>((size_t)steps * n), std::vector<double>((size_t)steps * n)};
+    check(kb_mc_stats(sums.data(), steps, n, samples, r.mean.data(), r.stddev.data()));
+    return r;
+}
+
+}  // namespace gokalman

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU (gloo, world_size 2): contiguous sharding of the run index and the Monte-Carlo
+statistics all-reduce.  Each rank simulates its shard of runs with the oracle's pure predictor fed
+by the engine's own counter-based noise (a run's draws depend only on its GLOBAL index), reduces
+the partial sums, and the result must equal the single-process statistics."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gokalman_amd import _capi as k
+from gokalman_amd import dist as kd
+from gokalman_amd.batch import MonteCarloRuns
+from oracle import oracle as orc
+
+F = np.array([[1, 0.1, 0, 7.726e-2], [4.015e-7, 1, 0, 1.545], [-2.319e-16, -1.732e-9, 1, 0.1], [-6.956e-15, -3.465e-8, 0, 1]])
+H = np.array([[1.0, 0, 0, 0], [0, 0, 1, 0]])
+Q = np.array([[6.669e-16, 1.001e-14, 3.823e-19, 5.150e-18], [1.001e-14, 2.002e-13, 1.030e-17, 1.545e-16],
+              [3.862e-19, 1.030e-17, 6.667e-19, 1.000e-17], [5.150e-18, 1.545e-16, 1.000e-17, 2.000e-16]])
+R = np.diag([2e-2, 2e-4])
+X0, P0 = np.array([2, 0.5, 0, 0.0]), np.diag([5, 1, 0.01, 1e-5])
+RUNS, STEPS, SEED = 37, 12, 4242
+
+
+def _simulate(lo, hi):
+    """states[step][run][n] of runs lo..hi-1 and the noise-free trajectory c[step][n]."""
+    LQ = orc.cholesky_lower(np.triu(Q) + np.triu(Q, 1).T)[1]
+    states = np.zeros((STEPS, hi - lo, 4))
+    for r in range(lo, hi):
+        f = orc.Filter.ldkf(orc.VANILLA_PREDICT, X0, P0, F, None, H, Q, R)
+        for t in range(STEPS):
+            z = np.array([k.lib().kb_noise_normal(SEED, r, 0, t, 0, i) for i in range(4)])
+            assert f.update(np.zeros(2), None, w_pred=LQ @ z) == orc.OK
+            states[t, r - lo] = f.state()
+    c = np.zeros((STEPS, 4))
+    x = X0.copy()
+    for t in range(STEPS):
+        x = F @ x
+        c[t] = x
+    return states, c
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = kd.shard_range(RUNS, rank, world)
+    states, c = _simulate(lo, hi)
+    d = states - c[:, None, :]
+    sums = np.stack([d.sum(axis=1), (d * d).sum(axis=1), c], axis=1)
+    sums[:, :2, :] = kd.allreduce_sum(np.ascontiguousarray(sums[:, :2, :]))
+    if rank == 0:
+        np.save(out, sums)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_partition_the_batch():
+    for n, w in [(1 << 20, 8), (37, 2), (5, 8), (64, 4)]:
+        spans = [kd.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_monte_carlo_statistics_allreduce_gloo_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sums.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    sums = np.load(out)
+    mc = MonteCarloRuns(RUNS, STEPS, 4, sums)
+    states, _ = _simulate(0, RUNS)
+    for t in range(STEPS):
+        mean, std = orc.mc_mean_stddev(states[t])
+        assert np.allclose(mc.mean(t), mean, rtol=1e-12, atol=0)
+        assert np.allclose(mc.stddev(t), std, rtol=1e-6, atol=0)
