@@ -9,9 +9,6 @@
 using namespace kb;
 
 namespace kb {
-int launch_squareroot(const Batch &b, const StepArgs &a, bool) { return launch_squareroot_gen(b, a); }
-int launch_srif(const Batch &b, const StepArgs &a) { return launch_srif_gen(b, a); }
-int launch_hybrid(const Batch &b, const StepArgs &a) { return launch_hybrid_gen(b, a); }
 }  // namespace kb
 
 static int ready_nl(kb_batch *b) {
@@ -34,6 +31,7 @@ int kb_prepare(kb_batch *b, const double *phi, const double *htilde, int64_t cou
     if (!phi || !htilde) { set_error("null argument"); return KB_ERR_INVALID; }
     if ((rc = kb_set(b, KB_F, phi, count, broadcast, 0))) return rc;
     if ((rc = kb_set(b, KB_H, htilde, count, broadcast, b->pmax))) return rc;
+    b->ext_phi = b->ext_h = nullptr;
     b->locked = 0;
     return KB_OK;
 }
@@ -42,8 +40,11 @@ int kb_prepare_dev(kb_batch *b, const void *phi, const void *htilde, int64_t ld)
     int rc = ready_nl(b);
     if (rc) return rc;
     if (!phi || !htilde) { set_error("null argument"); return KB_ERR_INVALID; }
-    if ((rc = kb_set_dev(b, KB_F, phi, ld, 0))) return rc;
-    if ((rc = kb_set_dev(b, KB_H, htilde, ld, b->pmax))) return rc;
+    if (ld < b->N) { set_error("ld < N"); return KB_ERR_INVALID; }
+    // zero-copy: the step kernel reads the caller's planar arrays directly (they must stay valid
+    // until the update has run); shapes without a register kernel get them packed at launch.
+    b->ext_phi = phi; b->ext_h = htilde; b->ext_ld = ld;
+    b->have[KB_F] = b->have[KB_H] = true;
     b->locked = 0;
     return KB_OK;
 }
@@ -65,6 +66,16 @@ static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
     int rc;
     if (b->locked) { set_error("kf is locked (call Prepare() first)"); return KB_ERR_LOCKED; }
     a.predict = predict ? 1 : 0;
+    if (b->ext_phi) {
+        a.ext_phi = b->ext_phi; a.ext_h = b->ext_h; a.ext_ld = b->ext_ld;
+        const bool reg = b->kind == KB_SRIF ? srif_reg_ok(*b, a) : hybrid_reg_ok(*b, a);
+        if (!reg) {  // generic kernel: materialise the model block first
+            if ((rc = kb_set_dev(b, KB_F, b->ext_phi, b->ext_ld, 0))) return rc;
+            if ((rc = kb_set_dev(b, KB_H, b->ext_h, b->ext_ld, b->pmax))) return rc;
+            b->ext_phi = b->ext_h = nullptr;
+            a.ext_phi = a.ext_h = nullptr;
+        }
+    }
     if ((rc = launch_nl(b, a))) return rc;
     b->step++;
     b->snc = 0;     // hybrid.go:201

@@ -1,0 +1,216 @@
+// kb_hybrid_reg.hip -- register-resident HybridKF update (hybrid.go:104-204) for the statOD-sized
+// ensemble (n = 6, p = 2): CKF or EKF, per-step Phi and H-tilde streamed from HBM (non-temporal),
+// x and packed P read and rewritten.  SNC (PreparePNT) and Predict() go through the generic kernel.
+// Algorithmic bytes per filter-step: x 6 + P 36 + Phi 36 + Htilde 12 + R 4 + real 2 + computed 2
+// read, x 6 + P 36 written = 1120 B.
+#include "kb_internal.h"
+#include "kb_static.h"
+
+namespace kb {
+
+template <typename T>
+__device__ __forceinline__ T hl(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+template <typename T>
+__device__ __forceinline__ T hnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
+template <typename T>
+__device__ __forceinline__ void hs(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+
+template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT>
+__global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
+    constexpr int TR = tri(NS);
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const bool active = tile * KB_TILE + lane < a.N;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
+    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
+    T x[NS], P[TR], F[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = hl(st, i);
+#pragma unroll
+    for (int e = 0; e < TR; e++) P[e] = hl(st, NS + e);
+    const int64_t fi = tile * KB_TILE + lane;
+    const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
+    const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) F[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : hnt(mo, a.L.mo_F + e);
+    // :114-116 PBar = Phi P Phi^T (upper triangle)
+    T Pm[TR];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        T fp[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += F[i * NS + l] * P[symi(l, k)];
+            fp[k] = s;
+        }
+#pragma unroll
+        for (int j = i; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
+            Pm[symi(i, j)] = s;
+        }
+    }
+    [[maybe_unused]] T xb[NS];
+    if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
+    T H[NM * NS], R[tri(NM)];
+#pragma unroll
+    for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : hnt(mo, a.L.mo_H + e);
+#pragma unroll
+    for (int e = 0; e < tri(NM); e++) R[e] = hnt(mo, a.L.mo_R + e);
+    // :146-153 K = PBar H^T (H PBar H^T + R)^-1
+    T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int c = 0; c < NM; c++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += Pm[symi(i, l)] * H[c * NS + l];
+            PHt[i * NM + c] = s;
+        }
+#pragma unroll
+    for (int r = 0; r < NM; r++)
+#pragma unroll
+        for (int c = 0; c < NM; c++) {
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
+            S[r * NM + c] = s + R[symi(r, c)];
+        }
+    unsigned err = inverse_lu<T, NM>(S, Si) ? KB_ST_SINGULAR : 0u;
+    smm_nn<T, NS, NM, NM>(PHt, Si, K);
+    // :156-173
+    T yv[NM], real[NM], innov[NM], xn[NS];
+#pragma unroll
+    for (int r = 0; r < NM; r++) {
+        real[r] = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
+        const T cv = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
+        yv[r] = real[r] - cv;
+        innov[r] = T(0);
+    }
+    if constexpr (EKF) {
+        smv<T, NS, NM>(K, yv, xn);
+    } else {
+#pragma unroll
+        for (int r = 0; r < NM; r++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += H[r * NS + l] * xb[l];
+            innov[r] = yv[r] - s;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
+            xn[i] = xb[i] + s;
+        }
+    }
+    // :174-182 Joseph form (upper): K R K^T + A PBar A^T
+    T Pn[TR];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        T kr[NM];
+#pragma unroll
+        for (int c = 0; c < NM; c++) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
+            kr[c] = s;
+        }
+#pragma unroll
+        for (int j = i; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
+            Pn[symi(i, j)] = s;
+        }
+    }
+    T A[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
+            A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
+        }
+    T chk = T(0);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        T ap[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
+            ap[k] = s;
+        }
+#pragma unroll
+        for (int j = i; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
+            Pn[symi(i, j)] = s + Pn[symi(i, j)];
+            chk += Pn[symi(i, j)] * T(0);
+        }
+        chk += xn[i] * T(0);
+    }
+    if (chk != chk) err |= KB_ST_NONFINITE;
+    if (active && !err) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) hs(st, i, xn[i]);
+#pragma unroll
+        for (int e = 0; e < TR; e++) hs(st, NS + e, Pn[e]);
+        if constexpr (FULL) {
+            T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+#pragma unroll
+            for (int e = 0; e < TR; e++) hs(es, a.L.es_ppred + e, Pm[e]);
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+#pragma unroll
+                for (int c = 0; c < NM; c++) hs(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+#pragma unroll
+            for (int r = 0; r < NM; r++) { hs(es, a.L.es_innov + r, innov[r]); hs(es, a.L.es_yhat + r, real[r]); hs(es, a.L.es_dobs + r, yv[r]); }
+        }
+    }
+    if (active && err) atomicOr(a.status + tile * KB_TILE + lane, err);
+}
+
+static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {
+    return a.n == NS && a.p == NM && !a.snc && !a.predict && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
+}
+
+template <typename T, int NS, int NM>
+static bool hybrid_try(const Batch &b, const StepArgs &a) {
+    if (!hybrid_shape_ok(a, NS, NM)) return false;
+    const dim3 grid = tile_grid(a.ntiles), block(256);
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+#define KB_H(E_, F_) do { if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true>), grid, block, 0, b.stream, a); \
+                          else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false>), grid, block, 0, b.stream, a); } while (0)
+    if (a.ekf) { if (full) KB_H(true, true); else KB_H(true, false); }
+    else       { if (full) KB_H(false, true); else KB_H(false, false); }
+#undef KB_H
+    return true;
+}
+
+bool hybrid_reg_ok(const Batch &b, const StepArgs &a) {
+    return b.dtype == KB_F64 && (hybrid_shape_ok(a, 6, 2) || hybrid_shape_ok(a, 6, 3));
+}
+
+int launch_hybrid(const Batch &b, const StepArgs &a) {
+    bool done = false;
+    if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a);
+    if (!done) return launch_hybrid_gen(b, a);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+}  // namespace kb

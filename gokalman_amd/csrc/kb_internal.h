@@ -59,6 +59,7 @@ struct Batch {
     void *d_ctrl = nullptr; size_t ctrl_bytes = 0;  // Monte-Carlo control sequence
     // NLDKF
     int ekf = 0, locked = 1, snc = 0;
+    const void *ext_phi = nullptr, *ext_h = nullptr; int64_t ext_ld = 0;  // kb_prepare_dev: caller's planar Phi / Htilde (zero-copy)
     // noise
     int noise_kind = KB_NOISE_NOISELESS;
     uint64_t seed = 0;
@@ -82,6 +83,7 @@ struct StepArgs {
     const void *y; int64_t y_es, y_ts, y_step;   // element stride, tile stride, step stride (elements)
     const void *y2; int64_t y2_es, y2_ts;        // NLDKF: computed observation
     const void *u; int64_t u_es, u_ts, u_step;
+    const void *ext_phi, *ext_h; int64_t ext_ld;   // NLDKF zero-copy model (planar, element e of filter i at ptr[e*ld + i])
     int64_t N, ntiles;
     int nsteps;
     int n, p, m, pmax;
@@ -118,6 +120,8 @@ int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)
 int launch_srif(const Batch &b, const StepArgs &a);
 int launch_hybrid(const Batch &b, const StepArgs &a);
+bool hybrid_reg_ok(const Batch &b, const StepArgs &a);
+bool srif_reg_ok(const Batch &b, const StepArgs &a);
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums);
 int mc_repl();
 // shared host helpers (kb_api.hip)

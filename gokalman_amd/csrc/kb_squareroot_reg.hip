@@ -1,0 +1,184 @@
+// kb_squareroot_reg.hip -- register-resident SquareRoot step (squareroot.go:129-274) for the
+// benchmark shapes: dimensions are template parameters, both QR panels live in VGPRs, and the
+// structural zeros of the panels (sqrtQ^T / sqrtR^T upper-triangular blocks) are skipped at
+// compile time.  Same one-filter-per-lane / AoSoA-64 mapping as kb_vanilla.hip; the model
+// (F, H, chol(Q), chol(R)) and the measurements are streamed with non-temporal loads so that
+// x and S stay resident in the Infinity Cache across steps.
+//
+// Per filter-step it reads x[n], S (packed lower), F[n^2], H[p n], chol(Q), chol(R) (packed), y[p]
+// and writes x, S: the same 1488 algorithmic bytes as Vanilla with S, sqrtQ, sqrtR in place of
+// P, Q, R.
+#include "kb_internal.h"
+#include "kb_static.h"
+
+namespace kb {
+
+template <typename T>
+__device__ __forceinline__ T ld_s(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+template <typename T>
+__device__ __forceinline__ T ld_nt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
+template <typename T>
+__device__ __forceinline__ void st_s(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+
+template <int NS>
+struct ActC {  // C = [S^T F^T ; sqrtQ^T]: bottom block row r' is non-zero in column k only when r' <= k
+    static constexpr bool active(int k, int r) { return r < NS || (r - NS) <= k; }
+};
+template <int NM>
+struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its column k are zero
+    static constexpr bool active(int k, int r) { return k >= NM || r >= NM; }
+};
+
+template <typename T, int NS, int NM, bool FULL>
+__global__ void __launch_bounds__(256, 2) squareroot_reg_kernel(const StepArgs a) {
+    constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const bool active = tile * KB_TILE + lane < a.N;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *yp = (const T *)a.y + tile * a.y_ts + lane;
+
+    T x[NS], S[TR], F[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = ld_s(st, i);
+#pragma unroll
+    for (int e = 0; e < TR; e++) S[e] = ld_s(st, NS + e);  // S[i][k], k <= i, at symi(k, i)
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) F[e] = ld_nt(mo, a.L.mo_F + e);
+
+    // :139-147 x- = F x
+    T xm[NS];
+    smv<T, NS, NS>(F, x, xm);
+    // :155-185 C = [S^T F^T ; sqrtQ^T] -> Uc; QUIRK S- := Uc (upper)
+    T C[2 * NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = i; l < NS; l++) s += S[symi(i, l)] * F[j * NS + l];  // S[l][i], l >= i
+            C[i * NS + j] = s;
+            C[(NS + i) * NS + j] = (j >= i) ? ld_nt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
+        }
+    sqr_r<T, 2 * NS, NS, ActC<NS>>(C);
+    // Sm[i][j] = C[i*NS+j], j >= i
+    T H[NM * NS];
+#pragma unroll
+    for (int e = 0; e < NM * NS; e++) H[e] = ld_nt(mo, a.L.mo_H + e);
+    // :190-216 Delta = [[sqrtR^T, 0],[S-^T H^T, S-^T]]
+    T D[DD * DD];
+#pragma unroll
+    for (int r = 0; r < DD; r++)
+#pragma unroll
+        for (int c = 0; c < DD; c++) {
+            T val;
+            if (c < NM) {
+                if (r < NM) {
+                    val = (c >= r) ? ld_nt(mo, a.L.mo_LR + symi(r, c)) : T(0);
+                } else {
+                    T s = T(0);  // (S-^T H^T)[r-NM][c] = sum_{l <= r-NM} Sm[l][r-NM] H[c][l]
+#pragma unroll
+                    for (int l = 0; l <= r - NM; l++) s += C[l * NS + (r - NM)] * H[c * NS + l];
+                    val = s;
+                }
+            } else if (r < NM) {
+                val = T(0);
+            } else {
+                val = (c - NM <= r - NM) ? C[(c - NM) * NS + (r - NM)] : T(0);  // S-^T[r-NM][c-NM] = Sm[c-NM][r-NM]
+            }
+            D[r * DD + c] = val;
+        }
+    [[maybe_unused]] T yhat[NM];
+    if constexpr (FULL) {
+        smv<T, NM, NS>(H, x, yhat);  // :237-239 yhat = H x_prev
+        T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+#pragma unroll
+                for (int j = i; j < NS; j++) st_s(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
+        }
+    }
+    sqr_r<T, DD, DD, ActD<NM>>(D);
+    // :225-252 Syy = UD[:p,:p]^T, W = UD[:p,p:]^T, K = W Syy^-1 (general inverse, error ignored)
+    T Syy[NM * NM], SyyI[NM * NM], K[NS * NM];
+#pragma unroll
+    for (int i = 0; i < NM; i++)
+#pragma unroll
+        for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? D[j * DD + i] : T(0);
+    inverse_lu<T, NM>(Syy, SyyI);
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int c = 0; c < NM; c++) {
+            T s = T(0);
+#pragma unroll
+            for (int k2 = 0; k2 < NM; k2++) s += D[k2 * DD + (NM + i)] * SyyI[k2 * NM + c];  // W[i][k2] = UD[k2][p+i]
+            K[i * NM + c] = s;
+        }
+    // :255-268
+    T innov[NM], xn[NS];
+#pragma unroll
+    for (int r = 0; r < NM; r++) {
+        const T yv = active ? __builtin_nontemporal_load(yp + (int64_t)r * a.y_es) : T(0);
+        T s = T(0);
+#pragma unroll
+        for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
+        innov[r] = yv - s;
+    }
+    T chk = T(0);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
+        xn[i] = xm[i] + s;
+        chk += xn[i] * T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) chk += D[(NM + j) * DD + (NM + i)] * T(0);
+    const bool ok = !(chk != chk);
+    if (active && ok) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) st_s(st, i, xn[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) st_s(st, NS + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
+        if constexpr (FULL) {
+            T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+#pragma unroll
+                for (int c = 0; c < NM; c++) st_s(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+#pragma unroll
+            for (int r = 0; r < NM; r++) { st_s(es, a.L.es_innov + r, innov[r]); st_s(es, a.L.es_yhat + r, yhat[r]); }
+        }
+    }
+    if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
+}
+
+template <typename T, int NS, int NM>
+static bool sqrt_try(const Batch &b, const StepArgs &a) {
+    if (a.n != NS || a.p != NM || a.sqrt_p != NM || a.need_ctrl || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    const dim3 grid = tile_grid(a.ntiles), block(256);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, true>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, false>), grid, block, 0, b.stream, a);
+    return true;
+}
+
+int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
+    bool done = false;
+    if (b.dtype == KB_F64) done = sqrt_try<double, 6, 3>(b, a) || sqrt_try<double, 4, 2>(b, a);
+    else done = sqrt_try<float, 6, 3>(b, a);
+    if (!done) return launch_squareroot_gen(b, a);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+}  // namespace kb

@@ -1,0 +1,118 @@
+// kb_static.h -- compile-time-dimension small dense algebra on register-resident arrays
+// (tightly packed row-major, every loop fully unrolled, no runtime indexing => no scratch).
+// Same algorithms and operation order as kb_dense.h / the oracle.
+#pragma once
+#include "kb_device.h"
+
+namespace kb {
+
+// C(R x C) = A(R x K) B(K x C)
+template <typename T, int R, int K, int C>
+__device__ __forceinline__ void smm_nn(const T (&A)[R * K], const T (&B)[K * C], T (&Cm)[R * C]) {
+#pragma unroll
+    for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < K; l++) s += A[i * K + l] * B[l * C + j];
+            Cm[i * C + j] = s;
+        }
+}
+// C(R x C) = A(R x K) B(C x K)^T
+template <typename T, int R, int K, int C>
+__device__ __forceinline__ void smm_nt(const T (&A)[R * K], const T (&B)[C * K], T (&Cm)[R * C]) {
+#pragma unroll
+    for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < K; l++) s += A[i * K + l] * B[j * K + l];
+            Cm[i * C + j] = s;
+        }
+}
+template <typename T, int R, int C>
+__device__ __forceinline__ void smv(const T (&A)[R * C], const T (&x)[C], T (&y)[R]) {
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < C; j++) s += A[i * C + j] * x[j];
+        y[i] = s;
+    }
+}
+
+// Dgeqr2 on a register panel a[M*N] (row-major), in place.  ACTIVE(k, r) tells at compile time
+// whether row r can hold a non-zero in column k when column k is eliminated (rows that are
+// structurally zero there are skipped: they would contribute exact zeros to the norm and to
+// every update, so results are unchanged).  On return the upper triangle holds R.
+struct AllRowsActive {
+    static constexpr bool active(int, int) { return true; }
+};
+template <typename T, int M, int N, typename ACT = AllRowsActive>
+__device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
+    constexpr int KMAX = M < N ? M : N;
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) {
+        T tau = T(0);
+        T xnorm2 = T(0);
+#pragma unroll
+        for (int r = i + 1; r < M; r++)
+            if (ACT::active(i, r)) xnorm2 += a[r * N + i] * a[r * N + i];
+        const T xnorm = sqrt(xnorm2);
+        const bool refl = (M - i > 1) && (xnorm != T(0));
+        const T alpha = a[i * N + i];
+        const T beta = -copysign(hypot(alpha, xnorm), alpha);
+        tau = refl ? (beta - alpha) / beta : T(0);
+        const T sc = refl ? T(1) / (alpha - beta) : T(0);
+#pragma unroll
+        for (int r = i + 1; r < M; r++)
+            if (ACT::active(i, r)) a[r * N + i] *= sc;   // v (zero when no reflection: the update below is then a no-op)
+        a[i * N + i] = refl ? beta : alpha;
+#pragma unroll
+        for (int c = i + 1; c < N; c++) {
+            T w = a[i * N + c];
+#pragma unroll
+            for (int r = i + 1; r < M; r++)
+                if (ACT::active(i, r)) w += a[r * N + i] * a[r * N + c];
+            const T tw = tau * w;
+            a[i * N + c] -= tw;
+#pragma unroll
+            for (int r = i + 1; r < M; r++)
+                if (ACT::active(i, r)) a[r * N + c] -= tw * a[r * N + i];
+        }
+    }
+}
+
+// helper.go:142-172 HouseholderTransf(A, n, m) on a register panel A[(NN+MM)*(NN+1)]
+template <typename T, int NN, int MM>
+__device__ __forceinline__ void shouseholder(T (&A)[(NN + MM) * (NN + 1)]) {
+    constexpr int ROWS = NN + MM, COLS = NN + 1;
+#pragma unroll
+    for (int k = 0; k < NN; k++) {
+        T sigma = T(0);
+#pragma unroll
+        for (int i = k; i < ROWS; i++) sigma += A[i * COLS + k] * A[i * COLS + k];
+        const T akk = A[k * COLS + k];
+        const T sgn = (akk == T(0) || fabs(akk) <= T(1e-12)) ? T(1) : akk / fabs(akk);
+        sigma = sqrt(sigma) * sgn;
+        const T uk = akk + sigma;
+        A[k * COLS + k] = -sigma;
+        const T beta = T(1) / (sigma * uk);
+#pragma unroll
+        for (int j = k + 1; j < COLS; j++) {
+            T gamma = uk * A[k * COLS + j];
+#pragma unroll
+            for (int i = k + 1; i < ROWS; i++) gamma += A[i * COLS + k] * A[i * COLS + j];
+            gamma *= beta;
+            A[k * COLS + j] = A[k * COLS + j] - gamma * uk;
+#pragma unroll
+            for (int i = k + 1; i < ROWS; i++) A[i * COLS + j] = A[i * COLS + j] - gamma * A[i * COLS + k];
+        }
+#pragma unroll
+        for (int i = k + 1; i < ROWS; i++) A[i * COLS + k] = T(0);
+    }
+}
+
+}  // namespace kb

@@ -1,0 +1,105 @@
+"""Throughput of the other SURVEY section 8d configs (C: SquareRoot, D: MC + Hybrid, E: SRIF fp32) and
+Information, through the C ABI with device-resident inputs.  Prints one JSON line per config.
+usage: python scripts/bench_kinds.py [sqrt info srif hybrid mc] [--n N]"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import gokalman_amd as ga
+from gokalman_amd import _capi as k, synth
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+which = args or ["sqrt", "info", "srif", "hybrid", "mc"]
+Nopt = None
+for a in sys.argv[1:]:
+    if a.startswith("--n="):
+        Nopt = int(a[4:])
+
+
+def timed(b, fn, K=20, warm=3):
+    s = torch.cuda.ExternalStream(b.stream())
+    for _ in range(warm):
+        fn()
+    b.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(K):
+        fn()
+    e1.record(s)
+    b.synchronize()
+    return e0.elapsed_time(e1) / K
+
+
+def report(name, N, ms, bytes_per, extra=None):
+    out = {"config": name, "filters": N, "ms_per_step": ms, "steps_per_s": N / (ms * 1e-3),
+           "algorithmic_GBps": N * bytes_per / (ms * 1e-3) / 1e9, "frac_of_8TBps": N * bytes_per / (ms * 1e-3) / 8e12}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+if "sqrt" in which or "info" in which:
+    N = Nopt or (1 << 20)
+    d = synth.linear_batch(N, 6, 3, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    for name, kind, fl in (("C: SquareRoot 6/3 f64", k.SQUAREROOT, 0), ("Information 6/3 f64 (from state)", k.INFORMATION, k.FLAG_INFO_FROM_STATE)):
+        if ("sqrt" in which and kind == k.SQUAREROOT) or ("info" in which and kind == k.INFORMATION):
+            b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=fl)
+            ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+            report(name, N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))})
+            del b
+
+if "srif" in which:
+    N = Nopt or (1 << 18)
+    n, p = 12, 6
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    for dt, nm, w in ((k.F32, "E: SRIF 12/6 f32", 4), (k.F64, "SRIF 12/6 f64", 8)):
+        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dt)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        tdt = torch.float32 if dt == k.F32 else torch.float64
+        Phi = (torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=tdt, device="cuda")).contiguous()
+        Ht = torch.randn(p * n, N, dtype=tdt, device="cuda")
+        real = torch.randn(p, N, dtype=tdt, device="cuda"); comp = real + 1e-2 * torch.randn(p, N, dtype=tdt, device="cuda")
+        b.prepare_dev = lambda: k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
+        def step():
+            b.prepare_dev()
+            k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
+        ms = timed(b, step, K=10)
+        # update only (model already resident): re-arm the lock without re-uploading
+        report(nm + " (prepare_dev + update_nl_dev)", N, ms, 576 * w, {"errors": int(np.count_nonzero(b.status()))})
+        del b
+
+if "hybrid" in which:
+    N = Nopt or (1 << 20)
+    n, p = 6, 2
+    rng = np.random.default_rng(6)
+    x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10, 10, 10, 1, 1, 1]
+    b = ga.FilterBatch(k.HYBRID, n, p, 0, N)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, np.diag([1e-6, 1e-6]), 2, p_rows=p); b.init(); b.enable_ekf()
+    Phi = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=torch.float64, device="cuda")).contiguous()
+    Ht = torch.randn(p * n, N, dtype=torch.float64, device="cuda")
+    real = torch.randn(p, N, dtype=torch.float64, device="cuda"); comp = real + 1e-3 * torch.randn(p, N, dtype=torch.float64, device="cuda")
+    def step():
+        k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
+        k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
+    ms = timed(b, step, K=10)
+    report("D(ii): Hybrid EKF 6/2 f64 (prepare_dev + update_nl_dev)", N, ms, 1120, {"errors": int(np.count_nonzero(b.status()))})
+    del b
+
+if "mc" in which:
+    from tests.test_kinds_gpu import STATOD as s
+    runs, steps = Nopt or (1 << 20), 1086
+    kf = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, s["x0"], s["P0"], s["F"], s["G"], s["H"], s["Q"], s["R"],
+                                 nfilters=runs, noise=k.NOISE_AWGN, seed=1)
+    ga.new_monte_carlo_runs(runs, 8, 2, np.zeros((1, 2)), kf)
+    t = time.perf_counter()
+    mc = ga.new_monte_carlo_runs(runs, steps, 2, np.zeros((1, 2)), kf)
+    dt = time.perf_counter() - t
+    print(json.dumps({"config": "D(i): MC pure-predictor statOD5044 n=4, AWGN", "runs": runs, "steps": steps, "seconds": dt,
+                      "run_steps_per_s": runs * steps / dt, "stddev_last": mc.stddev(steps - 1).tolist()}), flush=True)

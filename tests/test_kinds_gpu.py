@@ -249,3 +249,33 @@ def test_awgn_moments_and_vanilla_awgn_replay():
     with pytest.raises(ga.KalmanError):
         ga.FilterBatch.new_ldkf(k.VANILLA, np.zeros(2), np.eye(2), np.eye(2), None, np.array([[1.0, 0]]), bad, np.eye(1),
                                 noise=k.NOISE_AWGN)
+
+
+@pytest.mark.parametrize("kind,n,p", [(k.HYBRID, 6, 2), (k.SRIF, 12, 6), (k.SRIF, 6, 2)])
+def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p):
+    """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
+    import torch
+    rng = np.random.default_rng(21)
+    N, steps = 200, 3
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.tile(np.diag(np.full(p, 1e-3)), (N, 1, 1))
+    Phi, Ht, real, comp = _nl_models(N, n, p, steps, rng)
+
+    def make():
+        b = ga.FilterBatch(kind, n, p, 0, N)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        return b
+
+    host, dev = make(), make()
+    for t in range(steps):
+        host.prepare(Phi[t], Ht[t]); host.update_nl(real[t], comp[t])
+        dphi = torch.from_numpy(np.ascontiguousarray(Phi[t].reshape(N, n * n).T)).cuda()
+        dh = torch.from_numpy(np.ascontiguousarray(Ht[t].reshape(N, p * n).T)).cuda()
+        dr = torch.from_numpy(np.ascontiguousarray(real[t].T)).cuda(); dc = torch.from_numpy(np.ascontiguousarray(comp[t].T)).cuda()
+        k.check(k.lib().kb_prepare_dev(dev._h, dphi.data_ptr(), dh.data_ptr(), N))
+        k.check(k.lib().kb_update_nl_dev(dev._h, dr.data_ptr(), dc.data_ptr(), N))
+        dev.synchronize()
+    assert synth.rel_frobenius(dev.get(k.RAW_VEC), host.get(k.RAW_VEC)) <= 1e-13
+    assert synth.rel_frobenius(dev.get(k.RAW_MAT), host.get(k.RAW_MAT)) <= 1e-13
+    assert dev.step() == steps and not dev.status().any()
