@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--filters", type=int, default=1 << 20, help="filters per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-steps", type=int, default=16, help="T of the extra time-fused measurement (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing the N>1 path on fewer GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -80,10 +81,17 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and world > ndev:
+        raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank" % (world, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     import gokalman_amd as ga
     from gokalman_amd import _capi as k
@@ -118,7 +126,7 @@ def main():
     local_s = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the kernel's stream
     if world > 1:
-        tt = torch.tensor([local_s], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([local_s], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall_s = float(tt.item())
         dist.barrier()

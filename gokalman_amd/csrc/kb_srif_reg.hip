@@ -4,10 +4,15 @@
 // VGPRs (1 wave/SIMD, 512-register budget); Phi / H-tilde are read in place from the caller's
 // planar arrays after kb_prepare_dev (zero-copy) or from the model block after kb_prepare.
 //
+// Two launches per Update, mirroring the reference's own split: the time update
+// (srif.go:111-141, also the whole of Predict()) rewrites (b, R) as (bBar, RBar) in place, the
+// measurement update (srif.go:143-156, :298-340) runs the Householder panel on it.  RBar
+// (164 MB at 256k filters) stays in the Infinity Cache between the two.
 // Differences from the statement-by-statement generic kernel (rounding level only):
-//   State(prev) = R^-1 b is obtained by an LU solve instead of inverse-then-multiply
-//   (srif.go:223-234), and only exact singularity / non-finite results are flagged (the
-//   generic kernel also applies gonum's cond > 1e16 test).
+//   State(prev) = R^-1 b and RBar = R Phi^-1 are obtained by LU solves instead of
+//   inverse-then-multiply (srif.go:111-115, :223-234); only exact singularity / non-finite
+//   results are flagged (the generic kernel also applies gonum's cond > 1e16 test); a filter
+//   whose status word is non-zero is skipped by the measurement kernel until kb_clear_status.
 // Algorithmic bytes per filter-step: b 12 + R 144 + Phi 144 + Htilde 72 +
 // L 36 + real 6 + computed 6 read, b 12 + R 144 written = 576 elements = 2304 B in fp32.
 #include "kb_internal.h"
@@ -71,9 +76,77 @@ __device__ __forceinline__ bool lu_solve_inplace(T (&a)[P * P], T (&b)[P * C]) {
     return bad;
 }
 
-template <typename T, int NS, int NM, bool FULL, bool EXT>
-__global__ void __launch_bounds__(256, 1) srif_reg_kernel(const StepArgs a) {
-    constexpr int COLS = NS + 1;
+// LU factorisation with partial pivoting in place (unit-lower L below the diagonal, U on and
+// above), recording every row exchange as one bit (exchange index = position in the (j, r) loop
+// nest) so that later right-hand sides can be permuted without keeping a permutation matrix.
+template <typename T, int P>
+__device__ __forceinline__ bool lu_factor_record(T (&a)[P * P], unsigned (&bits)[(P * (P - 1) / 2 + 31) / 32]) {
+    bool bad = false;
+#pragma unroll
+    for (int w = 0; w < (P * (P - 1) / 2 + 31) / 32; w++) bits[w] = 0u;
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+#pragma unroll
+        for (int r = j + 1; r < P; r++) {
+            const bool sw = fabs(a[r * P + j]) > fabs(a[j * P + j]);
+            bits[idx >> 5] |= (sw ? 1u : 0u) << (idx & 31);
+            idx++;
+#pragma unroll
+            for (int c = 0; c < P; c++) {  // whole rows: the L part moves with its row (LAPACK dlaswp)
+                const T t0 = a[j * P + c], t1 = a[r * P + c];
+                a[j * P + c] = sw ? t1 : t0;
+                a[r * P + c] = sw ? t0 : t1;
+            }
+        }
+        const T piv = a[j * P + j];
+        bad = bad || (piv == T(0));
+        const T rp = T(1) / piv;
+#pragma unroll
+        for (int r = j + 1; r < P; r++) {
+            const T l = a[r * P + j] * rp;
+            a[r * P + j] = l;
+#pragma unroll
+            for (int c = j + 1; c < P; c++) a[r * P + c] -= l * a[j * P + c];
+        }
+    }
+    return bad;
+}
+
+// z = r A^-1 for a row vector r, given the recorded LU of A (P A = L U): w U = r, v L = w, z = v P.
+template <typename T, int P>
+__device__ __forceinline__ void lu_row_solve(const T (&lu)[P * P], const unsigned (&bits)[(P * (P - 1) / 2 + 31) / 32], T (&z)[P]) {
+#pragma unroll
+    for (int j = 0; j < P; j++) {  // w U = r
+        T s = z[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= z[k] * lu[k * P + j];
+        z[j] = s / lu[j * P + j];
+    }
+#pragma unroll
+    for (int j = P - 1; j >= 0; j--) {  // v L = w (unit lower)
+        T s = z[j];
+#pragma unroll
+        for (int k = j + 1; k < P; k++) s -= z[k] * lu[k * P + j];
+        z[j] = s;
+    }
+    int idx = P * (P - 1) / 2 - 1;  // z = v P: undo the exchanges in reverse order
+#pragma unroll
+    for (int j = P - 1; j >= 0; j--)
+#pragma unroll
+        for (int r = P - 1; r > j; r--) {
+            const bool sw = (bits[idx >> 5] >> (idx & 31)) & 1u;
+            idx--;
+            const T t0 = z[j], t1 = z[r];
+            z[j] = sw ? t1 : t0;
+            z[r] = sw ? t0 : t1;
+        }
+}
+
+// ---- time update (srif.go:111-141): b <- bBar, R <- RBar = R Phi^-1, in place -------------------
+template <typename T, int NS, bool FULL, bool EXT>
+__global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
+    constexpr int NB = (NS * (NS - 1) / 2 + 31) / 32;
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
@@ -82,14 +155,9 @@ __global__ void __launch_bounds__(256, 1) srif_reg_kernel(const StepArgs a) {
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
-    const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
-    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
-    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
     unsigned err = 0;
-
-    // State(prev) = R^-1 b  (srif.go:223-234)
     T xprev[NS];
-    {
+    {   // State(prev) = R^-1 b (srif.go:223-234)
         T Rw[NS * NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) xprev[i] = sl(st, i);
@@ -97,38 +165,72 @@ __global__ void __launch_bounds__(256, 1) srif_reg_kernel(const StepArgs a) {
         for (int e = 0; e < NS * NS; e++) Rw[e] = sl(st, NS + e);
         if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;
     }
-    // xBar = Phi xprev; Phi^-1  (srif.go:111-118)
-    T xBar[NS], invPhi[NS * NS];
-    {
-        T Phi[NS * NS];
+    // keep the machine scheduler from hoisting the next phase's loads above this one: the phases are
+    // sized to fit the register file one at a time (other waves cover the load latency)
+    __builtin_amdgcn_sched_barrier(0);
+    T Phi[NS * NS], xBar[NS];
+    unsigned bits[NB];
 #pragma unroll
-        for (int e = 0; e < NS * NS; e++) Phi[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : snt(mo, a.L.mo_F + e);
-        smv<T, NS, NS>(Phi, xprev, xBar);
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) invPhi[i * NS + j] = (i == j) ? T(1) : T(0);
-        if (lu_solve_inplace<T, NS, NS>(Phi, invPhi)) err |= KB_ST_SINGULAR;
-    }
-    // panel A = [[RBar, bBar],[L Htilde, L y]], RBar = R Phi^-1, bBar = RBar xBar (srif.go:115-119, :298-320)
-    T A[(NS + NM) * COLS];
+    for (int e = 0; e < NS * NS; e++) Phi[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : snt(mo, a.L.mo_F + e);
+    smv<T, NS, NS>(Phi, xprev, xBar);                      // :118 xBar = Phi State(prev)
+    if (lu_factor_record<T, NS>(Phi, bits)) err |= KB_ST_SINGULAR;  // :111-114
+    if (err) { if (active) atomicOr(a.status + fi, err); return; }
     T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
+    T bBar[NS], znext[NS];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int l = 0; l < NS; l++) znext[l] = sl(st, NS + l);  // row 0 of R again: cache hit
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        T Ri[NS];
+        T z[NS];
 #pragma unroll
-        for (int l = 0; l < NS; l++) Ri[l] = sl(st, NS + i * NS + l);  // second read of row i: L2 / Infinity Cache hit
+        for (int l = 0; l < NS; l++) z[l] = znext[l];
+        if (i + 1 < NS) {
+#pragma unroll
+            for (int l = 0; l < NS; l++) znext[l] = sl(st, NS + (i + 1) * NS + l);  // prefetch the next row
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lu_row_solve<T, NS>(Phi, bits, z);                 // :115 row i of RBar = R Phi^-1
         T bb = T(0);
 #pragma unroll
-        for (int j = 0; j < NS; j++) {
-            T s = T(0);
+        for (int j = 0; j < NS; j++) bb += z[j] * xBar[j];  // :119 bBar = RBar xBar
+        bBar[i] = bb;
+        if (active) {
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += Ri[l] * invPhi[l * NS + j];
-            A[i * COLS + j] = s;
-            bb += s * xBar[j];
-            if constexpr (FULL) { if (active) ss(es, a.L.es_ppred + i * NS + j, s); }
+            for (int j = 0; j < NS; j++) {
+                ss(st, NS + i * NS + j, z[j]);
+                if constexpr (FULL) ss(es, a.L.es_ppred + i * NS + j, z[j]);
+            }
         }
-        A[i * COLS + NS] = bb;
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) ss(st, i, bBar[i]);
+    }
+}
+
+// ---- measurement update (srif.go:143-156, :298-340): Householder on [[RBar bBar],[L Htilde, L y]] --
+template <typename T, int NS, int NM, bool FULL, bool EXT>
+__global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
+    constexpr int COLS = NS + 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    if (active && a.status[fi] != 0u) return;  // failed (now or earlier): the estimate stays frozen
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
+    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
+    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
+    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
+    T A[(NS + NM) * COLS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) A[i * COLS + j] = sl(st, NS + i * NS + j);
+        A[i * COLS + NS] = sl(st, i);
     }
     {
         T Lw[tri(NM)], yv[NM];
@@ -170,8 +272,8 @@ __global__ void __launch_bounds__(256, 1) srif_reg_kernel(const StepArgs a) {
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = i; j < COLS; j++) chk += A[i * COLS + j] * T(0);
-    if (chk != chk) err |= KB_ST_NONFINITE;
-    if (active && !err) {
+    const bool bad = chk != chk;
+    if (active && !bad) {
 #pragma unroll
         for (int i = 0; i < NS; i++) ss(st, i, A[i * COLS + NS]);
 #pragma unroll
@@ -183,20 +285,26 @@ __global__ void __launch_bounds__(256, 1) srif_reg_kernel(const StepArgs a) {
             for (int r = 0; r < NM; r++) ss(es, a.L.es_innov + r, A[(NS + r) * COLS + NS]);
         }
     }
-    if (active && err) atomicOr(a.status + fi, err);
+    if (active && bad) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
 }
 
-static bool srif_shape_ok(const StepArgs &a, int NS, int NM) { return a.n == NS && a.p == NM && !a.predict; }
+static bool srif_shape_ok(const StepArgs &a, int NS, int NM) { return a.n == NS && a.p == NM; }
 
 template <typename T, int NS, int NM>
 static bool srif_try(const Batch &b, const StepArgs &a) {
     if (!srif_shape_ok(a, NS, NM)) return false;
     const dim3 grid = tile_grid(a.ntiles), block(256);
-    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
-#define KB_S(F_) do { if (a.ext_phi) hipLaunchKernelGGL((srif_reg_kernel<T, NS, NM, F_, true>), grid, block, 0, b.stream, a); \
-                      else hipLaunchKernelGGL((srif_reg_kernel<T, NS, NM, F_, false>), grid, block, 0, b.stream, a); } while (0)
-    if (full) KB_S(true); else KB_S(false);
-#undef KB_S
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
+#define KB_T(F_, E_) hipLaunchKernelGGL((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a)
+#define KB_M(F_, E_) hipLaunchKernelGGL((srif_meas_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
+    if (full) { if (ext) KB_T(true, true); else KB_T(true, false); }
+    else      { if (ext) KB_T(false, true); else KB_T(false, false); }
+    if (!a.predict) {
+        if (full) { if (ext) KB_M(true, true); else KB_M(true, false); }
+        else      { if (ext) KB_M(false, true); else KB_M(false, false); }
+    }
+#undef KB_T
+#undef KB_M
     return true;
 }
 
