@@ -159,7 +159,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))  # measured at tj["filters"] filters per launch; scales linearly with the batch
+                traffic = tj["hbm_bytes_per_launch"] * (N / float(tj.get("filters", 1 << 20)))
             except Exception:
                 traffic = None
         out = {

@@ -1,0 +1,156 @@
+// kb_information_reg.hip -- register-resident Information filter step (information.go:153-227)
+// for the benchmark shape (n = 6, p = 3, fp64), state-only outputs (i+, I+).  Batches created
+// with KB_FLAG_FULL_ESTIMATE (which also need yhat = H State(prev), i.e. one more n x n inverse,
+// and I-) and the stale-1x1-Rinv quirk go through the generic kernel.
+// Per filter-step it reads i[n], I (packed), F^-1 [n^2], Q^-1 [n^2], H [p n], R^-1 [p^2], y[p] and
+// writes i, I.  The (M + Q^-1)^-1 inverse is the LU-pivoted register inverse (kb_device.h).
+#include "kb_internal.h"
+#include "kb_static.h"
+
+namespace kb {
+
+template <typename T>
+__device__ __forceinline__ T il(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+template <typename T>
+__device__ __forceinline__ T intl(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
+template <typename T>
+__device__ __forceinline__ void is(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+
+template <typename T, int NS, int NM>
+__global__ void __launch_bounds__(256, 2) information_reg_kernel(const StepArgs a) {
+    constexpr int TR = tri(NS);
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const bool active = tile * KB_TILE + lane < a.N;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *yp = (const T *)a.y + tile * a.y_ts + lane;
+    T iv[NS], I[TR], Fi[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) iv[i] = il(st, i);
+#pragma unroll
+    for (int e = 0; e < TR; e++) I[e] = il(st, NS + e);
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) Fi[e] = intl(mo, a.L.mo_Finv + e);
+    // :163-165 zk = Finv^T (I Finv)
+    T t1[NS * NS], zk[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += I[symi(i, l)] * Fi[l * NS + j];
+            t1[i * NS + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += Fi[l * NS + i] * t1[l * NS + j];
+            zk[i * NS + j] = s;
+        }
+    // iKp1Minus (first half, :176-177): Finv^T i
+    T im[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        T s = T(0);
+#pragma unroll
+        for (int i = 0; i < NS; i++) s += Fi[i * NS + j] * iv[i];
+        im[j] = s;
+    }
+    // :169-174 Z = -zk (zk + Qinv)^-1   (inverse error ignored by the reference)
+    T zq[NS * NS], zqi[NS * NS], Z[NS * NS];
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) zq[e] = zk[e] + intl(mo, a.L.mo_Qinv + e);
+    inverse_lu<T, NS>(zq, zqi);
+    smm_nn<T, NS, NS, NS>(zk, zqi, Z);
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) Z[e] = T(-1) * Z[e];
+    // :183-185 i- = (1 + Z) i-
+    T imn[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < NS; j++) s += ((i == j ? T(1) : T(0)) + Z[i * NS + j]) * im[j];
+        imn[i] = s;
+    }
+    // :188-190 I- = zk + Z zk^T (upper triangle)
+    T Im[TR];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = i; j < NS; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += Z[i * NS + l] * zk[j * NS + l];
+            Im[symi(i, j)] = zk[i * NS + j] + s;
+        }
+    // :197-212 HTR = H^T Rinv; i+ = HTR y + i-; I+ = I- + HTR H
+    T H[NM * NS], Ri[NM * NM], HTR[NS * NM];
+#pragma unroll
+    for (int e = 0; e < NM * NS; e++) H[e] = intl(mo, a.L.mo_H + e);
+#pragma unroll
+    for (int e = 0; e < NM * NM; e++) Ri[e] = intl(mo, a.L.mo_Rinv + e);
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NM; j++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NM; l++) s += H[l * NS + i] * Ri[l * NM + j];
+            HTR[i * NM + j] = s;
+        }
+    T chk = T(0);
+    T ip[NS], Ip[TR];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < NM; j++) {
+            const T yv = active ? __builtin_nontemporal_load(yp + (int64_t)j * a.y_es) : T(0);
+            s += HTR[i * NM + j] * yv;
+        }
+        ip[i] = s + imn[i];
+        chk += ip[i] * T(0);
+#pragma unroll
+        for (int j = i; j < NS; j++) {
+            T s2 = T(0);
+#pragma unroll
+            for (int l = 0; l < NM; l++) s2 += HTR[i * NM + l] * H[l * NS + j];
+            Ip[symi(i, j)] = Im[symi(i, j)] + s2;
+            chk += Ip[symi(i, j)] * T(0);
+        }
+    }
+    const bool ok = !(chk != chk);
+    if (active && ok) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) is(st, i, ip[i]);
+#pragma unroll
+        for (int e = 0; e < TR; e++) is(st, NS + e, Ip[e]);
+    }
+    if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
+}
+
+template <typename T, int NS, int NM>
+static bool info_try(const Batch &b, const StepArgs &a) {
+    if (a.n != NS || a.p != NM || a.rinv_p != NM || a.need_ctrl || a.nsteps != 1 || (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) ||
+        a.noise_kind != KB_NOISE_NOISELESS)
+        return false;
+    hipLaunchKernelGGL((information_reg_kernel<T, NS, NM>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a);
+    return true;
+}
+
+int launch_information(const Batch &b, const StepArgs &a) {
+    bool done = false;
+    if (b.dtype == KB_F64) done = info_try<double, 6, 3>(b, a) || info_try<double, 4, 2>(b, a);
+    if (!done) return launch_information_gen(b, a);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+}  // namespace kb

@@ -114,7 +114,8 @@ int launch_init(Batch &b, int *not_pd);
 int launch_refresh(Batch &b, int field, int *not_pd);
 // other kinds
 int launch_squareroot_gen(const Batch &b, const StepArgs &a);
-int launch_information(const Batch &b, const StepArgs &a);
+int launch_information(const Batch &b, const StepArgs &a);   // kb_information_reg.hip (falls back to _gen)
+int launch_information_gen(const Batch &b, const StepArgs &a);
 int launch_srif_gen(const Batch &b, const StepArgs &a);
 int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)

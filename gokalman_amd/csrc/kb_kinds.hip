@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
     } while (0)
 
 int launch_squareroot_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(squareroot_gen_kernel); return KB_OK; }
-int launch_information(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(information_gen_kernel); return KB_OK; }
+int launch_information_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(information_gen_kernel); return KB_OK; }
 int launch_srif_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(srif_gen_kernel); return KB_OK; }
 int launch_hybrid_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(hybrid_gen_kernel); return KB_OK; }
 
