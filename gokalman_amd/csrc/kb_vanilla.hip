@@ -57,19 +57,27 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
 #pragma unroll
     for (int e = 0; e < NS * NS; e++) F[e] = ldnt(mo, a.L.mo_F + e);
 
-    [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1];
-    if constexpr (FUSED) {
+    // Issue order is pinned with scheduling barriers: (1) x, P, F -- everything the prediction
+    // needs -- then (2) Q, H, R [, G] and the first measurement, then the arithmetic.  The
+    // compiler's in-order vmcnt accounting then lets the prediction start as soon as group (1) has
+    // landed while group (2) is still in flight.
+    __builtin_amdgcn_sched_barrier(0);
+    [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1], y0[NM];
 #pragma unroll
-        for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
+    for (int e = 0; e < TR; e++) Q[e] = ldnt(mo, a.L.mo_Q + e);
 #pragma unroll
-        for (int e = 0; e < TR; e++) Q[e] = ldnt(mo, a.L.mo_Q + e);
+    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
 #pragma unroll
-        for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
-        if constexpr (NC > 0) {
+    for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
+    if constexpr (NC > 0) {
 #pragma unroll
-            for (int e = 0; e < NS * NC; e++) G[e] = ldnt(mo, a.L.mo_G + e);
-        }
+        for (int e = 0; e < NS * NC; e++) G[e] = ldnt(mo, a.L.mo_G + e);
     }
+    if constexpr (!PREDICT) {
+#pragma unroll
+        for (int r = 0; r < NM; r++) y0[r] = active ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     unsigned err_acc = 0;
     const int nsteps = FUSED ? a.nsteps : 1;
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
                 T s = T(0);
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    const T g = FUSED ? G[i * NC + c] : ldnt(mo, a.L.mo_G + i * NC + c);
+                    const T g = G[i * NC + c];
                     s += g * u[c];
                 }
                 xm[i] = xm[i] + s;
@@ -115,16 +123,8 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
                 T s = T(0);
 #pragma unroll
                 for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
-                const T q = FUSED ? Q[symi(i, j)] : ldnt(mo, a.L.mo_Q + symi(i, j));
-                Pm[symi(i, j)] = s + q;
+                Pm[symi(i, j)] = s + Q[symi(i, j)];
             }
-        }
-        // ---- measurement model
-        if constexpr (!FUSED) {
-#pragma unroll
-            for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
-#pragma unroll
-            for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
         }
         // ---- yhat = H x_prev (previous posterior, vanilla.go:155-157)
         [[maybe_unused]] T yhat[NM];
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
             // ---- innovation and state update
 #pragma unroll
             for (int r = 0; r < NM; r++) {
-                const T yv = active ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0);
+                const T yv = (t == 0) ? y0[r] : (active ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
                 T s = T(0);
 #pragma unroll
                 for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
