@@ -16,7 +16,7 @@ OK, ERR_INVALID, ERR_DIMS, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_LOCKED, 
 ST_SINGULAR, ST_ASYMMETRIC, ST_NONFINITE, ST_INFO_NOT_INVERTIBLE = 1, 2, 4, 8
 X, P, F, G, H, Q, R = range(7)
 STATE, COVAR, PRED_COVAR, GAIN, INNOVATION, MEASUREMENT, RAW_VEC, RAW_MAT, RAW_PRED_MAT = range(16, 25)
-NOISE_NOISELESS, NOISE_AWGN = 0, 1
+NOISE_NOISELESS, NOISE_AWGN, NOISE_BATCH = 0, 1, 2
 
 _vp, _dp, _i, _i64, _u64 = C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_uint64
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "kb_stream": (_vp, [_vp]),
     "kb_synchronize": (_i, [_vp]),
     "kb_set_noise_kind": (_i, [_vp, _i, _u64]),
+    "kb_set_batch_noise": (_i, [_vp, _dp, _i, _dp, _i]),
     "kb_noise_sample": (_i, [_vp, _i64, _i64, _i64, _i, _dp]),
     "kb_noise_normal": (C.c_double, [_u64, _i64, _i64, _i64, _i, _i]),
     "kb_mc_run": (_i, [_vp, _i, _dp, _i, _i64, _dp]),

@@ -159,6 +159,11 @@ class FilterBatch:
     def set_noise_kind(self, kind, seed=0):
         k.check(k.lib().kb_set_noise_kind(self._h, kind, seed))
 
+    def set_batch_noise(self, process, measurement):
+        """SetNoise(BatchNoise{process, measurement}) (noise.go:67-106); give zero Q, R as BatchNoise reports."""
+        pr, me = _f64(process), _f64(measurement)
+        k.check(k.lib().kb_set_batch_noise(self._h, _ptr(pr), pr.shape[0], _ptr(me), me.shape[0]))
+
     def reset(self):
         k.check(k.lib().kb_reset(self._h))
 

@@ -164,6 +164,7 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p;
     a.ekf = b.ekf; a.snc = b.snc; a.predict = (b.kind == KB_VANILLA_PREDICT);
     a.noise_kind = b.noise_kind; a.seed = b.seed; a.epoch = b.epoch; a.step0 = b.step; a.first_filter = 0;
+    a.bn_proc = b.d_bn_proc; a.bn_meas = b.d_bn_meas; a.bn_p = b.bn_p;
 }
 
 static int launch_step(Batch &b, const StepArgs &a, bool fused) {
@@ -259,7 +260,7 @@ void kb_destroy(kb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_pred, b->d_pred0, b->d_est, b->d_model, b->d_status,
-                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc, b->d_ctrl};
+                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -398,6 +399,15 @@ static int check_update_dims(kb_batch *b, int meas_rows, int ctrl_rows, bool hav
     return KB_OK;
 }
 
+static int check_batch_noise(kb_batch *b, int nsteps) {
+    if (b->noise_kind != KB_NOISE_BATCH) return KB_OK;
+    const int64_t last = b->step + nsteps - 1;
+    if (last >= b->bn_nproc) { set_error("no process noise defined at step k=%lld", (long long)(b->step < b->bn_nproc ? b->bn_nproc : b->step)); return KB_ERR_INVALID; }
+    if (last >= b->bn_nmeas) { set_error("no measurement noise defined at step k=%lld", (long long)(b->step < b->bn_nmeas ? b->bn_nmeas : b->step)); return KB_ERR_INVALID; }
+    if (b->bn_p != b->p) { set_error("dimensions must agree: measurement noise(%dx...) H(%dx...)", b->bn_p, b->p); return KB_ERR_DIMS; }
+    return KB_OK;
+}
+
 static int ready_ldkf(kb_batch *b) {
     if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
     if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
@@ -410,6 +420,7 @@ int kb_update(kb_batch *b, const double *meas, int meas_rows, const double *ctrl
     if (rc) return rc;
     if (!meas) { set_error("measurement is NULL"); return KB_ERR_INVALID; }
     if ((rc = check_update_dims(b, meas_rows, ctrl_rows, ctrl != nullptr))) return rc;
+    if ((rc = check_batch_noise(b, 1))) return rc;
     if ((rc = stage_host_vec(*b, meas, meas_rows, &b->d_y))) return rc;
     if (b->need_ctrl) {
         // the staging buffer is reused: order the two packs on the stream
@@ -433,6 +444,7 @@ static int update_dev_common(kb_batch *b, const void *meas, int64_t ld_meas, con
     if (ld_meas < b->N) { set_error("ld_meas (%lld) < N (%lld)", (long long)ld_meas, (long long)b->N); return KB_ERR_INVALID; }
     if (b->need_ctrl && (!ctrl || ld_ctrl < b->N)) { set_error("control required (needCtrl) with ld_ctrl >= N"); return KB_ERR_DIMS; }
     if (nsteps < 1) { set_error("nsteps must be >= 1"); return KB_ERR_INVALID; }
+    if ((rc = check_batch_noise(b, nsteps))) return rc;
     StepArgs a;
     fill_step_args(*b, a);
     a.nsteps = nsteps;

@@ -134,6 +134,7 @@ int kb_predict_nl(kb_batch *b) {
 // ---- noise (noise.go) -------------------------------------------------------------------
 int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed) {
     if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
+    if (noise_kind == KB_NOISE_BATCH) { set_error("use kb_set_batch_noise to select BatchNoise"); return KB_ERR_INVALID; }
     if (noise_kind != KB_NOISE_NOISELESS && noise_kind != KB_NOISE_AWGN) { set_error("unknown noise kind %d", noise_kind); return KB_ERR_INVALID; }
     int rc = use_device(*b);
     if (rc) return rc;
@@ -145,6 +146,33 @@ int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed) {
         if ((rc = launch_refresh(*b, KB_R, &np2))) return rc;
         if (not_pd + np2) { set_error("process / measurement noise invalid: not positive definite"); return KB_ERR_NOT_PD; }
     }
+    return KB_OK;
+}
+
+// BatchNoise (noise.go:67-106)
+int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const double *measurement, int nmeas) {
+    if (!b || !process || !measurement || nproc < 1 || nmeas < 1) { set_error("bad argument"); return KB_ERR_INVALID; }
+    if (b->kind != KB_VANILLA && b->kind != KB_VANILLA_PREDICT) { set_error("BatchNoise is wired into the Vanilla kinds"); return KB_ERR_UNSUPPORTED; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    const int n = b->n, p = b->p;
+    auto upload = [&](const double *src, size_t cnt, void **dst) -> int {
+        if (*dst) KB_HIP(hipFree(*dst));
+        *dst = nullptr;
+        KB_HIP(hipMalloc(dst, cnt * b->esize()));
+        if (b->dtype == KB_F64) {
+            KB_HIP(hipMemcpy(*dst, src, cnt * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> tmp(cnt);
+            for (size_t i = 0; i < cnt; i++) tmp[i] = (float)src[i];
+            KB_HIP(hipMemcpy(*dst, tmp.data(), cnt * sizeof(float), hipMemcpyHostToDevice));
+        }
+        return KB_OK;
+    };
+    if ((rc = upload(process, (size_t)nproc * n, &b->d_bn_proc))) return rc;
+    if ((rc = upload(measurement, (size_t)nmeas * p, &b->d_bn_meas))) return rc;
+    b->bn_nproc = nproc; b->bn_nmeas = nmeas; b->bn_p = p;
+    b->noise_kind = KB_NOISE_BATCH;
     return KB_OK;
 }
 

@@ -64,6 +64,7 @@ struct Batch {
     int noise_kind = KB_NOISE_NOISELESS;
     uint64_t seed = 0;
     int64_t epoch = 0;
+    void *d_bn_proc = nullptr, *d_bn_meas = nullptr; int bn_nproc = 0, bn_nmeas = 0, bn_p = 0;  // BatchNoise sequences (batch dtype)
     size_t esize() const { return dtype == KB_F64 ? 8 : 4; }
     size_t block_bytes(int elems) const { return (size_t)ntiles * KB_TILE * (size_t)elems * esize(); }
 };
@@ -93,6 +94,7 @@ struct StepArgs {
     int rinv_p, sqrt_p;
     int ekf, snc, predict;
     int noise_kind; uint64_t seed; int64_t epoch; int64_t step0; int64_t first_filter;
+    const void *bn_proc, *bn_meas; int bn_p;     // BatchNoise: [step][n], [step][bn_p]
 };
 
 // kb_pack.hip

@@ -226,12 +226,7 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
     T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
     T A[(NS + NM) * COLS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-#pragma unroll
-        for (int j = 0; j < NS; j++) A[i * COLS + j] = sl(st, NS + i * NS + j);
-        A[i * COLS + NS] = sl(st, i);
-    }
+    // bottom block first (Htilde, L, y die before the 156 state values are loaded: bounds the live set)
     {
         T Lw[tri(NM)], yv[NM];
 #pragma unroll
@@ -265,6 +260,13 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
             A[(NS + r) * COLS + NS] = s;
             if constexpr (FULL) { if (active) ss(es, a.L.es_dobs + r, s); }
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) A[i * COLS + j] = sl(st, NS + i * NS + j);
+        A[i * COLS + NS] = sl(st, i);
     }
     shouseholder<T, NS, NM>(A);
     T chk = T(0);

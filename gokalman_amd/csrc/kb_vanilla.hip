@@ -312,6 +312,8 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const bool strict = (a.flags & KB_FLAG_STRICT_SYMCHECK) != 0;
     const bool awgn = a.noise_kind == KB_NOISE_AWGN;
+    const bool bnoise = a.noise_kind == KB_NOISE_BATCH;  // BatchNoise (noise.go:67-106)
+    const T *bnp = (const T *)a.bn_proc, *bnm = (const T *)a.bn_meas;
 
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * a.L.st_elems) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
@@ -348,6 +350,8 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
                 xm[i] = xm[i] + s;
             }
         }
+        if (bnoise)
+            for (int i = 0; i < n; i++) xm[i] += bnp[(int64_t)stepno * n + i];
         if (awgn) {  // Noise.Process(k): w = L_Q z  (noise.go:133-136)
             T z[LD];
             for (int k = 0; k < n; k++) z[k] = (T)normal_at(a.seed, (uint64_t)(a.first_filter + fi), stepno, (uint32_t)(a.epoch * 4 + 0), k);
@@ -378,6 +382,8 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
             for (int l = 0; l < n; l++) s += H[r * LD + l] * x[l];
             yhat[r] = s;
         }
+        if (bnoise)
+            for (int r = 0; r < p; r++) yhat[r] += bnm[(int64_t)stepno * p + r];
         if (awgn) {
             T z[LD];
             for (int k = 0; k < p; k++) z[k] = (T)normal_at(a.seed, (uint64_t)(a.first_filter + fi), stepno, (uint32_t)(a.epoch * 4 + 1), k);
@@ -425,6 +431,8 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
                 for (int c = 0; c < p; c++) s += K[i * LD + c] * innov[c];
                 xn[i] = xm[i] + s;
             }
+            if (bnoise)
+                for (int i = 0; i < n; i++) xn[i] += bnp[(int64_t)stepno * n + i];
             if (awgn) {  // second Noise.Process(k) (vanilla.go:195)
                 T z[LD];
                 for (int k = 0; k < n; k++) z[k] = (T)normal_at(a.seed, (uint64_t)(a.first_filter + fi), stepno, (uint32_t)(a.epoch * 4 + 2), k);

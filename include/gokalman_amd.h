@@ -198,12 +198,20 @@ int kb_synchronize(kb_batch *b);
 /* ---- noise (noise.go:13-164) -------------------------------------------------- */
 typedef enum {
     KB_NOISE_NOISELESS = 0, /* Noiseless (noise.go:23-64): w = v = 0               */
-    KB_NOISE_AWGN = 1       /* AWGN (noise.go:109-164): w ~ N(0,Q), v ~ N(0,R), device Philox4x32-10 + Box-Muller, x = L z with L = chol */
+    KB_NOISE_AWGN = 1,      /* AWGN (noise.go:109-164): w ~ N(0,Q), v ~ N(0,R), device Philox4x32-10 + Box-Muller, x = L z with L = chol */
+    KB_NOISE_BATCH = 2      /* BatchNoise (noise.go:67-106): pre-recorded vectors, see kb_set_batch_noise */
 } kb_noise_kind;
 /* Selects the Noise implementation; AWGN fails with KB_ERR_NOT_PD when Q or R is
  * not positive definite (the reference panics, noise.go:148-156).  `seed` replaces
  * the reference's wall-clock seed; every kb_reset moves to a fresh sub-stream. */
 int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed);
+/* BatchNoise{process, measurement} (noise.go:67-106): process[nproc][n] and measurement[nmeas][p]
+ * are the recorded vectors (host, row-major), shared by every filter of the batch; step k adds
+ * process[k] at both Process(k) call sites and measurement[k] to yhat.  An Update at a step with no
+ * recorded vector fails with "no process noise defined at step k=%d" (a panic in the reference,
+ * noise.go:75-86).  BatchNoise reports zero Q and R (noise.go:89-98): give kb_set zero matrices.
+ * Selects KB_NOISE_BATCH. */
+int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const double *measurement, int nmeas);
 /* The standard normals z behind the AWGN draw of the filter with global index `filter` at
  * (epoch, step, which); the noise vector is chol_L(Q) z (which 0, 2; n values) or
  * chol_L(R) z (which 1; p values).  For tests that replay the device's samples through the

@@ -137,3 +137,26 @@ def test_vanilla_dimension_errors_match_reference_strings():
     with pytest.raises(ga.KalmanError, match=r"dimensions must agree: control \(u\)\(2x\.\.\.\) G\(\.\.\.x1\)"):
         b.update(np.zeros((4, 2)), np.zeros((4, 2)))
     assert b.step() == 0
+
+
+def test_vanilla_batch_noise_replay():
+    """BatchNoise (noise.go:67-106): recorded process / measurement vectors, zero Q and R matrices."""
+    N, n, p, steps = 70, 4, 2, 6
+    d = synth.linear_batch(N, n, p, steps)
+    rng = np.random.default_rng(9)
+    proc, meas = 1e-2 * rng.standard_normal((steps, n)), 1e-2 * rng.standard_normal((steps, p))
+    Z_Q, Z_R = np.zeros((n, n)), np.zeros((p, p))
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], Z_Q, Z_R, nfilters=N, flags=k.FLAG_FULL_ESTIMATE)
+    b.set_batch_noise(proc, meas)
+    for t in range(steps):
+        est = b.update(d["y"][t])
+    xs, ys = [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], Z_Q, Z_R)
+        for t in range(steps):
+            assert f.update(d["y"][t, i], None, proc[t], meas[t], proc[t]) == orc.OK
+        xs.append(f.state()); ys.append(f.measurement())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-9
+    assert synth.rel_frobenius(est.measurement(), np.array(ys)) <= 1e-9
+    with pytest.raises(ga.KalmanError, match=r"no process noise defined at step k=6"):
+        b.update(d["y"][0])
