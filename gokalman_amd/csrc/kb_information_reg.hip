@@ -8,6 +8,9 @@
 #include "kb_static.h"
 
 namespace kb {
+#ifndef INFO_WAVES
+#define INFO_WAVES 1
+#endif
 
 template <typename T>
 __device__ __forceinline__ T il(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
@@ -17,7 +20,7 @@ template <typename T>
 __device__ __forceinline__ void is(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 template <typename T, int NS, int NM>
-__global__ void __launch_bounds__(256, 2) information_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

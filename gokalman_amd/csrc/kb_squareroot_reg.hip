@@ -12,6 +12,9 @@
 #include "kb_static.h"
 
 namespace kb {
+#ifndef SQRT_WAVES
+#define SQRT_WAVES 1
+#endif
 
 template <typename T>
 __device__ __forceinline__ T ld_s(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
@@ -30,7 +33,7 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 };
 
 template <typename T, int NS, int NM, bool FULL>
-__global__ void __launch_bounds__(256, 2) squareroot_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
