@@ -31,12 +31,17 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+# per-file extra flags: the SLP vectoriser packs fp32 pairs in the fully unrolled SRIF panels and
+# lengthens live ranges (more AGPR / scratch spills); it buys nothing there
+EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
             and os.path.getmtime(obj) > _deps_mtime()):
         return obj
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))
