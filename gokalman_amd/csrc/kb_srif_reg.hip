@@ -209,6 +209,134 @@ __global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
     }
 }
 
+// ---- time update, LDS-resident LU (n = 12 fp32) ------------------------------------------------
+// The 12 x 12 pivoted LU of Phi does not fit the register file once unrolled (see the header of
+// this file), so this variant keeps Phi / its LU factors in LDS, one private 144-element array per
+// lane laid out [element][lane]: lane l always hits bank l, whatever element it indexes, so
+// per-lane *dynamic* row indices are conflict-free and partial pivoting becomes a per-lane row
+// permutation (12 nibbles in a 64-bit register) instead of data movement.  One workgroup of
+// 4 waves per CU (4 x 39 KB of LDS).
+template <typename T, int NS>
+struct LdsLU {
+    T *base;  // this lane's element 0; element e at base[e * 64]
+    __device__ __forceinline__ T get(int row, int col) const { return base[(row * NS + col) * KB_TILE]; }
+    __device__ __forceinline__ void put(int row, int col, T v) const { base[(row * NS + col) * KB_TILE] = v; }
+};
+__device__ __forceinline__ int nib(uint64_t perm, int r) { return (int)((perm >> (4 * r)) & 15u); }
+
+template <typename T, int NS, bool FULL, bool EXT>
+__global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a) {
+    __shared__ T lds[4 * (NS * NS + NS) * KB_TILE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
+    const LdsLU<T, NS> lu{lds + wv * (NS * NS + NS) * KB_TILE + lane};
+    T *ltmp = lds + wv * (NS * NS + NS) * KB_TILE + NS * NS * KB_TILE + lane;  // NS spare elements per lane
+    unsigned err = 0;
+    T xprev[NS];
+    {   // State(prev) = R^-1 b (srif.go:223-234), register LU solve
+        T Rw[NS * NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) xprev[i] = sl(st, i);
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) Rw[e] = sl(st, NS + e);
+        if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // Phi -> LDS; xBar = Phi State(prev) (srif.go:118) -> spare slots
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                const T v = EXT ? __builtin_nontemporal_load(ephi + (int64_t)(i * NS + j) * a.ext_ld) : snt(mo, a.L.mo_F + i * NS + j);
+                lu.put(i, j, v);
+                s += v * xprev[j];
+            }
+            ltmp[i * KB_TILE] = s;
+        }
+    }
+    // LU with partial pivoting (srif.go:111-114's Inverse = Dgetrf + ...): logical row r lives in
+    // physical row nib(perm, r)
+    uint64_t perm = 0xBA9876543210ull;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        T best = T(-1);
+        int p = j;
+#pragma unroll 1
+        for (int r = j; r < NS; r++) {
+            const T v = fabs(lu.get(nib(perm, r), j));
+            if (v > best) { best = v; p = r; }
+        }
+        const uint64_t vj = (perm >> (4 * j)) & 15u, vp = (perm >> (4 * p)) & 15u, x = vj ^ vp;
+        perm ^= (x << (4 * j)) | (x << (4 * p));
+        const int pj = nib(perm, j);
+        T prow[NS];
+#pragma unroll
+        for (int c = j; c < NS; c++) prow[c] = lu.get(pj, c);
+        if (prow[j] == T(0)) err |= KB_ST_SINGULAR;
+        const T rp = T(1) / prow[j];
+#pragma unroll 1
+        for (int r = j + 1; r < NS; r++) {
+            const int pr = nib(perm, r);
+            const T l = lu.get(pr, j) * rp;
+            lu.put(pr, j, l);
+#pragma unroll
+            for (int c = j + 1; c < NS; c++) lu.put(pr, c, lu.get(pr, c) - l * prow[c]);
+        }
+    }
+    if (err) { if (active) atomicOr(a.status + fi, err); return; }
+    T xBarP[NS];  // xBar in pivoted order: xBarP[r] = xBar[perm_r]
+#pragma unroll
+    for (int r = 0; r < NS; r++) xBarP[r] = ltmp[nib(perm, r) * KB_TILE];
+    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
+    T bBar[NS];
+#pragma unroll 1
+    for (int i = 0; i < NS; i++) {
+        T z[NS];
+#pragma unroll
+        for (int l = 0; l < NS; l++) z[l] = sl(st, NS + i * NS + l);  // row i of R again: cache hit
+        // z Phi = r  with  P Phi = L U:  w U = r,  v L = w,  z[perm_r] = v_r   (srif.go:115)
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int pj = nib(perm, j);
+            T s = z[j];
+#pragma unroll
+            for (int k2 = 0; k2 < j; k2++) s -= z[k2] * lu.get(nib(perm, k2), j);
+            z[j] = s / lu.get(pj, j);
+        }
+#pragma unroll
+        for (int j = NS - 1; j >= 0; j--) {
+            T s = z[j];
+#pragma unroll
+            for (int k2 = j + 1; k2 < NS; k2++) s -= z[k2] * lu.get(nib(perm, k2), j);
+            z[j] = s;
+        }
+        T bb = T(0);
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            bb += z[r] * xBarP[r];                 // :119 bBar = RBar xBar (same products, pivoted order)
+            ltmp[nib(perm, r) * KB_TILE] = z[r];   // un-permute through the spare slots
+        }
+        bBar[0] = bb;  // placeholder, real store below (keeps bBar out of a dynamically indexed array)
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < NS; c++) {
+                const T v = ltmp[c * KB_TILE];
+                ss(st, NS + i * NS + c, v);
+                if constexpr (FULL) ss(es, a.L.es_ppred + i * NS + c, v);
+            }
+            ss(st, i, bb);  // b <- bBar, row by row: row i of R and b_i are not read again
+        }
+    }
+    (void)bBar;
+}
+
 // ---- measurement update (srif.go:143-156, :298-340): Householder on [[RBar bBar],[L Htilde, L y]] --
 template <typename T, int NS, int NM, bool FULL, bool EXT>
 __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
@@ -297,7 +425,8 @@ static bool srif_try(const Batch &b, const StepArgs &a) {
     if (!srif_shape_ok(a, NS, NM)) return false;
     const dim3 grid = tile_grid(a.ntiles), block(256);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
-#define KB_T(F_, E_) hipLaunchKernelGGL((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a)
+#define KB_T(F_, E_) do { if constexpr (NS == 12 && sizeof(T) == 4) hipLaunchKernelGGL((srif_time_lds_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a); \
+                            else hipLaunchKernelGGL((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a); } while (0)
 #define KB_M(F_, E_) hipLaunchKernelGGL((srif_meas_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
     if (full) { if (ext) KB_T(true, true); else KB_T(true, false); }
     else      { if (ext) KB_T(false, true); else KB_T(false, false); }

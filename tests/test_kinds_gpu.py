@@ -251,8 +251,8 @@ def test_awgn_moments_and_vanilla_awgn_replay():
                                 noise=k.NOISE_AWGN)
 
 
-@pytest.mark.parametrize("kind,n,p", [(k.HYBRID, 6, 2), (k.SRIF, 12, 6), (k.SRIF, 6, 2)])
-def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p):
+@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32)])
+def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
     import torch
     rng = np.random.default_rng(21)
@@ -263,19 +263,21 @@ def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p):
     Phi, Ht, real, comp = _nl_models(N, n, p, steps, rng)
 
     def make():
-        b = ga.FilterBatch(kind, n, p, 0, N)
+        b = ga.FilterBatch(kind, n, p, 0, N, dtype=dtype)
         b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
         return b
 
+    tdt = torch.float32 if dtype == k.F32 else torch.float64
     host, dev = make(), make()
     for t in range(steps):
         host.prepare(Phi[t], Ht[t]); host.update_nl(real[t], comp[t])
-        dphi = torch.from_numpy(np.ascontiguousarray(Phi[t].reshape(N, n * n).T)).cuda()
-        dh = torch.from_numpy(np.ascontiguousarray(Ht[t].reshape(N, p * n).T)).cuda()
-        dr = torch.from_numpy(np.ascontiguousarray(real[t].T)).cuda(); dc = torch.from_numpy(np.ascontiguousarray(comp[t].T)).cuda()
+        dphi = torch.from_numpy(np.ascontiguousarray(Phi[t].reshape(N, n * n).T)).to(tdt).cuda()
+        dh = torch.from_numpy(np.ascontiguousarray(Ht[t].reshape(N, p * n).T)).to(tdt).cuda()
+        dr = torch.from_numpy(np.ascontiguousarray(real[t].T)).to(tdt).cuda(); dc = torch.from_numpy(np.ascontiguousarray(comp[t].T)).to(tdt).cuda()
         k.check(k.lib().kb_prepare_dev(dev._h, dphi.data_ptr(), dh.data_ptr(), N))
         k.check(k.lib().kb_update_nl_dev(dev._h, dr.data_ptr(), dc.data_ptr(), N))
         dev.synchronize()
-    assert synth.rel_frobenius(dev.get(k.RAW_VEC), host.get(k.RAW_VEC)) <= 1e-13
-    assert synth.rel_frobenius(dev.get(k.RAW_MAT), host.get(k.RAW_MAT)) <= 1e-13
+    tol = 1e-13 if dtype == k.F64 else 1e-6
+    assert synth.rel_frobenius(dev.get(k.RAW_VEC), host.get(k.RAW_VEC)) <= tol
+    assert synth.rel_frobenius(dev.get(k.RAW_MAT), host.get(k.RAW_MAT)) <= tol
     assert dev.step() == steps and not dev.status().any()
