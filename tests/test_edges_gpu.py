@@ -1,0 +1,130 @@
+"""Edge cases through the C ABI: maximum dimensions, fp32 batches, partial reads, reset / re-run
+determinism, setter side effects (reference behaviours cited per test)."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from gokalman_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maximum_dimensions_16x8_generic_kernel():
+    N, n, p, steps = 33, 16, 8, 3
+    d = synth.linear_batch(N, n, p, steps)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    for t in range(steps):
+        est = b.update(d["y"][t])
+    xs, Ps = [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i])
+        for t in range(steps):
+            assert f.update(d["y"][t, i]) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-9
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= 1e-9
+    with pytest.raises(ga.KalmanError):
+        ga.FilterBatch(k.VANILLA, 17, 3, 0, 4)
+
+
+@pytest.mark.parametrize("kind,okind", [(k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)])
+def test_fp32_batches_track_the_fp64_oracle(kind, okind):
+    """fp32 storage + arithmetic (the SRIF config's dtype) on the LDKF kinds: fp32-appropriate tolerance."""
+    N, steps = 256, 10
+    d = synth.linear_batch(N, 6, 3, steps)
+    b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], dtype=k.F32)
+    for t in range(steps):
+        b.update(d["y"][t])
+    xo, Po, nerr = orc.ldkf_batch(okind, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+    assert nerr == 0
+    assert synth.rel_frobenius(b.get(k.STATE), xo) <= 5e-3
+    assert synth.rel_frobenius(b.get(k.COVAR), Po) <= 5e-3
+
+
+def test_partial_reads_and_reset_rerun_is_bitwise_repeatable():
+    N, steps = 1000, 5
+    d = synth.linear_batch(N, 6, 3, steps)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    for t in range(steps):
+        b.update(d["y"][t])
+    full = b.get(k.COVAR)
+    assert np.array_equal(b.get(k.COVAR, 137, 64), full[137:201])
+    assert np.array_equal(b.get(k.STATE, 999, 1), b.get(k.STATE)[999:])
+    x1 = b.get(k.STATE)
+    b.reset()                                    # vanilla.go:121-125
+    assert b.step() == 0 and np.array_equal(b.get(k.STATE), d["x0"])
+    for t in range(steps):
+        b.update(d["y"][t])
+    assert np.array_equal(b.get(k.STATE), x1) and np.array_equal(b.get(k.COVAR), full)
+    with pytest.raises(ga.KalmanError):
+        b.get(k.STATE, 990, 20)
+    with pytest.raises(ga.KalmanError, match="FULL_ESTIMATE"):
+        b.get(k.GAIN)
+
+
+def test_set_state_transition_and_noise_between_steps():
+    """Set* between steps (kalman.go:41-44); Information refreshes F^-1 but not Q^-1/R^-1
+    (information.go:117-138), SquareRoot recomputes chol(Q), chol(R) (squareroot.go:100-114)."""
+    N, n, p = 40, 4, 2
+    d = synth.linear_batch(N, n, p, 4)
+    d2 = synth.linear_batch(N, n, p, 1, seed=99)
+    for kind, okind, tol in ((k.VANILLA, orc.VANILLA, 1e-9), (k.SQUAREROOT, orc.SQUAREROOT, 1e-9), (k.INFORMATION, orc.INFORMATION, 1e-6)):
+        flags = k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=flags)
+        fs = []
+        for i in range(N):
+            if okind == orc.INFORMATION:
+                fs.append(orc.Filter.information_from_state(d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]))
+            else:
+                fs.append(orc.Filter.ldkf(okind, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]))
+        for t in range(4):
+            if t == 2:
+                b.set_state_transition(d2["F"]); b.set_noise(d2["Q"], d2["R"])
+                for i, f in enumerate(fs):
+                    f.set_state_transition(d2["F"][i]); f.set_noise(d2["Q"][i], d2["R"][i])
+            b.update(d["y"][t])
+            for i, f in enumerate(fs):
+                assert f.update(d["y"][t, i]) == orc.OK
+        assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= tol, kind
+        assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= tol, kind
+
+
+def test_is_within_nsigma_matches_oracle():
+    N, steps = 300, 4
+    d = synth.linear_batch(N, 6, 3, steps)
+    for kind, okind in ((k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)):
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        fs = [orc.Filter.ldkf(okind, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]) for i in range(N)]
+        for t in range(steps):
+            est = b.update(d["y"][t])
+            for i, f in enumerate(fs):
+                f.update(d["y"][t, i])
+        mixed = False
+        for ns in (2.0, 20.0, 100.0, 1000.0):
+            got = est.is_within_nsigma(ns)
+            exp = np.array([f.is_within_nsigma(ns) for f in fs])
+            assert np.mean(got == exp) >= 0.995   # ties at the boundary may flip with rounding
+            mixed = mixed or (0 < got.sum() < N)
+        assert mixed
+
+
+def test_predict_only_vanilla_matches_oracle():
+    """NewPurePredictorVanilla (vanilla.go:43-62, :170-179): estimate = {x-, yhat, 0, P-, P-, K}."""
+    N, steps = 128, 6
+    d = synth.linear_batch(N, 6, 3, steps)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    for t in range(steps):
+        est = b.update(np.zeros((N, 3)))
+    xs, Ps, Ks = [], [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.VANILLA_PREDICT, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i])
+        for t in range(steps):
+            assert f.update(np.zeros(3)) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); Ks.append(f.gain())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-9
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= 1e-9
+    assert synth.rel_frobenius(est.pred_covariance(), np.array(Ps)) <= 1e-9
+    assert synth.rel_frobenius(est.gain(), np.array(Ks)) <= 1e-9
+    assert np.all(est.innovation() == 0)
