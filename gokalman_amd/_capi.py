@@ -58,6 +58,7 @@ SIGNATURES = {
     "kb_noise_sample": (_i, [_vp, _i64, _i64, _i64, _i, _dp]),
     "kb_noise_normal": (C.c_double, [_u64, _i64, _i64, _i64, _i, _i]),
     "kb_mc_run": (_i, [_vp, _i, _dp, _i, _i64, _dp]),
+    "kb_chisquare": (_i, [_vp, _vp, _i, _dp, _i, _i64, _i, _i, _i, _dp]),
     "kb_mc_stats": (_i, [_dp, _i, _i, _i64, _dp, _dp]),
 }
 

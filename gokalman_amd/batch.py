@@ -318,3 +318,24 @@ def new_monte_carlo_runs(samples, steps, rows_h, controls, kf, first_run=0, redu
     if reduce is not None:  # add the shards' partial sums (rows 0, 1); row 2 (the shift) is identical everywhere
         sums[:, :2, :] = reduce(np.ascontiguousarray(sums[:, :2, :]))
     return MonteCarloRuns(samples, steps, kf.n, sums)
+
+
+def new_chi_square(kf, truth, steps, controls, with_nees=True, with_nis=True, first_run=0, replay_last_mc=True,
+                   total_runs=None, reduce=None):
+    """NewChiSquare(kf, runs, controls, withNEES, withNIS) (chisquare.go:16-95): returns (NISmeans, NEESmeans).
+
+    `truth` is the pure-predictor AWGN batch that generated (or generates) the Monte-Carlo runs, `kf`
+    the Vanilla batch under test.  `reduce` adds the per-shard sums across ranks; `total_runs` is then
+    the global number of runs."""
+    if not with_nees and not with_nis:
+        raise k.KalmanError(k.ERR_INVALID, "Chi Square requires either NEES or NIS or both")
+    controls = _f64(controls)
+    if controls.ndim == 1:
+        controls = controls.reshape(1, -1)
+    sums = np.zeros((steps, 2), dtype=np.float64)
+    k.check(k.lib().kb_chisquare(truth._h, kf._h, steps, _ptr(controls), controls.shape[0], first_run,
+                                 1 if replay_last_mc else 0, int(with_nees), int(with_nis), _ptr(sums)))
+    if reduce is not None:
+        sums = reduce(sums)
+    runs = float(total_runs if total_runs is not None else truth.N)
+    return sums[:, 0] / runs, sums[:, 1] / runs

@@ -1,0 +1,385 @@
+// kb_chisq.hip -- NEES / NIS consistency statistics (chisquare.go:16-95) fused with the
+// Monte-Carlo truth generation (montecarlo.go:92-119).
+//
+// Reference flow: NewMonteCarloRuns produces `runs` truth trajectories with a pure-predictor
+// Vanilla + AWGN (state x_k and measurement yhat_k = H x_{k-1} + v_k per step); NewChiSquare then
+// Reset()s a full filter per run, replays `kf.Update(truth.Measurement(), u_k)` and accumulates
+//   NEES_k = (x_k - xhat_k)^T P_k^-1 (x_k - xhat_k)          (chisquare.go:46-59)
+//   NIS_k  = innov^T (H P-_k H^T + R)^-1 innov               (chisquare.go:61-77)
+// averaged over runs per step.  Here one lane = one run: the truth and the filter advance
+// together in registers, all steps inside one launch; per step the wave reduces both statistics
+// (__shfl_xor) and adds them to one of 32 replicas with fp64 atomics.  The truth's noise comes
+// from the same Philox stream as kb_mc_run (seed; global run index, step, epoch, draw), so the
+// statistics refer to the same runs as the Monte-Carlo means when the same epoch is replayed.
+#include <cstring>
+#include <vector>
+
+#include "kb_internal.h"
+#include "kb_static.h"
+
+namespace kb {
+
+constexpr int CHI_REPL = 32;
+
+template <typename T>
+__device__ __forceinline__ T ldc(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+
+__device__ __forceinline__ double chi_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct ChiArgs {
+    const void *t_state, *t_model;  // truth batch (pure predictor, AWGN factors in its model block)
+    const void *k_state, *k_model;  // filter batch (initial estimate + model)
+    Layout tL, kL;
+    int64_t N, ntiles, first_run, epoch;
+    uint64_t seed;
+    int nsteps, ncontrols, need_ctrl, with_nees, with_nis;
+    const void *controls;
+    double *sums;  // [CHI_REPL][steps][2]
+};
+
+template <typename T, int NS, int NM, int NC>
+__global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
+    constexpr int TR = tri(NS), TM = tri(NM);
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    const T *ts = (const T *)a.t_state + tile * ((int64_t)KB_TILE * a.tL.st_elems) + lane;
+    const T *tm = (const T *)a.t_model + tile * ((int64_t)KB_TILE * a.tL.mo_elems) + lane;
+    const T *ks = (const T *)a.k_state + tile * ((int64_t)KB_TILE * a.kL.st_elems) + lane;
+    const T *km = (const T *)a.k_model + tile * ((int64_t)KB_TILE * a.kL.mo_elems) + lane;
+    // truth model
+    T xt[NS], Ft[NS * NS], Ht[NM * NS], LQ[TR], LR[TM];
+    [[maybe_unused]] T Gt[NC > 0 ? NS * NC : 1], Gk[NC > 0 ? NS * NC : 1];
+#pragma unroll
+    for (int i = 0; i < NS; i++) xt[i] = ldc(ts, a.tL.st_vec + i);
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) Ft[e] = ldc(tm, a.tL.mo_F + e);
+#pragma unroll
+    for (int e = 0; e < NM * NS; e++) Ht[e] = ldc(tm, a.tL.mo_H + e);
+#pragma unroll
+    for (int e = 0; e < TR; e++) LQ[e] = ldc(tm, a.tL.mo_LQ + e);
+#pragma unroll
+    for (int e = 0; e < TM; e++) LR[e] = ldc(tm, a.tL.mo_LR + e);
+    // filter
+    T x[NS], P[TR], F[NS * NS], H[NM * NS], Q[TR], R[TM];
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = ldc(ks, a.kL.st_vec + i);
+#pragma unroll
+    for (int e = 0; e < TR; e++) P[e] = ldc(ks, a.kL.st_mat + e);
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) F[e] = ldc(km, a.kL.mo_F + e);
+#pragma unroll
+    for (int e = 0; e < NM * NS; e++) H[e] = ldc(km, a.kL.mo_H + e);
+#pragma unroll
+    for (int e = 0; e < TR; e++) Q[e] = ldc(km, a.kL.mo_Q + e);
+#pragma unroll
+    for (int e = 0; e < TM; e++) R[e] = ldc(km, a.kL.mo_R + e);
+    if constexpr (NC > 0) {
+#pragma unroll
+        for (int e = 0; e < NS * NC; e++) { Gt[e] = ldc(tm, a.tL.mo_G + e); Gk[e] = ldc(km, a.kL.mo_G + e); }
+    }
+    const uint64_t gfi = (uint64_t)(a.first_run + fi);
+    double *my = a.sums + (size_t)(tile % CHI_REPL) * a.nsteps * 2;
+    for (int t = 0; t < a.nsteps; t++) {
+        [[maybe_unused]] T u[NC > 0 ? NC : 1];
+        if constexpr (NC > 0) {
+            const T *up = (const T *)a.controls + (a.ncontrols == 1 ? 0 : (int64_t)t * NC);
+#pragma unroll
+            for (int c = 0; c < NC; c++) u[c] = a.ncontrols == 1 ? T(0) : up[c];
+        }
+        // ---- truth: yhat_k = H x_{k-1} + v_k ; x_k = F x_{k-1} [+ G u_k] + w_k  (vanilla.go:138-157, predictionOnly)
+        T zq[NS], zr[NM];
+#pragma unroll
+        for (int k2 = 0; k2 < NS; k2 += 2) {
+            uint32_t r[4];
+            Philox::gen(a.seed, gfi, (uint32_t)t, ((uint32_t)(a.epoch * 4 + 0) << 8) | (uint32_t)(k2 >> 1), r);
+            double z0, z1;
+            box_muller(r, z0, z1);
+            zq[k2] = (T)z0;
+            if (k2 + 1 < NS) zq[k2 + 1] = (T)z1;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < NM; k2 += 2) {
+            uint32_t r[4];
+            Philox::gen(a.seed, gfi, (uint32_t)t, ((uint32_t)(a.epoch * 4 + 1) << 8) | (uint32_t)(k2 >> 1), r);
+            double z0, z1;
+            box_muller(r, z0, z1);
+            zr[k2] = (T)z0;
+            if (k2 + 1 < NM) zr[k2 + 1] = (T)z1;
+        }
+        T y[NM], xtn[NS];
+#pragma unroll
+        for (int r2 = 0; r2 < NM; r2++) {
+            T s = T(0), v = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += Ht[r2 * NS + l] * xt[l];
+#pragma unroll
+            for (int k2 = 0; k2 <= r2; k2++) v += LR[symi(k2, r2)] * zr[k2];
+            y[r2] = s + v;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0), w = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += Ft[i * NS + l] * xt[l];
+            if constexpr (NC > 0) {
+                T g = T(0);
+#pragma unroll
+                for (int c = 0; c < NC; c++) g += Gt[i * NC + c] * u[c];
+                s = s + g;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 <= i; k2++) w += LQ[symi(k2, i)] * zq[k2];
+            xtn[i] = s + w;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) xt[i] = xtn[i];
+        // ---- filter: Vanilla.Update(y, u), Noiseless (vanilla.go:128-220)
+        T xm[NS], Pm[TR];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += F[i * NS + l] * x[l];
+            if constexpr (NC > 0) {
+                T g = T(0);
+#pragma unroll
+                for (int c = 0; c < NC; c++) g += Gk[i * NC + c] * u[c];
+                s = s + g;
+            }
+            xm[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T fp[NS];
+#pragma unroll
+            for (int k2 = 0; k2 < NS; k2++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += F[i * NS + l] * P[symi(l, k2)];
+                fp[k2] = s;
+            }
+#pragma unroll
+            for (int j = i; j < NS; j++) {
+                T s = T(0);
+#pragma unroll
+                for (int k2 = 0; k2 < NS; k2++) s += fp[k2] * F[j * NS + k2];
+                Pm[symi(i, j)] = s + Q[symi(i, j)];
+            }
+        }
+        T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += Pm[symi(i, l)] * H[c * NS + l];
+                PHt[i * NM + c] = s;
+            }
+#pragma unroll
+        for (int r2 = 0; r2 < NM; r2++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int i = 0; i < NS; i++) s += H[r2 * NS + i] * PHt[i * NM + c];
+                S[r2 * NM + c] = s + R[symi(r2, c)];
+            }
+        inverse_lu<T, NM>(S, Si);
+        smm_nn<T, NS, NM, NM>(PHt, Si, K);
+        T innov[NM];
+#pragma unroll
+        for (int r2 = 0; r2 < NM; r2++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += H[r2 * NS + l] * xm[l];
+            innov[r2] = y[r2] - s;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
+            x[i] = xm[i] + s;
+        }
+        T A[NS * NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                T s = T(0);
+#pragma unroll
+                for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
+                A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
+            }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T ap[NS], kr[NM];
+#pragma unroll
+            for (int k2 = 0; k2 < NS; k2++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k2)];
+                ap[k2] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int k2 = 0; k2 < NM; k2++) s += K[i * NM + k2] * R[symi(k2, c)];
+                kr[c] = s;
+            }
+#pragma unroll
+            for (int j = i; j < NS; j++) {
+                T s = T(0), s2 = T(0);
+#pragma unroll
+                for (int k2 = 0; k2 < NS; k2++) s += ap[k2] * A[j * NS + k2];
+#pragma unroll
+                for (int c = 0; c < NM; c++) s2 += kr[c] * K[j * NM + c];
+                P[symi(i, j)] = s + s2;
+            }
+        }
+        // ---- statistics (chisquare.go:46-77)
+        double nis = 0.0, nees = 0.0;
+        if (a.with_nis) {
+            T s = T(0);
+#pragma unroll
+            for (int r2 = 0; r2 < NM; r2++) {
+                T v = T(0);
+#pragma unroll
+                for (int c = 0; c < NM; c++) v += Si[r2 * NM + c] * innov[c];
+                s += innov[r2] * v;
+            }
+            nis = (double)s;
+        }
+        if (a.with_nees) {
+            T Pf[NS * NS], Pi[NS * NS], dlt[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                dlt[i] = xt[i] - x[i];
+#pragma unroll
+                for (int j = 0; j < NS; j++) Pf[i * NS + j] = P[symi(i, j)];
+            }
+            inverse_lu<T, NS>(Pf, Pi);
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T v = T(0);
+#pragma unroll
+                for (int j = 0; j < NS; j++) v += Pi[i * NS + j] * dlt[j];
+                s += dlt[i] * v;
+            }
+            nees = (double)s;
+        }
+        const double s1 = chi_wave_sum(active ? nis : 0.0), s2 = chi_wave_sum(active ? nees : 0.0);
+        if (lane == 0) {
+            atomicAdd(my + (size_t)t * 2 + 0, s1);
+            atomicAdd(my + (size_t)t * 2 + 1, s2);
+        }
+    }
+}
+
+template <typename T, int NS, int NM>
+static bool chi_try(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
+    if (n != NS || p != NM) return false;
+    const dim3 grid = tile_grid(a.ntiles), block(256);
+    switch (nc) {
+    case 0: hipLaunchKernelGGL((chisq_kernel<T, NS, NM, 0>), grid, block, 0, tb.stream, a); return true;
+    case 1: hipLaunchKernelGGL((chisq_kernel<T, NS, NM, 1>), grid, block, 0, tb.stream, a); return true;
+    case 2: hipLaunchKernelGGL((chisq_kernel<T, NS, NM, 2>), grid, block, 0, tb.stream, a); return true;
+    }
+    return false;
+}
+
+int chi_repl() { return CHI_REPL; }
+
+int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
+    bool ok = false;
+    if (tb.dtype == KB_F64)
+        ok = chi_try<double, 2, 1>(tb, a, n, p, nc) || chi_try<double, 3, 1>(tb, a, n, p, nc) || chi_try<double, 4, 2>(tb, a, n, p, nc) ||
+             chi_try<double, 6, 3>(tb, a, n, p, nc);
+    if (!ok) {
+        set_error("kb_chisquare: no kernel for n=%d p=%d m=%d (built, fp64: (2,1) (3,1) (4,2) (6,3), m <= 2)", n, p, nc);
+        return KB_ERR_UNSUPPORTED;
+    }
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+}  // namespace kb
+
+using namespace kb;
+
+extern "C" int kb_chisquare(kb_batch *truth, kb_batch *kf, int steps, const double *controls, int ncontrols, int64_t first_run,
+                            int replay_last_mc, int with_nees, int with_nis, double *sums) {
+    if (!truth || !kf || !sums) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (!with_nees && !with_nis) { set_error("Chi Square requires either NEES or NIS or both"); return KB_ERR_INVALID; }  // chisquare.go:17-19
+    if (!truth->initialized || !kf->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
+    if (truth->kind != KB_VANILLA_PREDICT || truth->noise_kind != KB_NOISE_AWGN) {
+        set_error("the Monte-Carlo truth must be a pure-predictor Vanilla batch with AWGN noise");
+        return KB_ERR_INVALID;
+    }
+    if (kf->kind != KB_VANILLA) { set_error("the tested filter must be a Vanilla batch"); return KB_ERR_UNSUPPORTED; }
+    if (truth->N != kf->N || truth->n != kf->n || truth->p != kf->p || truth->m != kf->m || truth->dtype != kf->dtype || truth->device != kf->device) {
+        set_error("truth and filter batches must agree in size, shape, dtype and device");
+        return KB_ERR_DIMS;
+    }
+    if (steps < 1) { set_error("steps must be >= 1"); return KB_ERR_INVALID; }
+    if (ncontrols != 1 && ncontrols != steps) {  // chisquare.go:27-36
+        set_error("must provide as much control vectors as steps, or just one control vector");
+        return KB_ERR_INVALID;
+    }
+    if (truth->need_ctrl != kf->need_ctrl) { set_error("truth and filter disagree on needCtrl"); return KB_ERR_DIMS; }
+    int rc = use_device(*truth);
+    if (rc) return rc;
+    const int m = truth->m;
+    if (truth->need_ctrl) {
+        if (!controls) { set_error("controls required (needCtrl)"); return KB_ERR_INVALID; }
+        const size_t cnt = (size_t)ncontrols * m, bytes = cnt * truth->esize();
+        if (truth->ctrl_bytes < bytes) {
+            if (truth->d_ctrl) KB_HIP(hipFree(truth->d_ctrl));
+            truth->d_ctrl = nullptr; truth->ctrl_bytes = 0;
+            KB_HIP(hipMalloc(&truth->d_ctrl, bytes));
+            truth->ctrl_bytes = bytes;
+        }
+        KB_HIP(hipMemcpy(truth->d_ctrl, controls, bytes, hipMemcpyHostToDevice));  // fp64 only (see launch_chisq)
+    }
+    const int repl = chi_repl();
+    const size_t ndbl = (size_t)repl * steps * 2;
+    if (truth->mc_bytes < ndbl * sizeof(double)) {
+        if (truth->d_mc) KB_HIP(hipFree(truth->d_mc));
+        truth->d_mc = nullptr; truth->mc_bytes = 0;
+        KB_HIP(hipMalloc((void **)&truth->d_mc, ndbl * sizeof(double)));
+        truth->mc_bytes = ndbl * sizeof(double);
+    }
+    KB_HIP(hipStreamSynchronize(kf->stream));
+    KB_HIP(hipMemsetAsync(truth->d_mc, 0, ndbl * sizeof(double), truth->stream));
+    ChiArgs a;
+    memset(&a, 0, sizeof(a));
+    a.t_state = truth->d_state0; a.t_model = truth->d_model; a.k_state = kf->d_state0; a.k_model = kf->d_model;  // kf.Reset() per run (chisquare.go:39)
+    a.tL = truth->L; a.kL = kf->L;
+    a.N = truth->N; a.ntiles = truth->ntiles; a.first_run = first_run;
+    a.epoch = (replay_last_mc && truth->epoch > 0) ? truth->epoch - 1 : truth->epoch;
+    a.seed = truth->seed;
+    a.nsteps = steps; a.ncontrols = ncontrols; a.need_ctrl = truth->need_ctrl; a.with_nees = with_nees; a.with_nis = with_nis;
+    a.controls = truth->d_ctrl; a.sums = truth->d_mc;
+    if ((rc = launch_chisq(*truth, a, truth->n, truth->p, truth->need_ctrl ? m : 0))) return rc;
+    std::vector<double> host(ndbl);
+    KB_HIP(hipMemcpyAsync(host.data(), truth->d_mc, ndbl * sizeof(double), hipMemcpyDeviceToHost, truth->stream));
+    KB_HIP(hipStreamSynchronize(truth->stream));
+    for (int t = 0; t < steps; t++) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < repl; r++) { s1 += host[((size_t)r * steps + t) * 2 + 0]; s2 += host[((size_t)r * steps + t) * 2 + 1]; }
+        sums[(size_t)t * 2 + 0] = s1;
+        sums[(size_t)t * 2 + 1] = s2;
+    }
+    if (!replay_last_mc) truth->epoch++;
+    return KB_OK;
+}

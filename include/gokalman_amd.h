@@ -239,6 +239,20 @@ int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols,
  * `runs` runs: mean[steps][n], stddev[steps][n] (unbiased, n-1, as gonum stat.StdDev). */
 int kb_mc_stats(const double *sums, int steps, int n, int64_t runs, double *mean, double *stddev);
 
+/* ---- chi-square consistency tests (chisquare.go:16-95) ------------------------------------- */
+/* NewChiSquare(kf, runs, controls, withNEES, withNIS) fused with the truth generation of
+ * NewMonteCarloRuns: `truth` is the pure-predictor Vanilla batch with AWGN noise (one run per
+ * filter), `kf` a Vanilla batch of the same size and shape holding the filter under test (it is
+ * Reset() for every run, chisquare.go:39, i.e. started from its initial estimate; neither batch's
+ * current estimate is modified).  Per step and run: the truth advances, the filter is updated with
+ * the truth's measurement, NEES = (x - xhat)^T P^-1 (x - xhat) and NIS = innov^T (H P- H^T + R)^-1
+ * innov.  sums[steps][2] (host) receives { sum NIS, sum NEES } over this batch's runs; the step
+ * means are sums / total runs (after adding the shards of a multi-GPU job).
+ * replay_last_mc != 0 re-uses the noise epoch of the last kb_mc_run on `truth`, so the statistics
+ * refer to the same runs as its means; 0 draws fresh runs.  controls as in kb_mc_run. */
+int kb_chisquare(kb_batch *truth, kb_batch *kf, int steps, const double *controls, int ncontrols,
+                 int64_t first_run, int replay_last_mc, int with_nees, int with_nis, double *sums);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,4 +307,19 @@ inline MonteCarloRuns NewMonteCarloRuns(int64_t samples, int steps, int rowsH, c
     return r;
 }
 
+// NewChiSquare(kf, runs, controls, withNEES, withNIS) (NISmeans, NEESmeans, error)   chisquare.go:16-95
+// `truth` is the pure-predictor AWGN filter that generated the Monte-Carlo runs, `kf` the filter under test.
+inline std::pair<std::vector<double>, std::vector<double>> NewChiSquare(Vanilla &kf, Vanilla &truth, int steps, const std::vector<Vector> &controls,
+                                                                        bool withNEES, bool withNIS) {
+    if (!withNEES && !withNIS) throw Error(KB_ERR_INVALID, "Chi Square requires either NEES or NIS or both");
+    std::vector<double> ctrl;
+    for (const auto &c : controls) ctrl.insert(ctrl.end(), c.data.begin(), c.data.end());
+    std::vector<double> sums((size_t)steps * 2);
+    check(kb_chisquare(truth.batch()->handle(), kf.batch()->handle(), steps, ctrl.data(), (int)controls.size(), 0, 1, withNEES, withNIS, sums.data()));
+    std::vector<double> nis((size_t)steps), nees((size_t)steps);
+    const double runs = (double)truth.batch()->N();
+    for (int t = 0; t < steps; t++) { nis[t] = sums[(size_t)t * 2] / runs; nees[t] = sums[(size_t)t * 2 + 1] / runs; }
+    return {nis, nees};
+}
+
 }  // namespace gokalman

@@ -304,3 +304,35 @@ def mc_mean_stddev(states):
     mean, std = np.zeros(n), np.zeros(n)
     lib().orc_mc_mean_stddev(runs, n, _p(states), mean.ctypes.data_as(_dp), std.ctypes.data_as(_dp))
     return mean, std
+
+
+def chisquare(kf_factory, truth_states, truth_meas, controls, with_nees=True, with_nis=True):
+    """chisquare.go:16-95 NewChiSquare, restated over oracle filters.
+
+    truth_states[run][step][n], truth_meas[run][step][p] are the Monte-Carlo estimates' State() and
+    Measurement(); kf_factory() returns a fresh Vanilla oracle filter (the reference Reset()s one filter
+    per run, chisquare.go:39).  Returns (NISmeans, NEESmeans) (stat.Mean over runs, :85-94)."""
+    truth_states = np.asarray(truth_states, dtype=np.float64)
+    truth_meas = np.asarray(truth_meas, dtype=np.float64)
+    runs, steps, n = truth_states.shape
+    nis = np.zeros((steps, runs))
+    nees = np.zeros((steps, runs))
+    for r in range(runs):
+        kf = kf_factory()
+        H = None
+        for t in range(steps):
+            u = None if controls is None else controls[t if len(controls) > 1 else 0]
+            rc = kf.update(truth_meas[r, t], u)
+            assert rc == OK, rc
+            if with_nees:
+                rcode, Pinv, _ = inverse(kf.covariance())
+                d = truth_states[r, t] - kf.state()
+                nees[t, r] = d @ (Pinv @ d)
+            if with_nis:
+                # Pyy = H P- H^T + R: the innovation covariance the update inverted for the gain
+                Pm, K, innov = kf.pred_covariance(), kf.gain(), kf.innovation()
+                H = kf._H
+                Pyy = H @ (Pm @ H.T) + kf._R
+                rcode, PyyInv, _ = inverse(Pyy)
+                nis[t, r] = innov @ (PyyInv @ innov)
+    return nis.mean(axis=1), nees.mean(axis=1)

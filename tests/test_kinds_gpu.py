@@ -281,3 +281,43 @@ def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     assert synth.rel_frobenius(dev.get(k.RAW_VEC), host.get(k.RAW_VEC)) <= tol
     assert synth.rel_frobenius(dev.get(k.RAW_MAT), host.get(k.RAW_MAT)) <= tol
     assert dev.step() == steps and not dev.status().any()
+
+
+def test_chisquare_nees_nis_vs_oracle_replay():
+    """NewChiSquare (chisquare.go:16-95) on the examples/robot model (main.go:17-41): truth from a
+    pure predictor + AWGN, a Noiseless Vanilla filter under test; the device's noise draws are
+    replayed through the oracle and NIS / NEES means compared per step."""
+    dt = 0.1
+    F = np.array([[1, dt], [0, 1]]); G = np.array([[0.5 * dt * dt], [dt]]); H = np.array([[1.0, 0]])
+    R = np.array([[0.05]]); Q = np.array([[5e-2, 5e-4], [5e-4, 1e-3]])
+    x0, P0 = np.zeros(2), 2.0 * np.eye(2)
+    mc_x0 = np.array([0.7, -0.3])
+    runs, steps = 96, 30
+    controls = np.cos(0.75 * (np.arange(steps) + 1) * 0.1).reshape(steps, 1)
+    truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=77)
+    kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, nfilters=runs)
+    mc = ga.new_monte_carlo_runs(runs, steps, 1, controls, truth)
+    nis, nees = ga.new_chi_square(kf, truth, steps, controls)           # same runs as `mc`
+    LQ, LR = orc.cholesky_lower(Q)[1], orc.cholesky_lower(R)[1]
+    ts, tm = np.zeros((runs, steps, 2)), np.zeros((runs, steps, 1))
+    for r in range(runs):
+        f = orc.Filter.ldkf(orc.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R)
+        for t in range(steps):
+            w = LQ @ truth.noise_sample(r, 0, t, 0, 2); v = LR @ truth.noise_sample(r, 0, t, 1, 1)
+            assert f.update(np.zeros(1), controls[t], w_pred=w, v_meas=v) == orc.OK
+            ts[r, t], tm[r, t] = f.state(), f.measurement()
+    for t in range(steps):
+        assert np.allclose(mc.mean(t), ts[:, t].mean(axis=0), rtol=1e-9, atol=1e-12)
+
+    def factory():
+        f = orc.Filter.ldkf(orc.VANILLA, x0, P0, F, G, H, Q, R)
+        f._H, f._R = H, R
+        return f
+
+    onis, onees = orc.chisquare(factory, ts, tm, controls)
+    assert np.allclose(nis, onis, rtol=1e-8) and np.allclose(nees, onees, rtol=1e-8)
+    assert 0.3 < nis.mean() < 3.0     # a consistent filter has E[NIS] = p = 1
+    with pytest.raises(ga.KalmanError, match="either NEES or NIS"):
+        ga.new_chi_square(kf, truth, steps, controls, with_nees=False, with_nis=False)
+    with pytest.raises(ga.KalmanError, match="as much control vectors as steps"):
+        ga.new_chi_square(kf, truth, steps, controls[:2])
