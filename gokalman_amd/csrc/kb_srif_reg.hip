@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     if (tile >= a.ntiles) return;
     const int64_t fi = tile * KB_TILE + lane;
     const bool active = fi < a.N;
-    if (active && a.status[fi] != 0u) return;  // failed (now or earlier): the estimate stays frozen
+    if (active && (a.status[fi] & (KB_ST_SINGULAR | KB_ST_ASYMMETRIC | KB_ST_NONFINITE)) != 0u) return;  // failed (now or earlier): the estimate stays frozen
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;

@@ -15,288 +15,11 @@
 // A filter whose S is singular / ill-conditioned or whose result is non-finite keeps its
 // previous estimate and gets a status bit, as the reference's (nil, err) return does.
 #include "kb_internal.h"
+#include "kb_vanilla_reg.h"
 
 namespace kb {
 
-template <typename T>
-__device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
-// Streaming (read-once) operands -- the per-filter model F/H/Q/R/G and the measurements -- are
-// loaded non-temporally so that they do not displace the state block (x, P: re-read and
-// re-written every step, 226 MB at 1M filters) from the 256 MiB Infinity Cache.  Measured on
-// MI355X with the arithmetic removed: 0.208 ms -> 0.153 ms per 1M-filter step.
-template <typename T>
-__device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
-template <typename T>
-__device__ __forceinline__ T ldnt_at(const T *p) { return __builtin_nontemporal_load(p); }
-
-// ---------------------------------------------------------------------------------
-// register-resident kernel
-// ---------------------------------------------------------------------------------
-template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED>
-__global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
-    constexpr int TR = tri(NS);
-    constexpr int TM = tri(NM);
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
-    const bool active = tile * KB_TILE + lane < a.N;
-
-    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
-    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
-    const T *yp = (const T *)a.y + tile * a.y_ts + lane;
-    const T *up = NC > 0 ? (const T *)a.u + tile * a.u_ts + lane : nullptr;
-
-    // ---- state + transition model
-    T x[NS], P[TR], F[NS * NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
-#pragma unroll
-    for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
-#pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(mo, a.L.mo_F + e);
-
-    // Issue order is pinned with scheduling barriers: (1) x, P, F -- everything the prediction
-    // needs -- then (2) Q, H, R [, G] and the first measurement, then the arithmetic.  The
-    // compiler's in-order vmcnt accounting then lets the prediction start as soon as group (1) has
-    // landed while group (2) is still in flight.
-    __builtin_amdgcn_sched_barrier(0);
-    [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1], y0[NM];
-#pragma unroll
-    for (int e = 0; e < TR; e++) Q[e] = ldnt(mo, a.L.mo_Q + e);
-#pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
-#pragma unroll
-    for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
-    if constexpr (NC > 0) {
-#pragma unroll
-        for (int e = 0; e < NS * NC; e++) G[e] = ldnt(mo, a.L.mo_G + e);
-    }
-    if constexpr (!PREDICT) {
-#pragma unroll
-        for (int r = 0; r < NM; r++) y0[r] = active ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    unsigned err_acc = 0;
-    const int nsteps = FUSED ? a.nsteps : 1;
-    for (int t = 0; t < nsteps; t++) {
-        // ---- x- = F x [+ G u]
-        T xm[NS];
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += F[i * NS + l] * x[l];
-            xm[i] = s;
-        }
-        if constexpr (NC > 0) {
-            T u[NC];
-#pragma unroll
-            for (int c = 0; c < NC; c++) u[c] = active ? ldnt_at(up + (int64_t)t * a.u_step + (int64_t)c * a.u_es) : T(0);
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                T s = T(0);
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const T g = G[i * NC + c];
-                    s += g * u[c];
-                }
-                xm[i] = xm[i] + s;
-            }
-        }
-        // ---- P- = F P F^T + Q   (upper triangle; row i of F P, then dot with rows j >= i of F)
-        T Pm[TR];
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            T fp[NS];
-#pragma unroll
-            for (int k = 0; k < NS; k++) {
-                T s = T(0);
-#pragma unroll
-                for (int l = 0; l < NS; l++) s += F[i * NS + l] * P[symi(l, k)];
-                fp[k] = s;
-            }
-#pragma unroll
-            for (int j = i; j < NS; j++) {
-                T s = T(0);
-#pragma unroll
-                for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
-                Pm[symi(i, j)] = s + Q[symi(i, j)];
-            }
-        }
-        // ---- yhat = H x_prev (previous posterior, vanilla.go:155-157)
-        [[maybe_unused]] T yhat[NM];
-        if constexpr (FULL) {
-#pragma unroll
-            for (int r = 0; r < NM; r++) {
-                T s = T(0);
-#pragma unroll
-                for (int l = 0; l < NS; l++) s += H[r * NS + l] * x[l];
-                yhat[r] = s;
-            }
-        }
-        // ---- gain K = P- H^T (H P- H^T + R)^-1
-        T PHt[NS * NM];
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int c = 0; c < NM; c++) {
-                T s = T(0);
-#pragma unroll
-                for (int l = 0; l < NS; l++) s += Pm[symi(i, l)] * H[c * NS + l];
-                PHt[i * NM + c] = s;
-            }
-        T S[NM * NM], Si[NM * NM];
-#pragma unroll
-        for (int r = 0; r < NM; r++)
-#pragma unroll
-            for (int c = 0; c < NM; c++) {
-                T s = T(0);
-#pragma unroll
-                for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
-                S[r * NM + c] = s + R[symi(r, c)];
-            }
-        unsigned err = inverse_lu<T, NM>(S, Si) ? KB_ST_SINGULAR : 0u;
-        T K[NS * NM];
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int c = 0; c < NM; c++) {
-                T s = T(0);
-#pragma unroll
-                for (int k = 0; k < NM; k++) s += PHt[i * NM + k] * Si[k * NM + c];
-                K[i * NM + c] = s;
-            }
-
-        T xn[NS], Pn[TR];
-        [[maybe_unused]] T innov[NM];
-        if constexpr (PREDICT) {
-            // vanilla.go:170-179: estimate = {x-, yhat, 0, sym(P-), sym(P-), K}
-#pragma unroll
-            for (int i = 0; i < NS; i++) xn[i] = xm[i];
-#pragma unroll
-            for (int e = 0; e < TR; e++) Pn[e] = Pm[e];
-#pragma unroll
-            for (int r = 0; r < NM; r++) innov[r] = T(0);
-        } else {
-            // ---- innovation and state update
-#pragma unroll
-            for (int r = 0; r < NM; r++) {
-                const T yv = (t == 0) ? y0[r] : (active ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
-                T s = T(0);
-#pragma unroll
-                for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
-                innov[r] = yv - s;
-            }
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                T s = T(0);
-#pragma unroll
-                for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
-                xn[i] = xm[i] + s;
-            }
-            // ---- Joseph form, upper triangle: P+ = K R K^T + A P- A^T,  A = I - K H
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                T kr[NM];
-#pragma unroll
-                for (int c = 0; c < NM; c++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
-                    kr[c] = s;
-                }
-#pragma unroll
-                for (int j = i; j < NS; j++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
-                    Pn[symi(i, j)] = s;
-                }
-            }
-            T A[NS * NS];
-#pragma unroll
-            for (int i = 0; i < NS; i++)
-#pragma unroll
-                for (int j = 0; j < NS; j++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
-                    A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
-                }
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                T ap[NS];
-#pragma unroll
-                for (int k = 0; k < NS; k++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
-                    ap[k] = s;
-                }
-#pragma unroll
-                for (int j = i; j < NS; j++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
-                    Pn[symi(i, j)] = s + Pn[symi(i, j)];
-                }
-            }
-        }
-        // ---- non-finite screen (stands in for AsSymDense's NaN-failing comparison)
-        T chk = T(0);
-#pragma unroll
-        for (int i = 0; i < NS; i++) chk += xn[i] * T(0);
-#pragma unroll
-        for (int e = 0; e < TR; e++) chk += Pn[e] * T(0);
-        if (chk != chk) err |= KB_ST_NONFINITE;
-        if (err_acc) err = 0;  // already frozen: keep the first failure only
-        const bool ok = (err | err_acc) == 0;
-        err_acc |= err;
-
-        if constexpr (FULL) {
-            // Estimate extras of this step (only meaningful for the last fused step)
-            if (active && ok) {
-                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
-#pragma unroll
-                for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
-#pragma unroll
-                for (int i = 0; i < NS; i++)
-#pragma unroll
-                    for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
-#pragma unroll
-                for (int r = 0; r < NM; r++) {
-                    stt(es, a.L.es_innov + r, innov[r]);
-                    stt(es, a.L.es_yhat + r, yhat[r]);
-                }
-            }
-        }
-        if constexpr (FUSED) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) x[i] = ok ? xn[i] : x[i];
-#pragma unroll
-            for (int e = 0; e < TR; e++) P[e] = ok ? Pn[e] : P[e];
-        } else {
-            if (active && ok) {
-#pragma unroll
-                for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
-#pragma unroll
-                for (int e = 0; e < TR; e++) stt(st, NS + e, Pn[e]);
-            }
-        }
-    }
-    if constexpr (FUSED) {
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) stt(st, i, x[i]);
-#pragma unroll
-            for (int e = 0; e < TR; e++) stt(st, NS + e, P[e]);
-        }
-    }
-    if (active && err_acc) atomicOr(a.status + tile * KB_TILE + lane, err_acc);
-}
+// (vanilla_reg_kernel and try_reg live in kb_vanilla_reg.h)
 
 // ---------------------------------------------------------------------------------
 // generic run-time-dimension kernel (private arrays with leading dimension LD)
@@ -516,30 +239,13 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
 // ---------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------
-template <typename T, int NS, int NM, int NC>
-static bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
-    if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC) return false;
-    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
-    const dim3 grid = tile_grid(a.ntiles), block(256);
-#define KB_GO(FULL_, PRED_, FUSED_) \
-    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_>), grid, block, 0, b.stream, a)
-    if (a.predict) {
-        if (full) { if (fused) KB_GO(true, true, true); else KB_GO(true, true, false); }
-        else      { if (fused) KB_GO(false, true, true); else KB_GO(false, true, false); }
-    } else {
-        if (full) { if (fused) KB_GO(true, false, true); else KB_GO(true, false, false); }
-        else      { if (fused) KB_GO(false, false, true); else KB_GO(false, false, false); }
-    }
-#undef KB_GO
-    return true;
-}
-
 template <typename T>
 static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
     const bool special = !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS;
     bool done = false;
     if (special) {
         done = try_reg<T, 6, 3, 0>(b, a, fused) || try_reg<T, 4, 2, 0>(b, a, fused);
+        if (!done && b.dtype == KB_F64) done = launch_vanilla_extra_shapes(b, a, fused);
     }
     if (!done) {
         const int d = a.n > a.p ? (a.n > a.m ? a.n : a.m) : (a.p > a.m ? a.p : a.m);

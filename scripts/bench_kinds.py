@@ -13,7 +13,7 @@ import gokalman_amd as ga
 from gokalman_amd import _capi as k, synth
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["sqrt", "info", "srif", "hybrid", "mc"]
+which = args or ["vfull", "sqrt", "info", "srif", "hybrid", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -41,6 +41,15 @@ def report(name, N, ms, bytes_per, extra=None):
         out.update(extra)
     print(json.dumps(out), flush=True)
 
+
+if "vfull" in which:
+    N = Nopt or (1 << 20)
+    d = synth.linear_batch(N, 6, 3, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+    report("B': Vanilla 6/3 f64, FULL_ESTIMATE (also writes P-, K, innovation, yhat: +480 B)", N, ms, 1488 + 480, {"errors": int(np.count_nonzero(b.status()))})
+    del b
 
 if "sqrt" in which or "info" in which:
     N = Nopt or (1 << 20)
