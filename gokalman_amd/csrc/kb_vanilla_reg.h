@@ -19,6 +19,9 @@ template <typename T>
 __device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
 template <typename T>
 __device__ __forceinline__ T ldnt_at(const T *p) { return __builtin_nontemporal_load(p); }
+// write-once Estimate extras (P-, K, innovation, yhat) are stored non-temporally for the same reason
+template <typename T>
+__device__ __forceinline__ void stnt(T *p, int e, T v) { __builtin_nontemporal_store(v, p + (int64_t)e * KB_TILE); }
 
 // ---------------------------------------------------------------------------------
 // register-resident kernel
@@ -250,15 +253,15 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
             if (active && ok) {
                 T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll
-                for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
+                for (int e = 0; e < TR; e++) stnt(es, a.L.es_ppred + e, Pm[e]);
 #pragma unroll
                 for (int i = 0; i < NS; i++)
 #pragma unroll
-                    for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                    for (int c = 0; c < NM; c++) stnt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
                 for (int r = 0; r < NM; r++) {
-                    stt(es, a.L.es_innov + r, innov[r]);
-                    stt(es, a.L.es_yhat + r, yhat[r]);
+                    stnt(es, a.L.es_innov + r, innov[r]);
+                    stnt(es, a.L.es_yhat + r, yhat[r]);
                 }
             }
         }
