@@ -102,7 +102,13 @@ if "hybrid" in which:
     del b
 
 if "mc" in which:
-    from tests.test_kinds_gpu import STATOD as s
+    s = dict(  # examples/statOD5044/main.go:36-57
+        F=np.array([[1, 0.1, 0, 7.726e-2], [4.015e-7, 1, 0, 1.545], [-2.319e-16, -1.732e-9, 1, 0.1], [-6.956e-15, -3.465e-8, 0, 1]]),
+        G=np.array([[5e-3, 3.85e-7], [0.1, 1.157e-5], [-5.775e-11, 7.487e-7], [1.732e-9, 1.498e-5]]),
+        H=np.array([[1.0, 0, 0, 0], [0, 0, 1, 0]]),
+        Q=np.array([[6.669e-16, 1.001e-14, 3.823e-19, 5.150e-18], [1.001e-14, 2.002e-13, 1.030e-17, 1.545e-16],
+                    [3.862e-19, 1.030e-17, 6.667e-19, 1.000e-17], [5.150e-18, 1.545e-16, 1.000e-17, 2.000e-16]]),
+        R=np.diag([2e-3, 2e-5]) / 0.1, x0=np.array([2, 0.5, 0, 0.0]), P0=np.diag([5, 1, 0.01, 1e-5]))
     runs, steps = Nopt or (1 << 20), 1086
     kf = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, s["x0"], s["P0"], s["F"], s["G"], s["H"], s["Q"], s["R"],
                                  nfilters=runs, noise=k.NOISE_AWGN, seed=1)

@@ -128,3 +128,30 @@ def test_predict_only_vanilla_matches_oracle():
     assert synth.rel_frobenius(est.pred_covariance(), np.array(Ps)) <= 1e-9
     assert synth.rel_frobenius(est.gain(), np.array(Ks)) <= 1e-9
     assert np.all(est.innovation() == 0)
+
+
+def test_device_side_set_and_get_planar_roundtrip():
+    """kb_set_dev / kb_get_dev: planar device arrays in, planar device arrays out (no PCIe)."""
+    import torch
+    N, n, p, steps = 777, 6, 3, 3
+    d = synth.linear_batch(N, n, p, steps)
+    ref = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    b = ga.FilterBatch(k.VANILLA, n, p, 0, N)
+
+    def planar(a):  # [N, ...] -> [elems, N] on the device
+        return torch.from_numpy(np.ascontiguousarray(a.reshape(N, -1).T)).cuda()
+
+    keep = []
+    for field, arr, pr in ((k.X, d["x0"], 0), (k.P, d["P0"], 0), (k.F, d["F"], 0), (k.H, d["H"], p), (k.Q, d["Q"], 0), (k.R, d["R"], p)):
+        t = planar(arr); keep.append(t)
+        b.set_dev(field, t.data_ptr(), N, p_rows=pr)
+    b.init()
+    for t in range(steps):
+        ref.update(d["y"][t]); b.update(d["y"][t])
+    assert np.array_equal(b.get(k.STATE), ref.get(k.STATE)) and np.array_equal(b.get(k.COVAR), ref.get(k.COVAR))
+    xs = torch.zeros(n, N + 5, dtype=torch.float64, device="cuda"); Ps = torch.zeros(n * n, N + 5, dtype=torch.float64, device="cuda")
+    k.check(k.lib().kb_get_dev(b._h, k.STATE, xs.data_ptr(), N + 5))
+    k.check(k.lib().kb_get_dev(b._h, k.COVAR, Ps.data_ptr(), N + 5))
+    b.synchronize()
+    assert np.array_equal(xs.cpu().numpy()[:, :N].T, ref.get(k.STATE))
+    assert np.array_equal(Ps.cpu().numpy()[:, :N].T.reshape(N, n, n), ref.get(k.COVAR))
