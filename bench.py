@@ -63,8 +63,8 @@ def _cpu_baseline(d, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--filters", type=int, default=1 << 20, help="filters per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-steps", type=int, default=16, help="T of the extra time-fused measurement (0 = skip)")
