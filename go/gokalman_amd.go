@@ -19,6 +19,7 @@ import (
 	"errors"
 	"math"
 	"runtime"
+	"time"
 	"unsafe"
 
 	"github.com/ChristopherRabotin/gokalman"
@@ -164,6 +165,139 @@ var _ gokalman.LDKF = (*Vanilla)(nil)
 var _ gokalman.Estimate = Estimate{}
 var _ = math.Sqrt
 
-// SquareRoot, Information (KB_SQUAREROOT, KB_INFORMATION) and the NLDKF types SRIF / HybridKF
-// (kb_prepare, kb_prepare_pnt, kb_update_nl, kb_predict_nl, kb_set_ekf) follow the same pattern:
-// see INTEGRATION.md for the complete method-to-entry-point table.
+// newLDKF is the shared constructor body of the LDKF kinds (vanilla.go:21, squareroot.go:21,
+// information.go:20/65): kind selects the device kernels, flags carries INFO_FROM_STATE.
+func newLDKF(kind C.int, flags C.uint, x0 *mat64.Vector, P0 mat64.Symmetric, F, G, H mat64.Matrix, noise gokalman.Noise) (*Vanilla, *Estimate, error) {
+	n, _ := x0.Dims()
+	p, _ := H.Dims()
+	_, m := G.Dims()
+	b, err := newBatch(kind, n, p, m, 1, C.KB_FLAG_FULL_ESTIMATE|flags)
+	if err != nil {
+		return nil, nil, err
+	}
+	for _, s := range []struct {
+		f C.int
+		m mat64.Matrix
+		p int
+	}{{C.KB_X, x0, 0}, {C.KB_P, P0, 0}, {C.KB_F, F, 0}, {C.KB_G, G, 0}, {C.KB_H, H, p},
+		{C.KB_Q, noise.ProcessMatrix(), 0}, {C.KB_R, noise.MeasurementMatrix(), p}} {
+		if err := b.set(s.f, s.m, s.p); err != nil {
+			return nil, nil, err
+		}
+	}
+	if _, isAWGN := noise.(*gokalman.AWGN); isAWGN {
+		if err := kbErr(C.kb_set_noise_kind(b.h, C.KB_NOISE_AWGN, C.uint64_t(time.Now().UnixNano()))); err != nil {
+			return nil, nil, err // "process noise invalid" (noise.go:148-156 panics there)
+		}
+	}
+	if err := kbErr(C.kb_init(b.h)); err != nil {
+		return nil, nil, err
+	}
+	return &Vanilla{b, F, G, H, noise}, &Estimate{b}, nil
+}
+
+// The remaining LDKF constructors differ only in the kind handed to kb_create; the returned value
+// satisfies gokalman.LDKF through the methods defined on *Vanilla above.
+func NewPurePredictorVanilla(x0 *mat64.Vector, P0 mat64.Symmetric, F, G, H mat64.Matrix, n gokalman.Noise) (*Vanilla, *Estimate, error) {
+	return newLDKF(C.KB_VANILLA_PREDICT, 0, x0, P0, F, G, H, n) // vanilla.go:43-62
+}
+func NewSquareRoot(x0 *mat64.Vector, P0 mat64.Symmetric, F, G, H mat64.Matrix, n gokalman.Noise) (*Vanilla, *Estimate, error) {
+	return newLDKF(C.KB_SQUAREROOT, 0, x0, P0, F, G, H, n) // squareroot.go:21-50
+}
+func NewInformation(i0 *mat64.Vector, I0 mat64.Symmetric, F, G, H mat64.Matrix, n gokalman.Noise) (*Vanilla, *Estimate, error) {
+	return newLDKF(C.KB_INFORMATION, 0, i0, I0, F, G, H, n) // information.go:20-53
+}
+func NewInformationFromState(x0 *mat64.Vector, P0 mat64.Symmetric, F, G, H mat64.Matrix, n gokalman.Noise) (*Vanilla, *Estimate, error) {
+	return newLDKF(C.KB_INFORMATION, C.KB_FLAG_INFO_FROM_STATE, x0, P0, F, G, H, n) // information.go:65-81
+}
+
+// NLDKF implements gokalman.NLDKF (kalman.go:51-60) for SRIF and HybridKF batches.
+type NLDKF struct{ b *batch }
+
+func newNLDKF(kind C.int, x0 *mat64.Vector, P0 mat64.Symmetric, noise gokalman.Noise, measSize int, flags C.uint) (*NLDKF, *Estimate, error) {
+	n, _ := x0.Dims()
+	q := 0
+	if kind == C.KB_HYBRID {
+		q, _ = noise.ProcessMatrix().Dims()
+	}
+	b, err := newBatch(kind, n, measSize, q, 1, C.KB_FLAG_FULL_ESTIMATE|flags)
+	if err != nil {
+		return nil, nil, err
+	}
+	if err := b.set(C.KB_X, x0, 0); err != nil {
+		return nil, nil, err
+	}
+	if err := b.set(C.KB_P, P0, 0); err != nil {
+		return nil, nil, err
+	}
+	if err := b.set(C.KB_R, noise.MeasurementMatrix(), measSize); err != nil {
+		return nil, nil, err
+	}
+	if q > 0 {
+		if err := b.set(C.KB_Q, noise.ProcessMatrix(), 0); err != nil {
+			return nil, nil, err
+		}
+	}
+	if err := kbErr(C.kb_init(b.h)); err != nil {
+		return nil, nil, err
+	}
+	return &NLDKF{b}, &Estimate{b}, nil
+}
+
+// NewSRIF mirrors gokalman.NewSRIF (srif.go:14-49); NewHybridKF mirrors hybrid.go:23-34.
+func NewSRIF(x0 *mat64.Vector, P0 mat64.Symmetric, measSize int, nonTriR bool, n gokalman.Noise) (*NLDKF, *Estimate, error) {
+	var fl C.uint
+	if nonTriR {
+		fl = C.KB_FLAG_SRIF_NON_TRI_R
+	}
+	p, _ := n.MeasurementMatrix().Dims()
+	_ = measSize // only sizes Predict()'s zero vectors in the reference
+	return newNLDKF(C.KB_SRIF, x0, P0, n, p, fl)
+}
+func NewHybridKF(x0 *mat64.Vector, P0 mat64.Symmetric, n gokalman.Noise, measSize int) (*NLDKF, *Estimate, error) {
+	return newNLDKF(C.KB_HYBRID, x0, P0, n, measSize, 0)
+}
+
+func (kf *NLDKF) Prepare(Φ, Htilde *mat64.Dense) { // srif.go:82-86, hybrid.go:78-82
+	phi, h := rowMajor(Φ), rowMajor(Htilde)
+	if err := kbErr(C.kb_prepare(kf.b.h, ptr(phi), ptr(h), 1, 1)); err != nil {
+		panic(err)
+	}
+}
+func (kf *NLDKF) PreparePNT(Γ *mat64.Dense) { // hybrid.go:86-89
+	g := rowMajor(Γ)
+	if err := kbErr(C.kb_prepare_pnt(kf.b.h, ptr(g), 1, 1)); err != nil {
+		panic(err)
+	}
+}
+func (kf *NLDKF) Update(realObservation, computedObservation *mat64.Vector) (gokalman.Estimate, error) { // srif.go:90, hybrid.go:93
+	r, c := rowMajor(realObservation), rowMajor(computedObservation)
+	if err := kbErr(C.kb_update_nl(kf.b.h, ptr(r), C.int(len(r)), ptr(c), C.int(len(c)))); err != nil {
+		return nil, err // "kf is locked (call Prepare() first)", "dimensions must agree: ..."
+	}
+	var st C.uint32_t
+	C.kb_get_status(kf.b.h, &st, 0, 1)
+	if st&C.KB_ST_SINGULAR != 0 {
+		return nil, errors.New("could not invert `H*P_kp1_minus*H' + R`")
+	}
+	return Estimate{kf.b}, nil
+}
+func (kf *NLDKF) Predict() (gokalman.Estimate, error) { // srif.go:96, hybrid.go:99
+	if err := kbErr(C.kb_predict_nl(kf.b.h)); err != nil {
+		return nil, err
+	}
+	return Estimate{kf.b}, nil
+}
+func (kf *NLDKF) EKFEnabled() bool { return C.kb_ekf_enabled(kf.b.h) != 0 }
+func (kf *NLDKF) EnableEKF()       { C.kb_set_ekf(kf.b.h, 1) }
+func (kf *NLDKF) DisableEKF()      { C.kb_set_ekf(kf.b.h, 0) }
+func (kf *NLDKF) SetNoise(n gokalman.Noise) {
+	p, _ := n.MeasurementMatrix().Dims()
+	kf.b.set(C.KB_R, n.MeasurementMatrix(), p)
+}
+
+var _ gokalman.NLDKF = (*NLDKF)(nil)
+
+// MonteCarloRuns / NewMonteCarloRuns (montecarlo.go:12-59, 92-119) and NewChiSquare (chisquare.go:16-95)
+// bind kb_mc_run + kb_mc_stats and kb_chisquare the same way; the truth filter is a batch created with
+// nfilters = samples.

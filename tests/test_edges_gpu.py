@@ -155,3 +155,44 @@ def test_device_side_set_and_get_planar_roundtrip():
     b.synchronize()
     assert np.array_equal(xs.cpu().numpy()[:, :N].T, ref.get(k.STATE))
     assert np.array_equal(Ps.cpu().numpy()[:, :N].T.reshape(N, n, n), ref.get(k.COVAR))
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    import torch
+    d = synth.linear_batch(20000, 6, 3, 1)
+
+    def cycle():
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+        b.update(d["y"][0]); b.get(k.COVAR); b.is_within_nsigma(2.0)
+        s = ga.FilterBatch.new_ldkf(k.SQUAREROOT, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        s.update(d["y"][0]); s.get(k.COVAR)
+        b.close(); s.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_large_batch_4m_filters_properties():
+    """4M filters (beyond what the oracle can replay): size-independent properties -- every filter finite and
+    status-clean, covariance diagonals positive, and shard-invariance: filter i of a 4M batch equals filter i
+    of a 4096-filter batch built from the same rows."""
+    N, small = 1 << 22, 4096
+    rng = np.random.default_rng(0)
+    base = synth.linear_batch(small, 6, 3, 2)
+    rep = N // small
+    big = {kk: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if kk != "y" else np.tile(v, (1, rep, 1))) for kk, v in base.items()}
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, big["x0"], big["P0"], big["F"], None, big["H"], big["Q"], big["R"])
+    s = ga.FilterBatch.new_ldkf(k.VANILLA, base["x0"], base["P0"], base["F"], None, base["H"], base["Q"], base["R"])
+    for t in range(2):
+        b.update(big["y"][t]); s.update(base["y"][t])
+    assert not b.status().any()
+    tail = b.get(k.COVAR, N - small, small)
+    assert np.array_equal(tail, s.get(k.COVAR)) and np.array_equal(b.get(k.STATE, N - small, small), s.get(k.STATE))
+    assert np.all(np.isfinite(tail)) and np.all(np.diagonal(tail, axis1=1, axis2=2) > 0)
+    del rng
