@@ -158,7 +158,7 @@ __global__ void pack_planar_kernel(const T *__restrict__ src, int64_t ld, int sr
 
 void fill_step_args(const Batch &b, StepArgs &a) {
     memset(&a, 0, sizeof(a));
-    a.state = b.d_state; a.pred = b.d_pred; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status;
+    a.state = b.d_state; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status;
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p;
@@ -259,7 +259,7 @@ void kb_destroy(kb_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    void *ptrs[] = {b->d_state, b->d_state0, b->d_pred, b->d_pred0, b->d_est, b->d_model, b->d_status,
+    void *ptrs[] = {b->d_state, b->d_state0, b->d_est, b->d_model, b->d_status,
                     b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

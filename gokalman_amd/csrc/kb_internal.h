@@ -13,8 +13,7 @@ namespace kb {
 // HBM layout of one batch (all blocks AoSoA-64, see kb_device.h).
 //
 //   state block : raw vector [n] | raw matrix (packed sym or full, per kind)
-//   pred  block : predicted matrix (P- / S- / I- / Rbar)        -- kinds that keep it
-//   est   block : P- (packed) | K [n][pmax] | innovation [pmax] | yhat [pmax]   (FULL_ESTIMATE)
+//   est   block : P- / S- / I- / Rbar | K [n][pmax] | innovation [pmax] | yhat [pmax] | dobs [pmax]   (FULL_ESTIMATE)
 //   model block : F [n*n] | H [pmax*n] | Q packed | R packed(pmax) | G [n*m] | kind-specific
 // ---------------------------------------------------------------------------
 struct Layout {
@@ -40,7 +39,6 @@ struct Batch {
     Layout L;
     hipStream_t stream = nullptr;
     void *d_state = nullptr, *d_state0 = nullptr;  // current / initial estimate
-    void *d_pred = nullptr, *d_pred0 = nullptr;
     void *d_est = nullptr;
     void *d_model = nullptr;
     uint32_t *d_status = nullptr;
@@ -79,7 +77,7 @@ int hip_fail(hipError_t e, const char *what);
 
 // Arguments common to the step kernels (kept POD so it travels as kernarg).
 struct StepArgs {
-    void *state, *pred, *est, *model;
+    void *state, *est, *model;
     uint32_t *status;
     const void *y; int64_t y_es, y_ts, y_step;   // element stride, tile stride, step stride (elements)
     const void *y2; int64_t y2_es, y2_ts;        // NLDKF: computed observation
@@ -104,7 +102,6 @@ int launch_unpack(const Batch &b, const void *src_block, int src_elems, const in
                   int dst_elems, double *dst_aos, int64_t first, int64_t count);
 int launch_unpack_planar(const Batch &b, const void *src_block, int src_elems, const int16_t *map, int dst_elems,
                          void *dst, int64_t ld);
-int launch_pack_u(const Batch &b);
 
 // kb_vanilla.hip
 int launch_vanilla(const Batch &b, const StepArgs &a, bool fused);
