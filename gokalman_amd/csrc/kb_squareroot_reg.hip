@@ -13,7 +13,7 @@
 
 namespace kb {
 #ifndef SQRT_WAVES
-#define SQRT_WAVES 1
+#define SQRT_WAVES 2
 #endif
 
 template <typename T>
@@ -55,6 +55,10 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
     T xm[NS];
     smv<T, NS, NS>(F, x, xm);
     // :155-185 C = [S^T F^T ; sqrtQ^T] -> Uc; QUIRK S- := Uc (upper)
+    // Build order bounds the live set: the top block row by row (column i of S dies with row i), then a
+    // scheduling barrier, and only then chol(Q) for the bottom block -- F is dead by then.  Without the
+    // barrier the compiler hoists every load to the top and x, S, F, C and chol(Q) (126 doubles) are
+    // alive together.
     T C[2 * NS * NS];
 #pragma unroll
     for (int i = 0; i < NS; i++)
@@ -64,9 +68,14 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
 #pragma unroll
             for (int l = i; l < NS; l++) s += S[symi(i, l)] * F[j * NS + l];  // S[l][i], l >= i
             C[i * NS + j] = s;
-            C[(NS + i) * NS + j] = (j >= i) ? ld_nt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
         }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i) ? ld_nt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
     sqr_r<T, 2 * NS, NS, ActC<NS>>(C);
+    __builtin_amdgcn_sched_barrier(0);  // H, chol(R) loads and the Delta panel stay below the C phase
     // Sm[i][j] = C[i*NS+j], j >= i
     T H[NM * NS];
 #pragma unroll

@@ -7,21 +7,40 @@
 
 namespace kb {
 
+// Addressing: every block pointer below is WAVE-UNIFORM (tile index through readfirstlane), run-time
+// field offsets are folded into that uniform base and the lane enters as a 32-bit offset, so the
+// per-element offsets become instruction immediates: ~25 address computations per step instead of ~100.
 template <typename T>
-__device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+struct TilePtr {
+    T *base;        // uniform: start of this wave's tile (or of one field inside it)
+    unsigned lane;  // 0..63
+    __device__ __forceinline__ T ld(int e) const { return (base + e * KB_TILE)[lane]; }
+    __device__ __forceinline__ T ldnt(int e) const { return __builtin_nontemporal_load(base + e * KB_TILE + lane); }
+    __device__ __forceinline__ void st(int e, T v) const { (base + e * KB_TILE)[lane] = v; }
+    __device__ __forceinline__ void stnt(int e, T v) const { __builtin_nontemporal_store(v, base + e * KB_TILE + lane); }
+    __device__ __forceinline__ TilePtr field(int first_elem) const { return TilePtr{base + (int64_t)first_elem * KB_TILE, lane}; }
+};
+template <typename T>
+__device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }   // per-lane pointer form (generic kernel)
 template <typename T>
 __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+template <typename T>
+__device__ __forceinline__ T ldt(const TilePtr<T> &p, int e) { return p.ld(e); }
+template <typename T>
+__device__ __forceinline__ T ldt(const TilePtr<const T> &p, int e) { return p.ld(e); }
+template <typename T>
+__device__ __forceinline__ void stt(const TilePtr<T> &p, int e, T v) { p.st(e, v); }
 // Streaming (read-once) operands -- the per-filter model F/H/Q/R/G and the measurements -- are
 // loaded non-temporally so that they do not displace the state block (x, P: re-read and
 // re-written every step, 226 MB at 1M filters) from the 256 MiB Infinity Cache.  Measured on
 // MI355X with the arithmetic removed: 0.208 ms -> 0.153 ms per 1M-filter step.
 template <typename T>
-__device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
+__device__ __forceinline__ T ldnt(const TilePtr<const T> &p, int e) { return p.ldnt(e); }
 template <typename T>
 __device__ __forceinline__ T ldnt_at(const T *p) { return __builtin_nontemporal_load(p); }
 // write-once Estimate extras (P-, K, innovation, yhat) are stored non-temporally for the same reason
 template <typename T>
-__device__ __forceinline__ void stnt(T *p, int e, T v) { __builtin_nontemporal_store(v, p + (int64_t)e * KB_TILE); }
+__device__ __forceinline__ void stnt(const TilePtr<T> &p, int e, T v) { p.stnt(e, v); }
 
 // ---------------------------------------------------------------------------------
 // register-resident kernel
@@ -30,13 +49,15 @@ template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSE
 __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     constexpr int TM = tri(NM);
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
 
-    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
-    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const TilePtr<T> st{(T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)), lane};
+    const TilePtr<const T> mo{(const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems), lane};
+    const TilePtr<const T> moF = mo.field(a.L.mo_F), moH = mo.field(a.L.mo_H), moQ = mo.field(a.L.mo_Q), moR = mo.field(a.L.mo_R),
+                           moG = mo.field(a.L.mo_G);
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
     const T *up = NC > 0 ? (const T *)a.u + tile * a.u_ts + lane : nullptr;
 
@@ -47,7 +68,7 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
 #pragma unroll
     for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(mo, a.L.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(moF, e);
 
     // Issue order is pinned with scheduling barriers: (1) x, P, F -- everything the prediction
     // needs -- then (2) Q, H, R [, G] and the first measurement, then the arithmetic.  The
@@ -56,14 +77,14 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
     __builtin_amdgcn_sched_barrier(0);
     [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1], y0[NM];
 #pragma unroll
-    for (int e = 0; e < TR; e++) Q[e] = ldnt(mo, a.L.mo_Q + e);
+    for (int e = 0; e < TR; e++) Q[e] = ldnt(moQ, e);
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(moH, e);
 #pragma unroll
-    for (int e = 0; e < TM; e++) R[e] = ldnt(mo, a.L.mo_R + e);
+    for (int e = 0; e < TM; e++) R[e] = ldnt(moR, e);
     if constexpr (NC > 0) {
 #pragma unroll
-        for (int e = 0; e < NS * NC; e++) G[e] = ldnt(mo, a.L.mo_G + e);
+        for (int e = 0; e < NS * NC; e++) G[e] = ldnt(moG, e);
     }
     if constexpr (!PREDICT) {
 #pragma unroll
@@ -251,17 +272,18 @@ __global__ void __launch_bounds__(256, FUSED ? 1 : 2) vanilla_reg_kernel(const S
         if constexpr (FULL) {
             // Estimate extras of this step (only meaningful for the last fused step)
             if (active && ok) {
-                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+                const TilePtr<T> es0{(T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems), lane};
+                const TilePtr<T> esP = es0.field(a.L.es_ppred), esK = es0.field(a.L.es_gain), esI = es0.field(a.L.es_innov), esY = es0.field(a.L.es_yhat);
 #pragma unroll
-                for (int e = 0; e < TR; e++) stnt(es, a.L.es_ppred + e, Pm[e]);
+                for (int e = 0; e < TR; e++) stnt(esP, e, Pm[e]);
 #pragma unroll
                 for (int i = 0; i < NS; i++)
 #pragma unroll
-                    for (int c = 0; c < NM; c++) stnt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                    for (int c = 0; c < NM; c++) stnt(esK, i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
                 for (int r = 0; r < NM; r++) {
-                    stnt(es, a.L.es_innov + r, innov[r]);
-                    stnt(es, a.L.es_yhat + r, yhat[r]);
+                    stnt(esI, r, innov[r]);
+                    stnt(esY, r, yhat[r]);
                 }
             }
         }
