@@ -196,3 +196,21 @@ def test_large_batch_4m_filters_properties():
     assert np.array_equal(tail, s.get(k.COVAR)) and np.array_equal(b.get(k.STATE, N - small, small), s.get(k.STATE))
     assert np.all(np.isfinite(tail)) and np.all(np.diagonal(tail, axis1=1, axis2=2) > 0)
     del rng
+
+
+def test_nan_measurement_is_contained_to_its_filter():
+    """A NaN measurement makes that filter's update non-finite: AsSymDense's comparison fails on NaN in the
+    reference (helper.go:75, vanilla.go:207-215 -> (nil, err), estimate untouched); other filters are unaffected."""
+    N = 130
+    d = synth.linear_batch(N, 6, 3, 2)
+    d["y"][0, 77, 1] = np.nan
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    b.update(d["y"][0])
+    st = b.status()
+    assert st[77] & k.ST_NONFINITE and not st[np.arange(N) != 77].any()
+    assert np.array_equal(b.get(k.STATE, 77, 1)[0], d["x0"][77])
+    f = orc.Filter.ldkf(orc.VANILLA, d["x0"][77], d["P0"][77], d["F"][77], None, d["H"][77], d["Q"][77], d["R"][77])
+    assert f.update(d["y"][0, 77]) != orc.OK or not np.all(np.isfinite(f.state()))
+    ok = np.arange(N) != 77
+    xo, Po, _ = orc.ldkf_batch(orc.VANILLA, d["x0"][ok], d["P0"][ok], d["F"][ok], d["H"][ok], d["Q"][ok], d["R"][ok], d["y"][:1, ok])
+    assert synth.rel_frobenius(b.get(k.STATE)[ok], xo) <= 1e-9
