@@ -42,6 +42,7 @@ SIGNATURES = {
     "kb_update_nl": (_i, [_vp, _dp, _i, _dp, _i]),
     "kb_update_nl_dev": (_i, [_vp, _vp, _vp, _i64]),
     "kb_predict_nl": (_i, [_vp]),
+    "kb_smooth_all_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "kb_get": (_i, [_vp, _i, _dp, _i64, _i64]),
     "kb_get_dev": (_i, [_vp, _i, _vp, _i64]),
     "kb_get_status": (_i, [_vp, C.POINTER(C.c_uint32), _i64, _i64]),

@@ -131,6 +131,30 @@ int kb_predict_nl(kb_batch *b) {
     return KB_OK;
 }
 
+// SmoothAll(estimates) (hybrid.go:209-238, srif.go:165-192; estimates without SNC)
+int kb_smooth_all_dev(kb_batch *b, const void *phis, int64_t ld, int steps, void *x_out, void *P_out) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (!phis || !x_out || !P_out) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (ld < b->N) { set_error("ld < N"); return KB_ERR_INVALID; }
+    if (steps != b->step) {  // hybrid.go:210-212
+        set_error("incorrect number of estimates provided: %d instead of expected %lld", steps, (long long)b->step);
+        return KB_ERR_INVALID;
+    }
+    const int n = b->n;
+    if (b->kind == KB_SRIF) {
+        void *tmp = nullptr;
+        KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
+        rc = launch_materialise(*b, b->d_state, false, tmp);
+        if (!rc) rc = launch_smooth(*b, tmp, n + tri(n), 0, n, phis, ld, steps, x_out, P_out);
+        hipError_t e = hipStreamSynchronize(b->stream);
+        (void)hipFree(tmp);
+        if (!rc && e != hipSuccess) rc = hip_fail(e, "kb_smooth_all_dev");
+        return rc;
+    }
+    return launch_smooth(*b, b->d_state, b->L.st_elems, b->L.st_vec, b->L.st_mat, phis, ld, steps, x_out, P_out);
+}
+
 // ---- noise (noise.go) -------------------------------------------------------------------
 int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed) {
     if (!b) { set_error("null batch"); return KB_ERR_INVALID; }

@@ -281,6 +281,59 @@ int launch_materialise(const Batch &b, const void *src_block, bool pred, void *o
     return KB_OK;
 }
 
+// SmoothAll (hybrid.go:209-238, srif.go:165-192): backward sweep x_k = S x_{k+1}, P_k = sym(S P_{k+1} S^T),
+// S = inverse(Phi_{k+1}).  xp_block holds the last estimate's State() | Covariance() (packed); phis is the
+// caller's planar history [steps][n*n][ld]; outputs are planar [steps][n][ld] and [steps][n*n][ld].
+template <typename T, int LD>
+__global__ void __launch_bounds__(64) smooth_kernel(const T *xp_block, int xp_elems, int vec_off, int mat_off, const T *phis, int64_t ld,
+                                                    int steps, T *x_out, T *P_out, uint32_t *status, int64_t N, int n) {
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t fi = tile * KB_TILE + lane;
+    if (fi >= N) return;
+    const T *src = xp_block + tile * ((int64_t)KB_TILE * xp_elems) + lane;
+    T x[LD], P[LD * LD], S[LD * LD], W[LD * LD], A[LD * LD];
+    for (int i = 0; i < n; i++) x[i] = ldg_t(src, vec_off + i);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) P[i * LD + j] = ldg_t(src, mat_off + symi(i, j));
+    unsigned err = 0;
+    for (int k = steps - 1; k >= 0; k--) {
+        for (int i = 0; i < n; i++) x_out[((int64_t)k * n + i) * ld + fi] = x[i];
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) P_out[((int64_t)k * n * n + i * n + j) * ld + fi] = P[i * LD + j];
+        if (k == 0 || err) { if (err && k > 0) continue; break; }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) A[i * LD + j] = phis[((int64_t)k * n * n + i * n + j) * ld + fi];   // Phi of estimate k (= k+1 of the pair)
+        if (inverse_lu_rt<T, LD>(n, A, S)) { err |= KB_ST_SINGULAR; continue; }                          // "provided STM is not invertible"
+        mm_nn<T, LD, LD, LD>(n, n, n, S, P, W);
+        mm_nt<T, LD, LD, LD>(n, n, n, W, S, A);
+        T xn[LD];
+        mv_n<T, LD>(n, n, S, x, xn);
+        bool sym = true;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++)
+                if (i != j) sym = sym && sym_close(A[j * LD + i], A[i * LD + j]);
+        if (!sym) { err |= KB_ST_ASYMMETRIC; continue; }
+        for (int i = 0; i < n; i++) x[i] = xn[i];
+        for (int i = 0; i < n; i++)
+            for (int j = i; j < n; j++) { P[i * LD + j] = A[i * LD + j]; P[j * LD + i] = A[i * LD + j]; }
+    }
+    if (err) atomicOr(status + fi, err);
+}
+
+int launch_smooth(const Batch &b, const void *xp_block, int xp_elems, int vec_off, int mat_off, const void *phis, int64_t ld, int steps,
+                  void *x_out, void *P_out) {
+    const dim3 grid((unsigned)b.ntiles), block(64);
+    const int n = b.n;
+#define KB_SM(TT, LDD) hipLaunchKernelGGL((smooth_kernel<TT, LDD>), grid, block, 0, b.stream, (const TT *)xp_block, xp_elems, vec_off, mat_off, \
+                                          (const TT *)phis, ld, steps, (TT *)x_out, (TT *)P_out, b.d_status, b.N, n)
+    if (b.dtype == KB_F64) { if (n <= 4) KB_SM(double, 4); else if (n <= 8) KB_SM(double, 8); else KB_SM(double, 16); }
+    else                   { if (n <= 4) KB_SM(float, 4);  else if (n <= 8) KB_SM(float, 8);  else KB_SM(float, 16); }
+#undef KB_SM
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
 // Estimate.IsWithinNsigma (vanilla.go:231-239): |x_i| <= N sqrt(P_ii) for all i
 template <typename T>
 __global__ void within_kernel(const T *xp, int elems, int vec_off, int mat_off, int n, double nsigma, int64_t N, uint8_t *out) {

@@ -108,6 +108,8 @@ int launch_vanilla(const Batch &b, const StepArgs &a, bool fused);
 // kb_getters.hip (materialise State/Covariance for the kinds with a lazy getter)
 int launch_materialise(const Batch &b, const void *state_block, bool pred, void *out_block /* x[n] | P packed */);
 int launch_within_nsigma(const Batch &b, const void *xp_block, double nsigma, uint8_t *d_out);
+int launch_smooth(const Batch &b, const void *xp_block, int xp_elems, int vec_off, int mat_off, const void *phis, int64_t ld, int steps,
+                  void *x_out, void *P_out);
 // kb_init.hip (constructor arithmetic per kind)
 int launch_init(Batch &b, int *not_pd);
 int launch_refresh(Batch &b, int field, int *not_pd);

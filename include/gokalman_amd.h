@@ -176,6 +176,17 @@ int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs
 /* NLDKF.Predict() (srif.go:96, hybrid.go:99). */
 int kb_predict_nl(kb_batch *b);
 
+/* SmoothAll(estimates) of HybridKF / SRIF (hybrid.go:209-238, srif.go:165-192; estimates recorded
+ * without SNC): backward sweep from the batch's current (last) estimate,
+ *   S = inverse(Phi_{k+1});  x_k = S x_{k+1};  P_k = AsSymDense(S P_{k+1} S^T),  k = steps-2 .. 0.
+ * phis: the caller's history of the STMs handed to Prepare, planar on the device,
+ * phis[(k*n*n + e)*ld + i] = element e of Phi at step k of filter i (the reference keeps Phi inside
+ * every estimate; here the caller keeps the arrays it already passed to kb_prepare_dev).
+ * `steps` must equal kb_step() ("incorrect number of estimates provided", hybrid.go:210-212).
+ * Outputs, planar in the batch dtype: x_out[(k*n + i)*ld + f], P_out[(k*n*n + e)*ld + f] (full n x n).
+ * A singular Phi or an asymmetric result stops that filter's sweep and sets its status word. */
+int kb_smooth_all_dev(kb_batch *b, const void *phis, int64_t ld, int steps, void *x_out, void *P_out);
+
 /* ---- results ---------------------------------------------------------------- */
 /* Device -> host download of one Estimate member for filters [first, first+count),
  * always as float64, host layout.  KB_COVAR of SQRT / INFORMATION / SRIF batches is

@@ -1061,6 +1061,22 @@ long orc_vanilla_batch(long N, int T, int n, int p,
     return orc_ldkf_batch(ORC_VANILLA, N, T, n, p, x, P, F, H, Q, R, y, T, threads);
 }
 
+/* hybrid.go:209-238 HybridKF.SmoothAll / srif.go:165-192 SRIF.SmoothAll (no SNC):
+ * for k = l-1 .. 0:  S = inverse(Phi_{k+1});  x_k = S x_{k+1};  P_k = AsSymDense(S P_{k+1} S^T),
+ * starting from the last estimate's State() / Covariance().  Phi[k] is the STM stored in estimate k.
+ * x[steps][n], P[steps][n*n]: entry steps-1 is input, the others are written. */
+int orc_smooth_all(int n, int steps, const double *Phi, double *x, double *P) {
+    for (int k = steps - 2; k >= 0; k--) {
+        double S[NN], SP[NN], SPSt[NN];
+        if (orc_inverse(n, Phi + (size_t)(k + 1) * n * n, S, NULL) != 0) return ORC_ERR_SINGULAR;
+        mm(n, n, n, S, P + (size_t)(k + 1) * n * n, SP);
+        mm_nt(n, n, n, SP, S, SPSt);
+        mv(n, n, S, x + (size_t)(k + 1) * n, x + (size_t)k * n);
+        if (orc_as_sym_dense(n, SPSt, P + (size_t)k * n * n) != ORC_OK) return ORC_ERR_ASYMMETRIC;
+    }
+    return ORC_OK;
+}
+
 /* montecarlo.go:18-59 with gonum stat.Mean / stat.StdDev (two-pass, n-1). */
 void orc_mc_mean_stddev(long runs, int n, const double *states, double *mean, double *stddev) {
     for (int i = 0; i < n; i++) {

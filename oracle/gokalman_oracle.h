@@ -145,6 +145,9 @@ long orc_ldkf_batch(int kind, long N, int T, int n, int p,
                     int threads);
 int orc_max_threads(void);
 
+/* --- SmoothAll (hybrid.go:209-238, srif.go:165-192) ------------------------- */
+int orc_smooth_all(int n, int steps, const double *Phi, double *x, double *P);
+
 /* --- Monte-Carlo statistics (montecarlo.go:18-59) -------------------------- */
 /* states[runs][n] for ONE step -> mean[n], stddev[n] (unbiased, n-1). */
 void orc_mc_mean_stddev(long runs, int n, const double *states,

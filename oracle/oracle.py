@@ -76,6 +76,7 @@ def lib():
         L.orc_vanilla_batch.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int] + [_dp] * 7 + [C.c_int]
         L.orc_max_threads.restype = C.c_int
         L.orc_mc_mean_stddev.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp]
+        L.orc_smooth_all.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -336,3 +337,14 @@ def chisquare(kf_factory, truth_states, truth_meas, controls, with_nees=True, wi
                 rcode, PyyInv, _ = inverse(Pyy)
                 nis[t, r] = innov @ (PyyInv @ innov)
     return nis.mean(axis=1), nees.mean(axis=1)
+
+
+def smooth_all(Phi, x_last, P_last):
+    """SmoothAll (hybrid.go:209-238): Phi[steps][n][n] (the STM stored in each estimate), final state / covariance.
+    Returns (rc, x[steps][n], P[steps][n][n])."""
+    Phi = np.ascontiguousarray(Phi, dtype=np.float64)
+    steps, n, _ = Phi.shape
+    x = np.zeros((steps, n)); P = np.zeros((steps, n, n))
+    x[-1], P[-1] = x_last, P_last
+    rc = lib().orc_smooth_all(n, steps, _p(Phi), x.ctypes.data_as(_dp), P.ctypes.data_as(_dp))
+    return rc, x, P

@@ -321,3 +321,32 @@ def test_chisquare_nees_nis_vs_oracle_replay():
         ga.new_chi_square(kf, truth, steps, controls, with_nees=False, with_nis=False)
     with pytest.raises(ga.KalmanError, match="as much control vectors as steps"):
         ga.new_chi_square(kf, truth, steps, controls[:2])
+
+
+@pytest.mark.parametrize("kind", [k.HYBRID, k.SRIF])
+def test_smooth_all_backward_sweep_vs_oracle(kind):
+    """SmoothAll (hybrid.go:209-238, srif.go:165-192): x_k = S x_{k+1}, P_k = sym(S P_{k+1} S^T), S = inverse(Phi_{k+1})."""
+    import torch
+    rng = np.random.default_rng(31)
+    N, steps, n, p = 90, 5, 6, 2
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10, 10, 10, 1, 1, 1]
+    R = np.tile(np.diag([1e-2, 1e-2]), (N, 1, 1))
+    Phi, Ht, real, comp = _nl_models(N, n, p, steps, rng)
+    b = ga.FilterBatch(kind, n, p, 0, N)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+    for t in range(steps):
+        b.prepare(Phi[t], Ht[t]); b.update_nl(real[t], comp[t])
+    phis = torch.from_numpy(np.ascontiguousarray(Phi.reshape(steps, N, n * n).transpose(0, 2, 1))).cuda()   # [steps][n*n][N]
+    xs = torch.zeros(steps, n, N, dtype=torch.float64, device="cuda"); Ps = torch.zeros(steps, n * n, N, dtype=torch.float64, device="cuda")
+    k.check(k.lib().kb_smooth_all_dev(b._h, phis.data_ptr(), N, steps, xs.data_ptr(), Ps.data_ptr()))
+    b.synchronize()
+    xs_h = xs.cpu().numpy().transpose(2, 0, 1); Ps_h = Ps.cpu().numpy().transpose(2, 0, 1).reshape(N, steps, n, n)
+    x_last, P_last = b.get(k.STATE), b.get(k.COVAR)
+    for i in range(0, N, 7):
+        rc, xo, Po = orc.smooth_all(Phi[:, i], x_last[i], P_last[i])
+        assert rc == orc.OK
+        assert synth.rel_frobenius(xs_h[i], xo) <= 1e-9 and synth.rel_frobenius(Ps_h[i].reshape(steps, -1), Po.reshape(steps, -1)) <= 1e-9
+    assert not b.status().any()
+    with pytest.raises(ga.KalmanError, match="incorrect number of estimates provided: 3 instead of expected 5"):
+        k.check(k.lib().kb_smooth_all_dev(b._h, phis.data_ptr(), N, 3, xs.data_ptr(), Ps.data_ptr()))
