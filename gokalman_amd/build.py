@@ -41,7 +41,7 @@ def _compile(src, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
             and os.path.getmtime(obj) > _deps_mtime()):
         return obj
-    cmd = [_hipcc()] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA.get(os.path.basename(src), []) + os.environ.get("KB_EXTRA_DEFS", "").split() + ["-c", src, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))

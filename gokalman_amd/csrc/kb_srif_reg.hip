@@ -268,10 +268,12 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
     for (int j = 0; j < NS; j++) {
         T best = T(-1);
         int p = j;
-#pragma unroll 1
-        for (int r = j; r < NS; r++) {
+#pragma unroll
+        for (int r = j; r < NS; r++) {  // all reads issue back to back (static nibble positions), then a select chain
             const T v = fabs(lu.get(nib(perm, r), j));
-            if (v > best) { best = v; p = r; }
+            const bool g = v > best;
+            best = g ? v : best;
+            p = g ? r : p;
         }
         const uint64_t vj = (perm >> (4 * j)) & 15u, vp = (perm >> (4 * p)) & 15u, x = vj ^ vp;
         perm ^= (x << (4 * j)) | (x << (4 * p));
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
         for (int c = j; c < NS; c++) prow[c] = lu.get(pj, c);
         if (prow[j] == T(0)) err |= KB_ST_SINGULAR;
         const T rp = T(1) / prow[j];
-#pragma unroll 1
+#pragma unroll
         for (int r = j + 1; r < NS; r++) {
             const int pr = nib(perm, r);
             const T l = lu.get(pr, j) * rp;
@@ -295,46 +297,79 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
 #pragma unroll
     for (int r = 0; r < NS; r++) xBarP[r] = ltmp[nib(perm, r) * KB_TILE];
     T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
-    T bBar[NS];
-#pragma unroll 1
-    for (int i = 0; i < NS; i++) {
-        T z[NS];
+    // RBar = R Phi^-1 row by row, RG rows at a time so that every LU element read from LDS serves RG
+    // right-hand sides; the next group's rows of R are prefetched while the current group is solved.
+    constexpr int RG = (NS % 4 == 0) ? 4 : ((NS % 3 == 0) ? 3 : 1);
+    int prow[NS];  // physical row of logical row r
 #pragma unroll
-        for (int l = 0; l < NS; l++) z[l] = sl(st, NS + i * NS + l);  // row i of R again: cache hit
+    for (int r = 0; r < NS; r++) prow[r] = nib(perm, r);
+    T znext[RG][NS];
+#pragma unroll
+    for (int g = 0; g < RG; g++)
+#pragma unroll
+        for (int l = 0; l < NS; l++) znext[g][l] = sl(st, NS + g * NS + l);  // rows of R again: cache hits
+#pragma unroll 1
+    for (int i0 = 0; i0 < NS; i0 += RG) {
+        T z[RG][NS];
+#pragma unroll
+        for (int g = 0; g < RG; g++)
+#pragma unroll
+            for (int l = 0; l < NS; l++) z[g][l] = znext[g][l];
+        if (i0 + RG < NS) {
+#pragma unroll
+            for (int g = 0; g < RG; g++)
+#pragma unroll
+                for (int l = 0; l < NS; l++) znext[g][l] = sl(st, NS + (i0 + RG + g) * NS + l);
+        }
         // z Phi = r  with  P Phi = L U:  w U = r,  v L = w,  z[perm_r] = v_r   (srif.go:115)
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            const int pj = nib(perm, j);
-            T s = z[j];
+            T s[RG];
 #pragma unroll
-            for (int k2 = 0; k2 < j; k2++) s -= z[k2] * lu.get(nib(perm, k2), j);
-            z[j] = s / lu.get(pj, j);
+            for (int g = 0; g < RG; g++) s[g] = z[g][j];
+#pragma unroll
+            for (int k2 = 0; k2 < j; k2++) {
+                const T u = lu.get(prow[k2], j);
+#pragma unroll
+                for (int g = 0; g < RG; g++) s[g] -= z[g][k2] * u;
+            }
+            const T d = lu.get(prow[j], j);
+#pragma unroll
+            for (int g = 0; g < RG; g++) z[g][j] = s[g] / d;
         }
 #pragma unroll
         for (int j = NS - 1; j >= 0; j--) {
-            T s = z[j];
+            T s[RG];
 #pragma unroll
-            for (int k2 = j + 1; k2 < NS; k2++) s -= z[k2] * lu.get(nib(perm, k2), j);
-            z[j] = s;
-        }
-        T bb = T(0);
+            for (int g = 0; g < RG; g++) s[g] = z[g][j];
 #pragma unroll
-        for (int r = 0; r < NS; r++) {
-            bb += z[r] * xBarP[r];                 // :119 bBar = RBar xBar (same products, pivoted order)
-            ltmp[nib(perm, r) * KB_TILE] = z[r];   // un-permute through the spare slots
-        }
-        bBar[0] = bb;  // placeholder, real store below (keeps bBar out of a dynamically indexed array)
-        if (active) {
+            for (int k2 = j + 1; k2 < NS; k2++) {
+                const T l = lu.get(prow[k2], j);
 #pragma unroll
-            for (int c = 0; c < NS; c++) {
-                const T v = ltmp[c * KB_TILE];
-                ss(st, NS + i * NS + c, v);
-                if constexpr (FULL) ss(es, a.L.es_ppred + i * NS + c, v);
+                for (int g = 0; g < RG; g++) s[g] -= z[g][k2] * l;
             }
-            ss(st, i, bb);  // b <- bBar, row by row: row i of R and b_i are not read again
+#pragma unroll
+            for (int g = 0; g < RG; g++) z[g][j] = s[g];
+        }
+#pragma unroll
+        for (int g = 0; g < RG; g++) {
+            T bb = T(0);
+#pragma unroll
+            for (int r = 0; r < NS; r++) {
+                bb += z[g][r] * xBarP[r];             // :119 bBar = RBar xBar (same products, pivoted order)
+                ltmp[prow[r] * KB_TILE] = z[g][r];    // un-permute through the spare slots
+            }
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    const T v = ltmp[c * KB_TILE];
+                    ss(st, NS + (i0 + g) * NS + c, v);
+                    if constexpr (FULL) ss(es, a.L.es_ppred + (i0 + g) * NS + c, v);
+                }
+                ss(st, i0 + g, bb);  // b <- bBar: rows i0.. of R and their b entries are not read again
+            }
         }
     }
-    (void)bBar;
 }
 
 // ---- measurement update (srif.go:143-156, :298-340): Householder on [[RBar bBar],[L Htilde, L y]] --
