@@ -25,13 +25,13 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 static bool is_ldkf(int k) { return k == KB_VANILLA || k == KB_VANILLA_PREDICT || k == KB_SQUAREROOT || k == KB_INFORMATION; }
-static bool is_nldkf(int k) { return k == KB_SRIF || k == KB_HYBRID; }
+static bool is_nldkf(int k) { return k == KB_SRIF || k == KB_HYBRID || k == KB_BATCH_LS; }
 
 static Layout make_layout(int kind, int n, int pmax, int m, unsigned flags) {
     Layout L;
     L.n = n; L.pmax = pmax; L.m = m;
     L.st_vec = 0; L.st_mat = n;
-    L.st_mat_full = (kind == KB_SRIF);
+    L.st_mat_full = (kind == KB_SRIF || kind == KB_BATCH_LS);
     L.st_elems = n + (L.st_mat_full ? n * n : tri(n));
     int o = 0;
     L.es_ppred = o; o += L.st_mat_full ? n * n : tri(n);
@@ -214,7 +214,7 @@ int kb_device_count(void) {
 int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, int dtype, int device, unsigned flags) {
     if (!out) { set_error("out is NULL"); return KB_ERR_INVALID; }
     *out = nullptr;
-    if (kind < KB_VANILLA || kind > KB_HYBRID) { set_error("unknown filter kind %d", kind); return KB_ERR_INVALID; }
+    if (kind < KB_VANILLA || kind > KB_BATCH_LS) { set_error("unknown filter kind %d", kind); return KB_ERR_INVALID; }
     if (n < 1 || n > KB_MAX_DIM || p < 1 || p > KB_MAX_DIM || m < 0 || m > KB_MAX_DIM) {
         set_error("dimensions out of range: n=%d p=%d m=%d (1..%d)", n, p, m, KB_MAX_DIM);
         return KB_ERR_DIMS;
@@ -350,6 +350,7 @@ int kb_init(kb_batch *b) {
     const char *names[] = {"x0", "P0", "F", "G", "H", "Q", "R"};
     for (int f = KB_X; f <= KB_R; f++) {
         bool required = (f == KB_X || f == KB_P || f == KB_R);
+        if (b->kind == KB_BATCH_LS) required = (f == KB_R);  // NewBatchKF(numMeasurements, noise): Lambda, N start at zero
         if (need_fh && (f == KB_F || f == KB_H || f == KB_Q)) required = true;
         if (required && !b->have[f]) { set_error("kb_init: %s has not been set", names[f]); return KB_ERR_INVALID; }
     }
@@ -477,7 +478,7 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
     int16_t map[KB_MAX_DIM * KB_MAX_DIM];
     const void *block = nullptr; int block_elems = 0, out_elems = 0;
     const bool full = (b->flags & KB_FLAG_FULL_ESTIMATE) != 0;
-    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF);
+    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS);
     auto need_full = [&]() -> int {
         if (!full) { set_error("field %d needs a batch created with KB_FLAG_FULL_ESTIMATE", field); return KB_ERR_INVALID; }
         return KB_OK;
@@ -485,7 +486,7 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
     void *tmp = nullptr;
     switch (field) {
     case KB_X: case KB_RAW_VEC: case KB_STATE:
-        if (field == KB_STATE && (b->kind == KB_INFORMATION || b->kind == KB_SRIF)) {
+        if (field == KB_STATE && (b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS)) {
             KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
             if ((rc = launch_materialise(*b, b->d_state, false, tmp))) { (void)hipFree(tmp); return rc; }
             block = tmp; block_elems = n + tri(n); out_elems = n; map_dense(1, n, 0, n, map);
@@ -605,7 +606,7 @@ int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first
     const int n = b->n;
     void *tmp = nullptr;
     const void *xp = b->d_state;
-    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF);
+    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS);
     if (lazy) {
         KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
         if ((rc = launch_materialise(*b, b->d_state, false, tmp))) { (void)hipFree(tmp); return rc; }

@@ -14,11 +14,12 @@ namespace kb {
 static int ready_nl(kb_batch *b) {
     if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
     if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
-    if (b->kind != KB_SRIF && b->kind != KB_HYBRID) { set_error("not an NLDKF batch (SRIF / Hybrid)"); return KB_ERR_INVALID; }
+    if (b->kind != KB_SRIF && b->kind != KB_HYBRID && b->kind != KB_BATCH_LS) { set_error("not an NLDKF batch (SRIF / Hybrid / BatchKF)"); return KB_ERR_INVALID; }
     return use_device(*b);
 }
 
 static int launch_nl(kb_batch *b, const StepArgs &a) {
+    if (b->kind == KB_BATCH_LS) return launch_batch_ls(*b, a);
     return b->kind == KB_SRIF ? launch_srif(*b, a) : launch_hybrid(*b, a);
 }
 
@@ -68,7 +69,7 @@ static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
     a.predict = predict ? 1 : 0;
     if (b->ext_phi) {
         a.ext_phi = b->ext_phi; a.ext_h = b->ext_h; a.ext_ld = b->ext_ld;
-        const bool reg = b->kind == KB_SRIF ? srif_reg_ok(*b, a) : hybrid_reg_ok(*b, a);
+        const bool reg = b->kind == KB_SRIF ? srif_reg_ok(*b, a) : (b->kind == KB_HYBRID ? hybrid_reg_ok(*b, a) : false);
         if (!reg) {  // generic kernel: materialise the model block first
             if ((rc = kb_set_dev(b, KB_F, b->ext_phi, b->ext_ld, 0))) return rc;
             if ((rc = kb_set_dev(b, KB_H, b->ext_h, b->ext_ld, b->pmax))) return rc;
@@ -124,6 +125,7 @@ int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs
 int kb_predict_nl(kb_batch *b) {
     int rc = ready_nl(b);
     if (rc) return rc;
+    if (b->kind == KB_BATCH_LS) { set_error("BatchKF has no Predict()"); return KB_ERR_UNSUPPORTED; }
     StepArgs a;
     fill_step_args(*b, a);
     if ((rc = nl_common(b, a, true))) return rc;

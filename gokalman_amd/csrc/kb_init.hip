@@ -243,6 +243,24 @@ __global__ void __launch_bounds__(64) materialise_kernel(const void *src_, int s
             for (int j = 0; j < n; j++) s += W[i * LD + j] * v[j];
             x[i] = s;
         }
+    } else if (kind == KB_BATCH_LS) {  // batch.go:64-79 Solve: P0 = AsSymDense(inverse(Lambda)), xHat0 = P0 N
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) M[i * LD + j] = ldg_t(src, mat_off + i * n + j);
+        bool bad = inverse_lu_rt<T, LD>(n, M, W);
+        bool sym = true;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++)
+                if (i != j) sym = sym && sym_close(W[j * LD + i], W[i * LD + j]);
+        if (bad) atomicOr(status + fi, (unsigned)KB_ST_SINGULAR);
+        else if (!sym) atomicOr(status + fi, (unsigned)KB_ST_ASYMMETRIC);
+        bad = bad || !sym;
+        for (int i = 0; i < n; i++)
+            for (int j = i; j < n; j++) { const T val = bad ? T(0) : W[i * LD + j]; W[i * LD + j] = val; W[j * LD + i] = val; }
+        for (int i = 0; i < n; i++) {
+            T s = T(0);
+            for (int j = 0; j < n; j++) s += W[i * LD + j] * v[j];
+            x[i] = s;
+        }
     } else {  // KB_SRIF: x = R^-1 b, P = R^-1 R^-T (srif.go:223-281)
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) M[i * LD + j] = ldg_t(src, mat_off + i * n + j);

@@ -122,6 +122,7 @@ int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)
 int launch_srif(const Batch &b, const StepArgs &a);
 int launch_hybrid(const Batch &b, const StepArgs &a);
+int launch_batch_ls(const Batch &b, const StepArgs &a);
 bool hybrid_reg_ok(const Batch &b, const StepArgs &a);
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums);

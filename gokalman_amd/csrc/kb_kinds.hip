@@ -517,6 +517,40 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
 }
 
 // =====================================================================================
+// BatchKF normal equations (batch.go:41-61 SetNextMeasurement): Lambda += H^T R H, N += H^T R (real - computed)
+// QUIRK: the weight is the measurement noise matrix R itself, not its inverse.
+// =====================================================================================
+template <typename T, int LD>
+__global__ void __launch_bounds__(64) batch_ls_gen_kernel(const StepArgs a) {
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t fi = tile * KB_TILE + lane;
+    if (fi >= a.N) return;
+    const int n = a.n, p = a.p;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * a.L.st_elems) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
+    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
+    T H[LD * LD], R[LD * LD], HtR[LD * LD], y[LD];
+    for (int r = 0; r < p; r++) {
+        for (int j = 0; j < n; j++) H[r * LD + j] = ldk(mo, a.L.mo_H + r * n + j);
+        for (int c = 0; c < p; c++) R[r * LD + c] = ldk(mo, a.L.mo_R + symi(r, c));
+        y[r] = yr[(int64_t)r * a.y_es] - yc[(int64_t)r * a.y2_es];
+    }
+    mm_tn<T, LD, LD, LD>(n, p, p, H, R, HtR);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            T s = T(0);
+            for (int l = 0; l < p; l++) s += HtR[i * LD + l] * H[l * LD + j];
+            stk(st, a.L.st_mat + i * n + j, ldk(st, a.L.st_mat + i * n + j) + s);
+        }
+        T s = T(0);
+        for (int l = 0; l < p; l++) s += HtR[i * LD + l] * y[l];
+        stk(st, a.L.st_vec + i, ldk(st, a.L.st_vec + i) + s);
+    }
+}
+
+// =====================================================================================
 // dispatch
 // =====================================================================================
 #define KB_DISPATCH_GEN(KERNEL)                                                                              \
@@ -539,5 +573,6 @@ int launch_squareroot_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(s
 int launch_information_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(information_gen_kernel); return KB_OK; }
 int launch_srif_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(srif_gen_kernel); return KB_OK; }
 int launch_hybrid_gen(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(hybrid_gen_kernel); return KB_OK; }
+int launch_batch_ls(const Batch &b, const StepArgs &a) { KB_DISPATCH_GEN(batch_ls_gen_kernel); return KB_OK; }
 
 }  // namespace kb

@@ -53,7 +53,10 @@ typedef enum {
     KB_SQUAREROOT = 3,      /* NewSquareRoot            squareroot.go:21-50   */
     KB_INFORMATION = 4,     /* NewInformation / NewInformationFromState information.go:20-81 */
     KB_SRIF = 5,            /* NewSRIF                  srif.go:14-49         */
-    KB_HYBRID = 6           /* NewHybridKF              hybrid.go:23-34       */
+    KB_HYBRID = 6,          /* NewHybridKF              hybrid.go:23-34       */
+    KB_BATCH_LS = 7         /* NewBatchKF (batch least squares) batch.go:34-38: kb_set(KB_R), kb_init, then per
+                             * measurement kb_prepare(Phi, H) + kb_update_nl(real, computed) = SetNextMeasurement (batch.go:41-61);
+                             * kb_get(KB_STATE / KB_COVAR) = Solve() (batch.go:64-79); KB_RAW_VEC / KB_RAW_MAT = N / Lambda */
 } kb_kind;
 
 typedef enum { KB_F64 = 0, KB_F32 = 1 } kb_dtype;

@@ -484,6 +484,16 @@ orc_filter *orc_new_hybrid(int n, int p, const double *x0, const double *P0,
     return f;
 }
 
+/* batch.go:34-38 NewBatchKF */
+orc_filter *orc_new_batch_ls(int n, int p, const double *R) {
+    if (n < 1 || n > ORC_MAXN || p < 1 || p > ORC_MAXN) return NULL;
+    orc_filter *f = (orc_filter *)calloc(1, sizeof(*f));
+    f->kind = ORC_BATCH_LS; f->n = n; f->p = p; f->est_p = p;
+    sym_from_upper(p, R, f->R);
+    f->locked = 1;
+    return f;
+}
+
 void orc_free(orc_filter *f) { free(f); }
 int orc_step(const orc_filter *f) { return f->step; }
 
@@ -916,7 +926,23 @@ static int hybrid_full_update(orc_filter *f, int pure, const double *real_obs, c
     return ORC_OK;
 }
 
+/* batch.go:41-61 SetNextMeasurement: Lambda += H^T R H, N += H^T R (real - computed).
+ * QUIRK: the weight is the measurement noise matrix R itself, not its inverse. */
+static int batch_ls_add(orc_filter *f, const double *real_obs, const double *computed) {
+    const int n = f->n, p = f->p;
+    double HtR[NN], HtRH[NN], y[ORC_MAXN], t[ORC_MAXN];
+    mm_tn(n, p, p, f->Htilde, f->R, HtR);
+    mm(n, p, n, HtR, f->Htilde, HtRH);
+    for (int i = 0; i < n * n; i++) f->M[i] = f->M[i] + HtRH[i];
+    for (int i = 0; i < p; i++) y[i] = real_obs[i] - computed[i];
+    mv(n, p, HtR, y, t);
+    for (int i = 0; i < n; i++) f->x[i] = f->x[i] + t[i];
+    f->step++;
+    return ORC_OK;
+}
+
 int orc_update_nl(orc_filter *f, const double *real_obs, const double *computed_obs) {
+    if (f->kind == ORC_BATCH_LS) return batch_ls_add(f, real_obs, computed_obs);
     if (f->kind == ORC_SRIF) return srif_full_update(f, 0, real_obs, computed_obs);
     if (f->kind == ORC_HYBRID) return hybrid_full_update(f, 0, real_obs, computed_obs);
     return ORC_ERR_DIMS;
@@ -944,6 +970,13 @@ int orc_get(orc_filter *f, int what, double *out) {
     double t[NN];
     switch (what) {
     case ORC_GET_STATE:
+        if (f->kind == ORC_BATCH_LS) { /* batch.go:64-79 Solve: P0 = AsSymDense(inverse(Lambda)), xHat0 = P0 N */
+            double Li[NN], P0[NN];
+            if (orc_inverse(n, f->M, Li, NULL) != 0) return ORC_ERR_SINGULAR;
+            if (orc_as_sym_dense(n, Li, P0) != ORC_OK) return ORC_ERR_ASYMMETRIC;
+            mv(n, n, P0, f->x, out);
+            return ORC_OK;
+        }
         if (f->kind == ORC_INFORMATION) {
             double P[NN];
             info_covariance(n, f->M, P);
@@ -957,6 +990,11 @@ int orc_get(orc_filter *f, int what, double *out) {
     case ORC_GET_COVAR:
     case ORC_GET_PRED_COVAR: {
         const double *Msrc = (what == ORC_GET_COVAR) ? f->M : f->Mpred;
+        if (f->kind == ORC_BATCH_LS) {
+            double Li[NN];
+            if (orc_inverse(n, f->M, Li, NULL) != 0) return ORC_ERR_SINGULAR;
+            return orc_as_sym_dense(n, Li, out);
+        }
         if (f->kind == ORC_SQUAREROOT) {          /* squareroot.go:317-340 */
             mm_nt(n, n, n, Msrc, Msrc, t);
             sym_from_upper(n, t, out);

@@ -45,7 +45,8 @@ enum {
     ORC_SQUAREROOT = 3,        /* squareroot.go:21                              */
     ORC_INFORMATION = 4,       /* information.go:20,65                          */
     ORC_SRIF = 5,              /* srif.go:14                                    */
-    ORC_HYBRID = 6             /* hybrid.go:23                                  */
+    ORC_HYBRID = 6,            /* hybrid.go:23                                  */
+    ORC_BATCH_LS = 7           /* batch.go:34  NewBatchKF (batch least squares)  */
 };
 
 /* return codes of orc_update & friends (the reference's `error` / panic sites) */
@@ -101,6 +102,9 @@ orc_filter *orc_new_srif(int n, int p, const double *x0, const double *P0,
                          const double *R, int non_tri_r);
 orc_filter *orc_new_hybrid(int n, int p, const double *x0, const double *P0,
                            int nq, const double *Q, const double *R);
+/* NewBatchKF (batch.go:34-38): normal-equation accumulator; orc_update_nl = SetNextMeasurement
+ * (:41-61) with the H given to orc_prepare, ORC_GET_STATE / ORC_GET_COVAR = Solve() (:64-79). */
+orc_filter *orc_new_batch_ls(int n, int p, const double *R);
 void orc_free(orc_filter *f);
 
 /* LDKF setters (Set* in vanilla.go:96-118, squareroot.go:85-114, information.go:117-138) */

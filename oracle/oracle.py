@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libgokalman_oracle.so")
 _SRC = [os.path.join(_HERE, "gokalman_oracle.c"), os.path.join(_HERE, "gokalman_oracle.h")]
 
-VANILLA, VANILLA_PREDICT, SQUAREROOT, INFORMATION, SRIF, HYBRID = 1, 2, 3, 4, 5, 6
+VANILLA, VANILLA_PREDICT, SQUAREROOT, INFORMATION, SRIF, HYBRID, BATCH_LS = 1, 2, 3, 4, 5, 6, 7
 OK, ERR_SINGULAR, ERR_ASYMMETRIC, ERR_LOCKED, ERR_DIMS, ERR_NOTPD = 0, 1, 2, 3, 4, 5
 (GET_STATE, GET_COVAR, GET_PRED_COVAR, GET_GAIN, GET_INNOV, GET_MEAS,
  GET_RAW_VEC, GET_RAW_MAT, GET_RAW_PRED_MAT) = range(9)
@@ -47,6 +47,8 @@ def lib():
         L.orc_new_srif.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
         L.orc_new_hybrid.restype = vp
         L.orc_new_hybrid.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        L.orc_new_batch_ls.restype = vp
+        L.orc_new_batch_ls.argtypes = [C.c_int, C.c_int, _dp]
         L.orc_free.argtypes = [vp]
         L.orc_set_state_transition.argtypes = [vp, _dp]
         L.orc_set_input_control.argtypes = [vp, C.c_int, _dp]
@@ -139,6 +141,11 @@ class Filter:
         keep = [_a(v) for v in (x0, P0, Q, R)]
         h = lib().orc_new_hybrid(n, p, keep[0][1], keep[1][1], nq, keep[2][1], keep[3][1])
         return cls(h, HYBRID, n, p)
+
+    @classmethod
+    def batch_ls(cls, n, p, R):
+        keep = _a(R)
+        return cls(lib().orc_new_batch_ls(n, p, keep[1]), BATCH_LS, n, p)
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

@@ -350,3 +350,31 @@ def test_smooth_all_backward_sweep_vs_oracle(kind):
     assert not b.status().any()
     with pytest.raises(ga.KalmanError, match="incorrect number of estimates provided: 3 instead of expected 5"):
         k.check(k.lib().kb_smooth_all_dev(b._h, phis.data_ptr(), N, 3, xs.data_ptr(), Ps.data_ptr()))
+
+
+def test_batch_least_squares_normal_equations_vs_oracle():
+    """BatchKF (batch.go:34-79): SetNextMeasurement accumulates Lambda += H^T R H, N += H^T R y (R, not R^-1:
+    reference quirk); Solve() = (sym(Lambda^-1) N, sym(Lambda^-1))."""
+    rng = np.random.default_rng(41)
+    N, n, p, nmeas = 150, 6, 2, 9
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = rng.uniform(0.1, 1.0, size=(N, p))
+    Hs = rng.standard_normal((nmeas, N, p, n)); real = rng.standard_normal((nmeas, N, p)); comp = rng.standard_normal((nmeas, N, p))
+    b = ga.FilterBatch(k.BATCH_LS, n, p, 0, N)
+    b.set(k.R, R, 2, p_rows=p); b.init()
+    for t in range(nmeas):
+        b.prepare(np.tile(np.eye(n), (N, 1, 1)), Hs[t]); b.update_nl(real[t], comp[t])
+    xs, Ps = [], []
+    for i in range(N):
+        f = orc.Filter.batch_ls(n, p, R[i])
+        for t in range(nmeas):
+            f.prepare(np.eye(n), Hs[t, i]); assert f.update_nl(real[t, i], comp[t, i]) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+    assert synth.rel_frobenius(b.get(k.STATE), np.array(xs)) <= 1e-9
+    assert synth.rel_frobenius(b.get(k.COVAR), np.array(Ps)) <= 1e-9
+    assert b.step() == nmeas and not b.status().any()
+    # too few measurements: Lambda singular -> Solve() errors in the reference, a status bit here
+    c = ga.FilterBatch(k.BATCH_LS, n, p, 0, 8)
+    c.set(k.R, R[0], 2, p_rows=p); c.init()
+    c.prepare(np.eye(n), Hs[0, 0]); c.update_nl(real[0, 0], comp[0, 0])
+    c.get(k.COVAR)
+    assert (c.status() & k.ST_SINGULAR).all()
