@@ -13,7 +13,7 @@
 
 namespace kb {
 #ifndef SQRT_WAVES
-#define SQRT_WAVES 2
+#define SQRT_WAVES 1
 #endif
 
 template <typename T>

@@ -55,32 +55,32 @@ __device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
     constexpr int KMAX = M < N ? M : N;
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
-        T tau = T(0);
         T xnorm2 = T(0);
 #pragma unroll
         for (int r = i + 1; r < M; r++)
             if (ACT::active(i, r)) xnorm2 += a[r * N + i] * a[r * N + i];
-        const T xnorm = sqrt(xnorm2);
-        const bool refl = (M - i > 1) && (xnorm != T(0));
+        // Dlarfg: beta = -sign(alpha) * dlapy2(alpha, xnorm).  dlapy2 only guards against overflow of the squares;
+        // the panels here are covariance square roots, so the plain sqrt of the sum is used (one rounding apart).
+        // The reflector is applied in its unnormalised form H = I + f u u^T, u = (alpha - beta, x),
+        // f = 1 / (beta (alpha - beta)): the same matrix as LAPACK's I - tau v v^T (v = u / u0,
+        // tau = (beta - alpha) / beta) with one division per column instead of two and no scaling pass.
+        const bool refl = (M - i > 1) && (xnorm2 != T(0));
         const T alpha = a[i * N + i];
-        const T beta = -copysign(hypot(alpha, xnorm), alpha);
-        tau = refl ? (beta - alpha) / beta : T(0);
-        const T sc = refl ? T(1) / (alpha - beta) : T(0);
-#pragma unroll
-        for (int r = i + 1; r < M; r++)
-            if (ACT::active(i, r)) a[r * N + i] *= sc;   // v (zero when no reflection: the update below is then a no-op)
+        const T beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+        const T u0 = alpha - beta;
+        const T f = refl ? T(1) / (beta * u0) : T(0);
         a[i * N + i] = refl ? beta : alpha;
 #pragma unroll
         for (int c = i + 1; c < N; c++) {
-            T w = a[i * N + c];
+            T s = u0 * a[i * N + c];
 #pragma unroll
             for (int r = i + 1; r < M; r++)
-                if (ACT::active(i, r)) w += a[r * N + i] * a[r * N + c];
-            const T tw = tau * w;
-            a[i * N + c] -= tw;
+                if (ACT::active(i, r)) s += a[r * N + i] * a[r * N + c];
+            const T fs = f * s;
+            a[i * N + c] += fs * u0;
 #pragma unroll
             for (int r = i + 1; r < M; r++)
-                if (ACT::active(i, r)) a[r * N + c] -= tw * a[r * N + i];
+                if (ACT::active(i, r)) a[r * N + c] += fs * a[r * N + i];
         }
     }
 }
