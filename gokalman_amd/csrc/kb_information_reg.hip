@@ -65,14 +65,22 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
         for (int i = 0; i < NS; i++) s += Fi[i * NS + j] * iv[i];
         im[j] = s;
     }
-    // :169-174 Z = -zk (zk + Qinv)^-1   (inverse error ignored by the reference)
-    T zq[NS * NS], zqi[NS * NS], Z[NS * NS];
+    // :169-174 Z = -zk (zk + Qinv)^-1 (inverse error ignored by the reference).  Obtained as an in-place
+    // pivoted LU solve of (zk + Qinv)^T X = zk^T (X = (zk (zk + Qinv)^-1)^T) instead of inverse-then-multiply:
+    // two 6x6 work arrays instead of four (the explicit inverse kept the kernel at 1 wave/SIMD).
+    T zqT[NS * NS], X[NS * NS], Z[NS * NS];
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) zq[e] = zk[e] + intl(mo, a.L.mo_Qinv + e);
-    inverse_lu<T, NS>(zq, zqi);
-    smm_nn<T, NS, NS, NS>(zk, zqi, Z);
+    for (int i = 0; i < NS; i++)
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) Z[e] = T(-1) * Z[e];
+        for (int j = 0; j < NS; j++) {
+            zqT[j * NS + i] = zk[i * NS + j] + intl(mo, a.L.mo_Qinv + i * NS + j);
+            X[j * NS + i] = zk[i * NS + j];
+        }
+    lu_solve_inplace<T, NS, NS>(zqT, X);
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) Z[i * NS + j] = T(-1) * X[j * NS + i];
     // :183-185 i- = (1 + Z) i-
     T imn[NS];
 #pragma unroll

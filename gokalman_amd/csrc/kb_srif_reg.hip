@@ -27,55 +27,6 @@ __device__ __forceinline__ T snt(const T *p, int e) { return __builtin_nontempor
 template <typename T>
 __device__ __forceinline__ void ss(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
-// Gaussian elimination with partial pivoting on registers, right-hand sides solved in place.
-// a[P*P] is destroyed, b[P*C] becomes a^-1 b.  Returns true on an exact zero pivot.
-template <typename T, int P, int C>
-__device__ __forceinline__ bool lu_solve_inplace(T (&a)[P * P], T (&b)[P * C]) {
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-#pragma unroll
-        for (int r = j + 1; r < P; r++) {
-            const bool sw = fabs(a[r * P + j]) > fabs(a[j * P + j]);
-#pragma unroll
-            for (int c = j; c < P; c++) {
-                const T t0 = a[j * P + c], t1 = a[r * P + c];
-                a[j * P + c] = sw ? t1 : t0;
-                a[r * P + c] = sw ? t0 : t1;
-            }
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const T u0 = b[j * C + c], u1 = b[r * C + c];
-                b[j * C + c] = sw ? u1 : u0;
-                b[r * C + c] = sw ? u0 : u1;
-            }
-        }
-        const T piv = a[j * P + j];
-        bad = bad || (piv == T(0));
-        const T rp = T(1) / piv;
-#pragma unroll
-        for (int r = j + 1; r < P; r++) {
-            const T l = a[r * P + j] * rp;
-#pragma unroll
-            for (int c = j + 1; c < P; c++) a[r * P + c] -= l * a[j * P + c];
-#pragma unroll
-            for (int c = 0; c < C; c++) b[r * C + c] -= l * b[j * C + c];
-        }
-    }
-#pragma unroll
-    for (int i = P - 1; i >= 0; i--) {
-        const T rd = T(1) / a[i * P + i];
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            T s = b[i * C + c];
-#pragma unroll
-            for (int k = i + 1; k < P; k++) s -= a[i * P + k] * b[k * C + c];
-            b[i * C + c] = s * rd;
-        }
-    }
-    return bad;
-}
-
 // LU factorisation with partial pivoting in place (unit-lower L below the diagonal, U on and
 // above), recording every row exchange as one bit (exchange index = position in the (j, r) loop
 // nest) so that later right-hand sides can be permuted without keeping a permutation matrix.
