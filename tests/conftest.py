@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The suites bind the in-tree C-ABI library: build it (hipcc, gfx950 cross-compile works without a GPU)
+    and the C oracle (gcc) when they are missing or stale, exactly as __graft_entry__.build() does."""
+    from gokalman_amd import build as kb_build
+    from oracle import oracle as orc
+    kb_build.build()
+    orc.build()
+
+
 def _has_gpu():
     try:
         import torch
