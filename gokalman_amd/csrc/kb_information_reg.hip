@@ -19,7 +19,7 @@ __device__ __forceinline__ T intl(const T *p, int e) { return __builtin_nontempo
 template <typename T>
 __device__ __forceinline__ void is(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
-template <typename T, int NS, int NM>
+template <typename T, int NS, int NM, int NC, bool SCALAR_RINV>
 __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     const int lane = threadIdx.x & 63;
@@ -81,6 +81,24 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) Z[i * NS + j] = T(-1) * X[j * NS + i];
+    if constexpr (NC > 0) {  // :178-182 i- += zk (G u)
+        const T *up = (const T *)a.u + tile * a.u_ts + lane;
+        T gu[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NC; c++) s += intl(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+            gu[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int j = 0; j < NS; j++) s += zk[i * NS + j] * gu[j];
+            im[i] = im[i] + s;
+        }
+    }
     // :183-185 i- = (1 + Z) i-
     T imn[NS];
 #pragma unroll
@@ -102,20 +120,29 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
             Im[symi(i, j)] = zk[i * NS + j] + s;
         }
     // :197-212 HTR = H^T Rinv; i+ = HTR y + i-; I+ = I- + HTR H
-    T H[NM * NS], Ri[NM * NM], HTR[NS * NM];
+    T H[NM * NS], HTR[NS * NM];
 #pragma unroll
     for (int e = 0; e < NM * NS; e++) H[e] = intl(mo, a.L.mo_H + e);
+    if constexpr (SCALAR_RINV) {  // QUIRK information.go:198-200: a (stale) 1x1 R^-1 scales H^T whatever p is
+        const T r0 = intl(mo, a.L.mo_Rinv);
 #pragma unroll
-    for (int e = 0; e < NM * NM; e++) Ri[e] = intl(mo, a.L.mo_Rinv + e);
+        for (int i = 0; i < NS; i++)
 #pragma unroll
-    for (int i = 0; i < NS; i++)
+            for (int j = 0; j < NM; j++) HTR[i * NM + j] = r0 * H[j * NS + i];
+    } else {
+        T Ri[NM * NM];
 #pragma unroll
-        for (int j = 0; j < NM; j++) {
-            T s = T(0);
+        for (int e = 0; e < NM * NM; e++) Ri[e] = intl(mo, a.L.mo_Rinv + e);
 #pragma unroll
-            for (int l = 0; l < NM; l++) s += H[l * NS + i] * Ri[l * NM + j];
-            HTR[i * NM + j] = s;
-        }
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NM; j++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NM; l++) s += H[l * NS + i] * Ri[l * NM + j];
+                HTR[i * NM + j] = s;
+            }
+    }
     T chk = T(0);
     T ip[NS], Ip[TR];
 #pragma unroll
@@ -147,18 +174,21 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
 }
 
-template <typename T, int NS, int NM>
+template <typename T, int NS, int NM, int NC = 0>
 static bool info_try(const Batch &b, const StepArgs &a) {
-    if (a.n != NS || a.p != NM || a.rinv_p != NM || a.need_ctrl || a.nsteps != 1 || (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) ||
-        a.noise_kind != KB_NOISE_NOISELESS)
+    if (a.n != NS || a.p != NM || (a.rinv_p != NM && a.rinv_p != 1) || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 ||
+        (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) || a.noise_kind != KB_NOISE_NOISELESS)
         return false;
-    hipLaunchKernelGGL((information_reg_kernel<T, NS, NM>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a);
+    if (a.rinv_p == 1) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, true>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a);
+    else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, false>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a);
     return true;
 }
 
 int launch_information(const Batch &b, const StepArgs &a) {
     bool done = false;
-    if (b.dtype == KB_F64) done = info_try<double, 6, 3>(b, a) || info_try<double, 4, 2>(b, a);
+    if (b.dtype == KB_F64)
+        done = info_try<double, 6, 3>(b, a) || info_try<double, 4, 2>(b, a) ||
+               info_try<double, 4, 1, 1>(b, a) || info_try<double, 4, 2, 1>(b, a);  // examples/jerkcar
     if (!done) return launch_information_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

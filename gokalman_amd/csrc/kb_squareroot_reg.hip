@@ -32,7 +32,7 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
     static constexpr bool active(int k, int r) { return k >= NM || r >= NM; }
 };
 
-template <typename T, int NS, int NM, bool FULL>
+template <typename T, int NS, int NM, int NC, bool FULL>
 __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int lane = threadIdx.x & 63;
@@ -51,9 +51,19 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
 #pragma unroll
     for (int e = 0; e < NS * NS; e++) F[e] = ld_nt(mo, a.L.mo_F + e);
 
-    // :139-147 x- = F x
+    // :139-147 x- = F x [+ G u]
     T xm[NS];
     smv<T, NS, NS>(F, x, xm);
+    if constexpr (NC > 0) {
+        const T *up = (const T *)a.u + tile * a.u_ts + lane;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NC; c++) s += ld_nt(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+            xm[i] = xm[i] + s;
+        }
+    }
     // :155-185 C = [S^T F^T ; sqrtQ^T] -> Uc; QUIRK S- := Uc (upper)
     // Build order bounds the live set: the top block row by row (column i of S dies with row i), then a
     // scheduling barrier, and only then chol(Q) for the bottom block -- F is dead by then.  Without the
@@ -175,18 +185,20 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
 }
 
-template <typename T, int NS, int NM>
+template <typename T, int NS, int NM, int NC = 0>
 static bool sqrt_try(const Batch &b, const StepArgs &a) {
-    if (a.n != NS || a.p != NM || a.sqrt_p != NM || a.need_ctrl || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    if (a.n != NS || a.p != NM || a.sqrt_p != NM || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
     const dim3 grid = tile_grid(a.ntiles), block(256);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, true>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, false>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false>), grid, block, 0, b.stream, a);
     return true;
 }
 
 int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
     bool done = false;
-    if (b.dtype == KB_F64) done = sqrt_try<double, 6, 3>(b, a) || sqrt_try<double, 4, 2>(b, a);
+    if (b.dtype == KB_F64)
+        done = sqrt_try<double, 6, 3>(b, a) || sqrt_try<double, 4, 2>(b, a) ||
+               sqrt_try<double, 4, 1, 1>(b, a) || sqrt_try<double, 4, 2, 1>(b, a);  // examples/jerkcar: 1- and 2-row H, one control
     else done = sqrt_try<float, 6, 3>(b, a);
     if (!done) return launch_squareroot_gen(b, a);
     KB_HIP(hipGetLastError());
