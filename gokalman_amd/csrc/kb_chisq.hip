@@ -21,8 +21,6 @@ namespace kb {
 
 constexpr int CHI_REPL = 32;
 
-template <typename T>
-__device__ __forceinline__ T ldc(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
 
 __device__ __forceinline__ double chi_wave_sum(double v) {
 #pragma unroll
@@ -57,32 +55,32 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
     T xt[NS], Ft[NS * NS], Ht[NM * NS], LQ[TR], LR[TM];
     [[maybe_unused]] T Gt[NC > 0 ? NS * NC : 1], Gk[NC > 0 ? NS * NC : 1];
 #pragma unroll
-    for (int i = 0; i < NS; i++) xt[i] = ldc(ts, a.tL.st_vec + i);
+    for (int i = 0; i < NS; i++) xt[i] = ldt(ts, a.tL.st_vec + i);
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) Ft[e] = ldc(tm, a.tL.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) Ft[e] = ldt(tm, a.tL.mo_F + e);
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) Ht[e] = ldc(tm, a.tL.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) Ht[e] = ldt(tm, a.tL.mo_H + e);
 #pragma unroll
-    for (int e = 0; e < TR; e++) LQ[e] = ldc(tm, a.tL.mo_LQ + e);
+    for (int e = 0; e < TR; e++) LQ[e] = ldt(tm, a.tL.mo_LQ + e);
 #pragma unroll
-    for (int e = 0; e < TM; e++) LR[e] = ldc(tm, a.tL.mo_LR + e);
+    for (int e = 0; e < TM; e++) LR[e] = ldt(tm, a.tL.mo_LR + e);
     // filter
     T x[NS], P[TR], F[NS * NS], H[NM * NS], Q[TR], R[TM];
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = ldc(ks, a.kL.st_vec + i);
+    for (int i = 0; i < NS; i++) x[i] = ldt(ks, a.kL.st_vec + i);
 #pragma unroll
-    for (int e = 0; e < TR; e++) P[e] = ldc(ks, a.kL.st_mat + e);
+    for (int e = 0; e < TR; e++) P[e] = ldt(ks, a.kL.st_mat + e);
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldc(km, a.kL.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) F[e] = ldt(km, a.kL.mo_F + e);
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ldc(km, a.kL.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) H[e] = ldt(km, a.kL.mo_H + e);
 #pragma unroll
-    for (int e = 0; e < TR; e++) Q[e] = ldc(km, a.kL.mo_Q + e);
+    for (int e = 0; e < TR; e++) Q[e] = ldt(km, a.kL.mo_Q + e);
 #pragma unroll
-    for (int e = 0; e < TM; e++) R[e] = ldc(km, a.kL.mo_R + e);
+    for (int e = 0; e < TM; e++) R[e] = ldt(km, a.kL.mo_R + e);
     if constexpr (NC > 0) {
 #pragma unroll
-        for (int e = 0; e < NS * NC; e++) { Gt[e] = ldc(tm, a.tL.mo_G + e); Gk[e] = ldc(km, a.kL.mo_G + e); }
+        for (int e = 0; e < NS * NC; e++) { Gt[e] = ldt(tm, a.tL.mo_G + e); Gk[e] = ldt(km, a.kL.mo_G + e); }
     }
     const uint64_t gfi = (uint64_t)(a.first_run + fi);
     double *my = a.sums + (size_t)(tile % CHI_REPL) * a.nsteps * 2;

@@ -21,6 +21,15 @@ __host__ __device__ constexpr int tri(int n) { return n * (n + 1) / 2; }
 // packed index of symmetric element (i,j), any order of i,j
 __host__ __device__ constexpr int symi(int i, int j) { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
 
+// Tile accessors shared by every kernel: `p` already points at this lane's slot of element 0 of its tile
+// (block + tile*64*elems + lane), element e is 64 values further per step.
+template <typename T>
+__device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
+template <typename T>
+__device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }  // read-once streams
+template <typename T>
+__device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct Eps<float>  { static constexpr float  tiny = 1.17549435e-38f; };

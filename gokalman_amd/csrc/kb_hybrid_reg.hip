@@ -8,12 +8,6 @@
 
 namespace kb {
 
-template <typename T>
-__device__ __forceinline__ T hl(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ T hnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
-template <typename T>
-__device__ __forceinline__ void hs(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT>
 __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
@@ -28,14 +22,14 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
     T x[NS], P[TR], F[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = hl(st, i);
+    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
 #pragma unroll
-    for (int e = 0; e < TR; e++) P[e] = hl(st, NS + e);
+    for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
     const int64_t fi = tile * KB_TILE + lane;
     const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
     const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : hnt(mo, a.L.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) F[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
     // :114-116 PBar = Phi P Phi^T (upper triangle)
     T Pm[TR];
 #pragma unroll
@@ -60,9 +54,9 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
     if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
     T H[NM * NS], R[tri(NM)];
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : hnt(mo, a.L.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
 #pragma unroll
-    for (int e = 0; e < tri(NM); e++) R[e] = hnt(mo, a.L.mo_R + e);
+    for (int e = 0; e < tri(NM); e++) R[e] = ldnt(mo, a.L.mo_R + e);
     // :146-153 K = PBar H^T (H PBar H^T + R)^-1
     T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
 #pragma unroll
@@ -166,19 +160,19 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
     if (chk != chk) err |= KB_ST_NONFINITE;
     if (active && !err) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) hs(st, i, xn[i]);
+        for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
 #pragma unroll
-        for (int e = 0; e < TR; e++) hs(st, NS + e, Pn[e]);
+        for (int e = 0; e < TR; e++) stt(st, NS + e, Pn[e]);
         if constexpr (FULL) {
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll
-            for (int e = 0; e < TR; e++) hs(es, a.L.es_ppred + e, Pm[e]);
+            for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
 #pragma unroll
             for (int i = 0; i < NS; i++)
 #pragma unroll
-                for (int c = 0; c < NM; c++) hs(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
-            for (int r = 0; r < NM; r++) { hs(es, a.L.es_innov + r, innov[r]); hs(es, a.L.es_yhat + r, real[r]); hs(es, a.L.es_dobs + r, yv[r]); }
+            for (int r = 0; r < NM; r++) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, real[r]); stt(es, a.L.es_dobs + r, yv[r]); }
         }
     }
     if (active && err) atomicOr(a.status + tile * KB_TILE + lane, err);

@@ -12,12 +12,6 @@ namespace kb {
 #define INFO_WAVES 1
 #endif
 
-template <typename T>
-__device__ __forceinline__ T il(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ T intl(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
-template <typename T>
-__device__ __forceinline__ void is(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 template <typename T, int NS, int NM, int NC, bool SCALAR_RINV>
 __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const StepArgs a) {
@@ -31,11 +25,11 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
     T iv[NS], I[TR], Fi[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) iv[i] = il(st, i);
+    for (int i = 0; i < NS; i++) iv[i] = ldt(st, i);
 #pragma unroll
-    for (int e = 0; e < TR; e++) I[e] = il(st, NS + e);
+    for (int e = 0; e < TR; e++) I[e] = ldt(st, NS + e);
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) Fi[e] = intl(mo, a.L.mo_Finv + e);
+    for (int e = 0; e < NS * NS; e++) Fi[e] = ldnt(mo, a.L.mo_Finv + e);
     // :163-165 zk = Finv^T (I Finv)
     T t1[NS * NS], zk[NS * NS];
 #pragma unroll
@@ -73,7 +67,7 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            zqT[j * NS + i] = zk[i * NS + j] + intl(mo, a.L.mo_Qinv + i * NS + j);
+            zqT[j * NS + i] = zk[i * NS + j] + ldnt(mo, a.L.mo_Qinv + i * NS + j);
             X[j * NS + i] = zk[i * NS + j];
         }
     lu_solve_inplace<T, NS, NS>(zqT, X);
@@ -88,7 +82,7 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
         for (int i = 0; i < NS; i++) {
             T s = T(0);
 #pragma unroll
-            for (int c = 0; c < NC; c++) s += intl(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+            for (int c = 0; c < NC; c++) s += ldnt(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
             gu[i] = s;
         }
 #pragma unroll
@@ -122,9 +116,9 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     // :197-212 HTR = H^T Rinv; i+ = HTR y + i-; I+ = I- + HTR H
     T H[NM * NS], HTR[NS * NM];
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = intl(mo, a.L.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
     if constexpr (SCALAR_RINV) {  // QUIRK information.go:198-200: a (stale) 1x1 R^-1 scales H^T whatever p is
-        const T r0 = intl(mo, a.L.mo_Rinv);
+        const T r0 = ldnt(mo, a.L.mo_Rinv);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -132,7 +126,7 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     } else {
         T Ri[NM * NM];
 #pragma unroll
-        for (int e = 0; e < NM * NM; e++) Ri[e] = intl(mo, a.L.mo_Rinv + e);
+        for (int e = 0; e < NM * NM; e++) Ri[e] = ldnt(mo, a.L.mo_Rinv + e);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -167,9 +161,9 @@ __global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const 
     const bool ok = !(chk != chk);
     if (active && ok) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) is(st, i, ip[i]);
+        for (int i = 0; i < NS; i++) stt(st, i, ip[i]);
 #pragma unroll
-        for (int e = 0; e < TR; e++) is(st, NS + e, Ip[e]);
+        for (int e = 0; e < TR; e++) stt(st, NS + e, Ip[e]);
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
 }

@@ -22,10 +22,6 @@ enum DeriveOp {
     OP_SRIF_INIT = 8
 };
 
-template <typename T>
-__device__ __forceinline__ T ldg_t(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ void stg_t(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 template <typename T, int LD>
 __global__ void __launch_bounds__(64) derive_kernel(void *state_, void *model_, int64_t N, Layout L, int op, int rp,
@@ -42,82 +38,82 @@ __global__ void __launch_bounds__(64) derive_kernel(void *state_, void *model_, 
     switch (op) {
     case OP_SQRT_P0: {
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) A[i * LD + j] = ldg_t(st, L.st_mat + symi(i, j));
+            for (int j = 0; j < n; j++) A[i * LD + j] = ldt(st, L.st_mat + symi(i, j));
         fail = !cholesky_lower_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++)
-            for (int k = 0; k <= i; k++) stg_t(st, L.st_mat + symi(k, i), fail ? T(0) : B[i * LD + k]);
+            for (int k = 0; k <= i; k++) stt(st, L.st_mat + symi(k, i), fail ? T(0) : B[i * LD + k]);
         break;
     }
     case OP_CHOL_Q: {
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) A[i * LD + j] = ldg_t(mo, L.mo_Q + symi(i, j));
+            for (int j = 0; j < n; j++) A[i * LD + j] = ldt(mo, L.mo_Q + symi(i, j));
         fail = !cholesky_lower_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++)
-            for (int k = 0; k <= i; k++) stg_t(mo, L.mo_LQ + symi(k, i), fail ? T(0) : B[i * LD + k]);
+            for (int k = 0; k <= i; k++) stt(mo, L.mo_LQ + symi(k, i), fail ? T(0) : B[i * LD + k]);
         break;
     }
     case OP_CHOL_R: {
         for (int i = 0; i < rp; i++)
-            for (int j = 0; j < rp; j++) A[i * LD + j] = ldg_t(mo, L.mo_R + symi(i, j));
+            for (int j = 0; j < rp; j++) A[i * LD + j] = ldt(mo, L.mo_R + symi(i, j));
         fail = !cholesky_lower_rt<T, LD>(rp, A, B);
         for (int i = 0; i < rp; i++)
-            for (int k = 0; k <= i; k++) stg_t(mo, L.mo_LR + symi(k, i), fail ? T(0) : B[i * LD + k]);
+            for (int k = 0; k <= i; k++) stt(mo, L.mo_LR + symi(k, i), fail ? T(0) : B[i * LD + k]);
         break;
     }
     case OP_INV_F: {  // errors are only printed by the reference (information.go:39-41)
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) A[i * LD + j] = ldg_t(mo, L.mo_F + i * n + j);
+            for (int j = 0; j < n; j++) A[i * LD + j] = ldt(mo, L.mo_F + i * n + j);
         inverse_lu_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) stg_t(mo, L.mo_Finv + i * n + j, B[i * LD + j]);
+            for (int j = 0; j < n; j++) stt(mo, L.mo_Finv + i * n + j, B[i * LD + j]);
         break;
     }
     case OP_INV_Q: {
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) A[i * LD + j] = ldg_t(mo, L.mo_Q + symi(i, j));
+            for (int j = 0; j < n; j++) A[i * LD + j] = ldt(mo, L.mo_Q + symi(i, j));
         inverse_lu_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) stg_t(mo, L.mo_Qinv + i * n + j, B[i * LD + j]);
+            for (int j = 0; j < n; j++) stt(mo, L.mo_Qinv + i * n + j, B[i * LD + j]);
         break;
     }
     case OP_INV_R: {
         for (int i = 0; i < rp; i++)
-            for (int j = 0; j < rp; j++) A[i * LD + j] = ldg_t(mo, L.mo_R + symi(i, j));
+            for (int j = 0; j < rp; j++) A[i * LD + j] = ldt(mo, L.mo_R + symi(i, j));
         inverse_lu_rt<T, LD>(rp, A, B);
         for (int i = 0; i < rp; i++)
-            for (int j = 0; j < rp; j++) stg_t(mo, L.mo_Rinv + i * rp + j, B[i * LD + j]);
+            for (int j = 0; j < rp; j++) stt(mo, L.mo_Rinv + i * rp + j, B[i * LD + j]);
         break;
     }
     case OP_INFO_FROM_STATE: {  // information.go:65-81
         T x[LD];
-        for (int i = 0; i < n; i++) x[i] = ldg_t(st, L.st_vec + i);
+        for (int i = 0; i < n; i++) x[i] = ldt(st, L.st_vec + i);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) A[i * LD + j] = ldg_t(st, L.st_mat + symi(i, j));
+            for (int j = 0; j < n; j++) A[i * LD + j] = ldt(st, L.st_mat + symi(i, j));
         const bool bad = inverse_lu_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++)
             for (int j = i; j < n; j++) { const T v = bad ? T(0) : B[i * LD + j]; B[i * LD + j] = v; B[j * LD + i] = v; }
         for (int i = 0; i < n; i++) {
             T s = T(0);
             for (int j = 0; j < n; j++) s += B[i * LD + j] * x[j];
-            stg_t(st, L.st_vec + i, s);
+            stt(st, L.st_vec + i, s);
         }
         for (int i = 0; i < n; i++)
-            for (int j = i; j < n; j++) stg_t(st, L.st_mat + symi(i, j), B[i * LD + j]);
+            for (int j = i; j < n; j++) stt(st, L.st_mat + symi(i, j), B[i * LD + j]);
         break;
     }
     case OP_SRIF_INIT: {  // srif.go:20-35: state block holds x0 | P0 (full) on entry, b0 | R0 on exit
         T x[LD];
-        for (int i = 0; i < n; i++) x[i] = ldg_t(st, L.st_vec + i);
+        for (int i = 0; i < n; i++) x[i] = ldt(st, L.st_vec + i);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) A[i * LD + j] = (i == j) ? T(1) / ldg_t(st, L.st_mat + i * n + i) : T(0);
+            for (int j = 0; j < n; j++) A[i * LD + j] = (i == j) ? T(1) / ldt(st, L.st_mat + i * n + i) : T(0);
         fail = !cholesky_lower_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++) {
             T s = T(0);
             for (int j = 0; j < n; j++) s += B[i * LD + j] * x[j];
-            stg_t(st, L.st_vec + i, fail ? T(0) : s);
+            stt(st, L.st_vec + i, fail ? T(0) : s);
         }
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) stg_t(st, L.st_mat + i * n + j, fail ? T(0) : B[i * LD + j]);
+            for (int j = 0; j < n; j++) stt(st, L.st_mat + i * n + j, fail ? T(0) : B[i * LD + j]);
         break;
     }
     }
@@ -214,26 +210,26 @@ __global__ void __launch_bounds__(64) materialise_kernel(const void *src_, int s
     T *out = (T *)out_ + tile * ((int64_t)KB_TILE * (n + tri(n))) + lane;
     T M[LD * LD], W[LD * LD], v[LD], x[LD];
     (void)vec_off;
-    for (int i = 0; i < n; i++) v[i] = ldg_t(vsrc, vec_src_off + i);
+    for (int i = 0; i < n; i++) v[i] = ldt(vsrc, vec_src_off + i);
     if (kind == KB_SQUAREROOT) {
         // S lower packed (posterior) or S- = Uc upper packed (predicted, squareroot.go:185 quirk)
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) {
                 const bool nz = pred ? (j >= i) : (j <= i);
-                M[i * LD + j] = nz ? ldg_t(src, mat_off + symi(i, j)) : T(0);
+                M[i * LD + j] = nz ? ldt(src, mat_off + symi(i, j)) : T(0);
             }
         for (int i = 0; i < n; i++)
             for (int j = i; j < n; j++) {
                 T s = T(0);
                 for (int k = 0; k < n; k++) s += M[i * LD + k] * M[j * LD + k];
-                stg_t(out, n + symi(i, j), s);
+                stt(out, n + symi(i, j), s);
             }
-        for (int i = 0; i < n; i++) stg_t(out, i, v[i]);
+        for (int i = 0; i < n; i++) stt(out, i, v[i]);
         return;
     }
     if (kind == KB_INFORMATION) {
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) M[i * LD + j] = ldg_t(src, mat_off + symi(i, j));
+            for (int j = 0; j < n; j++) M[i * LD + j] = ldt(src, mat_off + symi(i, j));
         const bool bad = inverse_lu_rt<T, LD>(n, M, W);  // information.go:284-288: zeros + warning
         if (bad && !pred) atomicOr(status + fi, KB_ST_INFO_NOT_INVERTIBLE);
         for (int i = 0; i < n; i++)
@@ -245,7 +241,7 @@ __global__ void __launch_bounds__(64) materialise_kernel(const void *src_, int s
         }
     } else if (kind == KB_BATCH_LS) {  // batch.go:64-79 Solve: P0 = AsSymDense(inverse(Lambda)), xHat0 = P0 N
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) M[i * LD + j] = ldg_t(src, mat_off + i * n + j);
+            for (int j = 0; j < n; j++) M[i * LD + j] = ldt(src, mat_off + i * n + j);
         bool bad = inverse_lu_rt<T, LD>(n, M, W);
         bool sym = true;
         for (int i = 0; i < n; i++)
@@ -263,7 +259,7 @@ __global__ void __launch_bounds__(64) materialise_kernel(const void *src_, int s
         }
     } else {  // KB_SRIF: x = R^-1 b, P = R^-1 R^-T (srif.go:223-281)
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) M[i * LD + j] = ldg_t(src, mat_off + i * n + j);
+            for (int j = 0; j < n; j++) M[i * LD + j] = ldt(src, mat_off + i * n + j);
         const bool bad = inverse_lu_rt<T, LD>(n, M, W);
         if (bad && !pred) atomicOr(status + fi, KB_ST_INFO_NOT_INVERTIBLE);
         for (int i = 0; i < n; i++) {
@@ -280,9 +276,9 @@ __global__ void __launch_bounds__(64) materialise_kernel(const void *src_, int s
         for (int i = 0; i < n; i++)
             for (int j = i; j < n; j++) W[i * LD + j] = M[i * LD + j];
     }
-    for (int i = 0; i < n; i++) stg_t(out, i, x[i]);
+    for (int i = 0; i < n; i++) stt(out, i, x[i]);
     for (int i = 0; i < n; i++)
-        for (int j = i; j < n; j++) stg_t(out, n + symi(i, j), W[i * LD + j]);
+        for (int j = i; j < n; j++) stt(out, n + symi(i, j), W[i * LD + j]);
 }
 
 int launch_materialise(const Batch &b, const void *src_block, bool pred, void *out_block) {
@@ -311,9 +307,9 @@ __global__ void __launch_bounds__(64) smooth_kernel(const T *xp_block, int xp_el
     if (fi >= N) return;
     const T *src = xp_block + tile * ((int64_t)KB_TILE * xp_elems) + lane;
     T x[LD], P[LD * LD], S[LD * LD], W[LD * LD], A[LD * LD];
-    for (int i = 0; i < n; i++) x[i] = ldg_t(src, vec_off + i);
+    for (int i = 0; i < n; i++) x[i] = ldt(src, vec_off + i);
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) P[i * LD + j] = ldg_t(src, mat_off + symi(i, j));
+        for (int j = 0; j < n; j++) P[i * LD + j] = ldt(src, mat_off + symi(i, j));
     unsigned err = 0;
     for (int k = steps - 1; k >= 0; k--) {
         for (int i = 0; i < n; i++) x_out[((int64_t)k * n + i) * ld + fi] = x[i];
@@ -360,8 +356,8 @@ __global__ void within_kernel(const T *xp, int elems, int vec_off, int mat_off, 
     const T *s = xp + (fi / KB_TILE) * ((int64_t)KB_TILE * elems) + (fi % KB_TILE);
     bool ok = true;
     for (int i = 0; i < n; i++) {
-        const double ns = nsigma * sqrt((double)ldg_t(s, mat_off + symi(i, i)));
-        const double x = (double)ldg_t(s, vec_off + i);
+        const double ns = nsigma * sqrt((double)ldt(s, mat_off + symi(i, i)));
+        const double x = (double)ldt(s, vec_off + i);
         if (x > ns || x < -ns) ok = false;
     }
     out[fi] = ok ? 1 : 0;

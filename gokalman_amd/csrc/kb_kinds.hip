@@ -9,15 +9,11 @@
 
 namespace kb {
 
-template <typename T>
-__device__ __forceinline__ T ldk(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ void stk(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 template <typename T, int LD>
 __device__ inline T awgn_component(const StepArgs &a, const T *mo, int off_L, int64_t gfi, uint32_t stepno, uint32_t which, int i, const T *z) {
     T s = T(0);
-    for (int k = 0; k <= i; k++) s += ldk(mo, off_L + symi(k, i)) * z[k];
+    for (int k = 0; k <= i; k++) s += ldt(mo, off_L + symi(k, i)) * z[k];
     (void)a; (void)gfi; (void)stepno; (void)which;
     return s;
 }
@@ -40,14 +36,14 @@ __global__ void __launch_bounds__(64) squareroot_gen_kernel(const StepArgs a) {
     const T *up = a.u ? (const T *)a.u + tile * a.u_ts + lane : nullptr;
 
     T x[LD], S[LD * LD], F[LD * LD], H[LD * LD];
-    for (int i = 0; i < n; i++) x[i] = ldk(st, a.L.st_vec + i);
+    for (int i = 0; i < n; i++) x[i] = ldt(st, a.L.st_vec + i);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) {
-            S[i * LD + j] = (j <= i) ? ldk(st, a.L.st_mat + symi(j, i)) : T(0);
-            F[i * LD + j] = ldk(mo, a.L.mo_F + i * n + j);
+            S[i * LD + j] = (j <= i) ? ldt(st, a.L.st_mat + symi(j, i)) : T(0);
+            F[i * LD + j] = ldt(mo, a.L.mo_F + i * n + j);
         }
     for (int r = 0; r < p; r++)
-        for (int j = 0; j < n; j++) H[r * LD + j] = ldk(mo, a.L.mo_H + r * n + j);
+        for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
     unsigned err_acc = 0;
     for (int t = 0; t < a.nsteps; t++) {
         const uint32_t stepno = (uint32_t)(a.step0 + t);
@@ -57,7 +53,7 @@ __global__ void __launch_bounds__(64) squareroot_gen_kernel(const StepArgs a) {
         if (a.need_ctrl)
             for (int i = 0; i < n; i++) {
                 T s = T(0);
-                for (int c = 0; c < m; c++) s += ldk(mo, a.L.mo_G + i * m + c) * up[(int64_t)t * a.u_step + (int64_t)c * a.u_es];
+                for (int c = 0; c < m; c++) s += ldt(mo, a.L.mo_G + i * m + c) * up[(int64_t)t * a.u_step + (int64_t)c * a.u_es];
                 xm[i] = xm[i] + s;
             }
         // :155-185 C = [S^T F^T ; sqrtQ^T], Uc = R-factor; QUIRK S- := Uc
@@ -67,7 +63,7 @@ __global__ void __launch_bounds__(64) squareroot_gen_kernel(const StepArgs a) {
                 T s = T(0);
                 for (int l = 0; l < n; l++) s += S[l * LD + i] * F[j * LD + l];
                 C[i * LD + j] = s;
-                C[(n + i) * LD + j] = (j >= i) ? ldk(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
+                C[(n + i) * LD + j] = (j >= i) ? ldt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
             }
         qr_r_rt<T, LD>(2 * n, n, C);
         T Sm[LD * LD];
@@ -80,7 +76,7 @@ __global__ void __launch_bounds__(64) squareroot_gen_kernel(const StepArgs a) {
             for (int c = 0; c < d; c++) {
                 T val;
                 if (c < sp) {
-                    if (r < sp) val = (c >= r) ? ldk(mo, a.L.mo_LR + symi(r, c)) : T(0);  // sqrtR^T[r][c] = L[c][r]
+                    if (r < sp) val = (c >= r) ? ldt(mo, a.L.mo_LR + symi(r, c)) : T(0);  // sqrtR^T[r][c] = L[c][r]
                     else {
                         T s = T(0);  // (S-^T H^T)[r-sp][c]
                         for (int l = 0; l < n; l++) s += Sm[l * LD + (r - sp)] * H[c * LD + l];
@@ -140,19 +136,19 @@ __global__ void __launch_bounds__(64) squareroot_gen_kernel(const StepArgs a) {
             if (full) {
                 T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
                 for (int i = 0; i < n; i++)
-                    for (int j = i; j < n; j++) stk(es, a.L.es_ppred + symi(i, j), Sm[i * LD + j]);
+                    for (int j = i; j < n; j++) stt(es, a.L.es_ppred + symi(i, j), Sm[i * LD + j]);
                 for (int i = 0; i < n; i++)
-                    for (int c = 0; c < p; c++) stk(es, a.L.es_gain + i * a.pmax + c, K[i * LD + c]);
-                for (int r = 0; r < p; r++) { stk(es, a.L.es_innov + r, innov[r]); stk(es, a.L.es_yhat + r, yhat[r]); }
+                    for (int c = 0; c < p; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * LD + c]);
+                for (int r = 0; r < p; r++) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, yhat[r]); }
             }
             for (int i = 0; i < n; i++) x[i] = xn[i];
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < n; j++) S[i * LD + j] = Sp[i * LD + j];
         }
     }
-    for (int i = 0; i < n; i++) stk(st, a.L.st_vec + i, x[i]);
+    for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, x[i]);
     for (int i = 0; i < n; i++)
-        for (int j = 0; j <= i; j++) stk(st, a.L.st_mat + symi(j, i), S[i * LD + j]);
+        for (int j = 0; j <= i; j++) stt(st, a.L.st_mat + symi(j, i), S[i * LD + j]);
     if (err_acc) atomicOr(a.status + fi, err_acc);
 }
 
@@ -173,14 +169,14 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
     const T *up = a.u ? (const T *)a.u + tile * a.u_ts + lane : nullptr;
 
     T iv[LD], I[LD * LD], Fi[LD * LD], H[LD * LD];
-    for (int i = 0; i < n; i++) iv[i] = ldk(st, a.L.st_vec + i);
+    for (int i = 0; i < n; i++) iv[i] = ldt(st, a.L.st_vec + i);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) {
-            I[i * LD + j] = ldk(st, a.L.st_mat + symi(i, j));
-            Fi[i * LD + j] = ldk(mo, a.L.mo_Finv + i * n + j);
+            I[i * LD + j] = ldt(st, a.L.st_mat + symi(i, j));
+            Fi[i * LD + j] = ldt(mo, a.L.mo_Finv + i * n + j);
         }
     for (int r = 0; r < p; r++)
-        for (int j = 0; j < n; j++) H[r * LD + j] = ldk(mo, a.L.mo_H + r * n + j);
+        for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
     unsigned err_acc = 0;
     for (int t = 0; t < a.nsteps; t++) {
         const uint32_t stepno = (uint32_t)(a.step0 + t);
@@ -190,7 +186,7 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
         mm_tn<T, LD, LD, LD>(n, n, n, Fi, t1, zk);
         // :169-174 Z = -zk (zk + Qinv)^-1
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) zq[i * LD + j] = zk[i * LD + j] + ldk(mo, a.L.mo_Qinv + i * n + j);
+            for (int j = 0; j < n; j++) zq[i * LD + j] = zk[i * LD + j] + ldt(mo, a.L.mo_Qinv + i * n + j);
         inverse_lu_rt<T, LD>(n, zq, zqi);
         mm_nn<T, LD, LD, LD>(n, n, n, zk, zqi, Z);
         for (int i = 0; i < n; i++)
@@ -201,7 +197,7 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
         if (a.need_ctrl) {
             for (int i = 0; i < n; i++) {
                 T s = T(0);
-                for (int c = 0; c < m; c++) s += ldk(mo, a.L.mo_G + i * m + c) * up[(int64_t)t * a.u_step + (int64_t)c * a.u_es];
+                for (int c = 0; c < m; c++) s += ldt(mo, a.L.mo_G + i * m + c) * up[(int64_t)t * a.u_step + (int64_t)c * a.u_es];
                 tv[i] = s;
             }
             mv_n<T, LD>(n, n, zk, tv, tv2);
@@ -241,14 +237,14 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
         // :197-203 HTR = H^T Rinv; QUIRK: a stale 1x1 Rinv acts as a scalar on any p
         T HTR[LD * LD];
         if (rp == 1) {
-            const T r0 = ldk(mo, a.L.mo_Rinv);
+            const T r0 = ldt(mo, a.L.mo_Rinv);
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < p; j++) HTR[i * LD + j] = r0 * H[j * LD + i];
         } else {
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < p; j++) {
                     T s = T(0);
-                    for (int l = 0; l < p; l++) s += H[l * LD + i] * ldk(mo, a.L.mo_Rinv + l * rp + j);
+                    for (int l = 0; l < p; l++) s += H[l * LD + i] * ldt(mo, a.L.mo_Rinv + l * rp + j);
                     HTR[i * LD + j] = s;
                 }
         }
@@ -282,17 +278,17 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
             if (full) {
                 T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
                 for (int i = 0; i < n; i++)
-                    for (int j = i; j < n; j++) stk(es, a.L.es_ppred + symi(i, j), Im[i * LD + j]);
-                for (int r = 0; r < p; r++) stk(es, a.L.es_yhat + r, yhat[r]);
+                    for (int j = i; j < n; j++) stt(es, a.L.es_ppred + symi(i, j), Im[i * LD + j]);
+                for (int r = 0; r < p; r++) stt(es, a.L.es_yhat + r, yhat[r]);
             }
             for (int i = 0; i < n; i++) iv[i] = ip[i];
             for (int i = 0; i < n; i++)
                 for (int j = i; j < n; j++) { I[i * LD + j] = Ip[i * LD + j]; I[j * LD + i] = Ip[i * LD + j]; }
         }
     }
-    for (int i = 0; i < n; i++) stk(st, a.L.st_vec + i, iv[i]);
+    for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, iv[i]);
     for (int i = 0; i < n; i++)
-        for (int j = i; j < n; j++) stk(st, a.L.st_mat + symi(i, j), I[i * LD + j]);
+        for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), I[i * LD + j]);
     if (err_acc) atomicOr(a.status + fi, err_acc);
 }
 
@@ -313,11 +309,11 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
 
     T b[LD], R[LD * LD], Phi[LD * LD], Rc[LD * LD];
-    for (int i = 0; i < n; i++) b[i] = ldk(st, a.L.st_vec + i);
+    for (int i = 0; i < n; i++) b[i] = ldt(st, a.L.st_vec + i);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) {
-            R[i * LD + j] = ldk(st, a.L.st_mat + i * n + j);
-            Phi[i * LD + j] = ldk(mo, a.L.mo_F + i * n + j);
+            R[i * LD + j] = ldt(st, a.L.st_mat + i * n + j);
+            Phi[i * LD + j] = ldt(mo, a.L.mo_F + i * n + j);
         }
     unsigned err = 0;
     // :111-115 RBar = R inv(Phi)
@@ -336,13 +332,13 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
     T *es = full ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
     if (a.predict) {  // :134-141
         if (!err) {
-            for (int i = 0; i < n; i++) stk(st, a.L.st_vec + i, bBar[i]);
+            for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, bBar[i]);
             for (int i = 0; i < n; i++)
-                for (int j = 0; j < n; j++) stk(st, a.L.st_mat + i * n + j, RBar[i * LD + j]);
+                for (int j = 0; j < n; j++) stt(st, a.L.st_mat + i * n + j, RBar[i * LD + j]);
             if (full) {
                 for (int i = 0; i < n; i++)
-                    for (int j = 0; j < n; j++) stk(es, a.L.es_ppred + i * n + j, RBar[i * LD + j]);
-                for (int r = 0; r < p; r++) { stk(es, a.L.es_yhat + r, T(0)); stk(es, a.L.es_dobs + r, T(0)); }
+                    for (int j = 0; j < n; j++) stt(es, a.L.es_ppred + i * n + j, RBar[i * LD + j]);
+                for (int r = 0; r < p; r++) { stt(es, a.L.es_yhat + r, T(0)); stt(es, a.L.es_dobs + r, T(0)); }
             }
         } else atomicOr(a.status + fi, err);
         return;
@@ -360,11 +356,11 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
     for (int r = 0; r < p; r++) {
         for (int j = 0; j < n; j++) {
             T s = T(0);
-            for (int l = 0; l <= r; l++) s += ldk(mo, a.L.mo_LR + symi(l, r)) * ldk(mo, a.L.mo_H + l * n + j);
+            for (int l = 0; l <= r; l++) s += ldt(mo, a.L.mo_LR + symi(l, r)) * ldt(mo, a.L.mo_H + l * n + j);
             A[(n + r) * PC + j] = s;
         }
         T s = T(0);
-        for (int l = 0; l <= r; l++) s += ldk(mo, a.L.mo_LR + symi(l, r)) * yv[l];
+        for (int l = 0; l <= r; l++) s += ldt(mo, a.L.mo_LR + symi(l, r)) * yv[l];
         yw[r] = s;
         A[(n + r) * PC + n] = s;
     }
@@ -374,13 +370,13 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
         for (int j = 0; j <= n; j++) finite = finite && (A[i * PC + j] * T(0) == T(0));
     if (!finite) err |= KB_ST_NONFINITE;
     if (err) { atomicOr(a.status + fi, err); return; }
-    for (int i = 0; i < n; i++) stk(st, a.L.st_vec + i, A[i * PC + n]);
+    for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, A[i * PC + n]);
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) stk(st, a.L.st_mat + i * n + j, A[i * PC + j]);
+        for (int j = 0; j < n; j++) stt(st, a.L.st_mat + i * n + j, A[i * PC + j]);
     if (full) {
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) stk(es, a.L.es_ppred + i * n + j, RBar[i * LD + j]);
-        for (int r = 0; r < p; r++) { stk(es, a.L.es_yhat + r, real[r]); stk(es, a.L.es_dobs + r, yw[r]); stk(es, a.L.es_innov + r, A[(n + r) * PC + n]); }
+            for (int j = 0; j < n; j++) stt(es, a.L.es_ppred + i * n + j, RBar[i * LD + j]);
+        for (int r = 0; r < p; r++) { stt(es, a.L.es_yhat + r, real[r]); stt(es, a.L.es_dobs + r, yw[r]); stt(es, a.L.es_innov + r, A[(n + r) * PC + n]); }
     }
 }
 
@@ -399,15 +395,15 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * a.L.st_elems) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     T x[LD], P[LD * LD], Phi[LD * LD], H[LD * LD], R[LD * LD];
-    for (int i = 0; i < n; i++) x[i] = ldk(st, a.L.st_vec + i);
+    for (int i = 0; i < n; i++) x[i] = ldt(st, a.L.st_vec + i);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) {
-            P[i * LD + j] = ldk(st, a.L.st_mat + symi(i, j));
-            Phi[i * LD + j] = ldk(mo, a.L.mo_F + i * n + j);
+            P[i * LD + j] = ldt(st, a.L.st_mat + symi(i, j));
+            Phi[i * LD + j] = ldt(mo, a.L.mo_F + i * n + j);
         }
     for (int r = 0; r < p; r++) {
-        for (int j = 0; j < n; j++) H[r * LD + j] = ldk(mo, a.L.mo_H + r * n + j);
-        for (int c = 0; c < p; c++) R[r * LD + c] = ldk(mo, a.L.mo_R + symi(r, c));
+        for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
+        for (int c = 0; c < p; c++) R[r * LD + c] = ldt(mo, a.L.mo_R + symi(r, c));
     }
     // :114-123 PBar = Phi P Phi^T [+ Gamma Q Gamma^T]
     T PhiP[LD * LD], PBar[LD * LD];
@@ -418,13 +414,13 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
         for (int i = 0; i < n; i++)
             for (int c = 0; c < q; c++) {
                 T s = T(0);
-                for (int l = 0; l < q; l++) s += ldk(mo, a.L.mo_G + i * q + l) * ldk(mo, a.L.mo_Q + symi(l, c));
+                for (int l = 0; l < q; l++) s += ldt(mo, a.L.mo_G + i * q + l) * ldt(mo, a.L.mo_Q + symi(l, c));
                 GQ[i * LD + c] = s;
             }
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) {
                 T s = T(0);
-                for (int c = 0; c < q; c++) s += GQ[i * LD + c] * ldk(mo, a.L.mo_G + j * q + c);
+                for (int c = 0; c < q; c++) s += GQ[i * LD + c] * ldt(mo, a.L.mo_G + j * q + c);
                 PBar[i * LD + j] += s;
             }
     }
@@ -442,15 +438,15 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
             }
         if (!finite) err |= KB_ST_NONFINITE; else if (!sym) err |= KB_ST_ASYMMETRIC;
         if (err) { atomicOr(a.status + fi, err); return; }
-        for (int i = 0; i < n; i++) stk(st, a.L.st_vec + i, xBar[i]);
+        for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, xBar[i]);
         for (int i = 0; i < n; i++)
-            for (int j = i; j < n; j++) stk(st, a.L.st_mat + symi(i, j), PBar[i * LD + j]);
+            for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), PBar[i * LD + j]);
         if (full) {
             for (int i = 0; i < n; i++)
-                for (int j = i; j < n; j++) stk(es, a.L.es_ppred + symi(i, j), PBar[i * LD + j]);
+                for (int j = i; j < n; j++) stt(es, a.L.es_ppred + symi(i, j), PBar[i * LD + j]);
             for (int i = 0; i < n; i++)
-                for (int c = 0; c < p; c++) stk(es, a.L.es_gain + i * a.pmax + c, T(0));
-            for (int r = 0; r < p; r++) { stk(es, a.L.es_innov + r, T(0)); stk(es, a.L.es_yhat + r, T(0)); stk(es, a.L.es_dobs + r, T(0)); }
+                for (int c = 0; c < p; c++) stt(es, a.L.es_gain + i * a.pmax + c, T(0));
+            for (int r = 0; r < p; r++) { stt(es, a.L.es_innov + r, T(0)); stt(es, a.L.es_yhat + r, T(0)); stt(es, a.L.es_dobs + r, T(0)); }
         }
         return;
     }
@@ -504,15 +500,15 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
     }
     if (!finite) err |= KB_ST_NONFINITE; else if (!sym) err |= KB_ST_ASYMMETRIC;
     if (err) { atomicOr(a.status + fi, err); return; }
-    for (int i = 0; i < n; i++) stk(st, a.L.st_vec + i, xh[i]);
+    for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, xh[i]);
     for (int i = 0; i < n; i++)
-        for (int j = i; j < n; j++) stk(st, a.L.st_mat + symi(i, j), Pn[i * LD + j]);
+        for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), Pn[i * LD + j]);
     if (full) {
         for (int i = 0; i < n; i++)
-            for (int j = i; j < n; j++) stk(es, a.L.es_ppred + symi(i, j), PBar[i * LD + j]);
+            for (int j = i; j < n; j++) stt(es, a.L.es_ppred + symi(i, j), PBar[i * LD + j]);
         for (int i = 0; i < n; i++)
-            for (int c = 0; c < p; c++) stk(es, a.L.es_gain + i * a.pmax + c, K[i * LD + c]);
-        for (int r = 0; r < p; r++) { stk(es, a.L.es_innov + r, innov[r]); stk(es, a.L.es_yhat + r, real[r]); stk(es, a.L.es_dobs + r, yv[r]); }
+            for (int c = 0; c < p; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * LD + c]);
+        for (int r = 0; r < p; r++) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, real[r]); stt(es, a.L.es_dobs + r, yv[r]); }
     }
 }
 
@@ -533,8 +529,8 @@ __global__ void __launch_bounds__(64) batch_ls_gen_kernel(const StepArgs a) {
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
     T H[LD * LD], R[LD * LD], HtR[LD * LD], y[LD];
     for (int r = 0; r < p; r++) {
-        for (int j = 0; j < n; j++) H[r * LD + j] = ldk(mo, a.L.mo_H + r * n + j);
-        for (int c = 0; c < p; c++) R[r * LD + c] = ldk(mo, a.L.mo_R + symi(r, c));
+        for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
+        for (int c = 0; c < p; c++) R[r * LD + c] = ldt(mo, a.L.mo_R + symi(r, c));
         y[r] = yr[(int64_t)r * a.y_es] - yc[(int64_t)r * a.y2_es];
     }
     mm_tn<T, LD, LD, LD>(n, p, p, H, R, HtR);
@@ -542,11 +538,11 @@ __global__ void __launch_bounds__(64) batch_ls_gen_kernel(const StepArgs a) {
         for (int j = 0; j < n; j++) {
             T s = T(0);
             for (int l = 0; l < p; l++) s += HtR[i * LD + l] * H[l * LD + j];
-            stk(st, a.L.st_mat + i * n + j, ldk(st, a.L.st_mat + i * n + j) + s);
+            stt(st, a.L.st_mat + i * n + j, ldt(st, a.L.st_mat + i * n + j) + s);
         }
         T s = T(0);
         for (int l = 0; l < p; l++) s += HtR[i * LD + l] * y[l];
-        stk(st, a.L.st_vec + i, ldk(st, a.L.st_vec + i) + s);
+        stt(st, a.L.st_vec + i, ldt(st, a.L.st_vec + i) + s);
     }
 }
 

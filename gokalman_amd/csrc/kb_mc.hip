@@ -17,8 +17,6 @@ namespace kb {
 
 constexpr int MC_REPL = 32;
 
-template <typename T>
-__device__ __forceinline__ T ldm(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -40,14 +38,14 @@ __global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__re
     T x[NS], c[NS], F[NS * NS], LQ[tri(NS)];
     [[maybe_unused]] T G[NC > 0 ? NS * NC : 1];
 #pragma unroll
-    for (int i = 0; i < NS; i++) { x[i] = ldm(st, a.L.st_vec + i); c[i] = x[i]; }
+    for (int i = 0; i < NS; i++) { x[i] = ldt(st, a.L.st_vec + i); c[i] = x[i]; }
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldm(mo, a.L.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) F[e] = ldt(mo, a.L.mo_F + e);
 #pragma unroll
-    for (int e = 0; e < tri(NS); e++) LQ[e] = ldm(mo, a.L.mo_LQ + e);
+    for (int e = 0; e < tri(NS); e++) LQ[e] = ldt(mo, a.L.mo_LQ + e);
     if constexpr (NC > 0) {
 #pragma unroll
-        for (int e = 0; e < NS * NC; e++) G[e] = ldm(mo, a.L.mo_G + e);
+        for (int e = 0; e < NS * NC; e++) G[e] = ldt(mo, a.L.mo_G + e);
     }
     double *my = sums + (size_t)(tile % MC_REPL) * a.nsteps * 2 * NS;
     const uint64_t gfi = (uint64_t)(a.first_filter + fi);

@@ -16,12 +16,6 @@ namespace kb {
 #define SQRT_WAVES 1
 #endif
 
-template <typename T>
-__device__ __forceinline__ T ld_s(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ T ld_nt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
-template <typename T>
-__device__ __forceinline__ void st_s(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 template <int NS>
 struct ActC {  // C = [S^T F^T ; sqrtQ^T]: bottom block row r' is non-zero in column k only when r' <= k
@@ -45,11 +39,11 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
 
     T x[NS], S[TR], F[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = ld_s(st, i);
+    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
 #pragma unroll
-    for (int e = 0; e < TR; e++) S[e] = ld_s(st, NS + e);  // S[i][k], k <= i, at symi(k, i)
+    for (int e = 0; e < TR; e++) S[e] = ldt(st, NS + e);  // S[i][k], k <= i, at symi(k, i)
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ld_nt(mo, a.L.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(mo, a.L.mo_F + e);
 
     // :139-147 x- = F x [+ G u]
     T xm[NS];
@@ -60,7 +54,7 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
         for (int i = 0; i < NS; i++) {
             T s = T(0);
 #pragma unroll
-            for (int c = 0; c < NC; c++) s += ld_nt(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+            for (int c = 0; c < NC; c++) s += ldnt(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
             xm[i] = xm[i] + s;
         }
     }
@@ -83,13 +77,13 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i) ? ld_nt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
+        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i) ? ldnt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
     sqr_r<T, 2 * NS, NS, ActC<NS>>(C);
     __builtin_amdgcn_sched_barrier(0);  // H, chol(R) loads and the Delta panel stay below the C phase
     // Sm[i][j] = C[i*NS+j], j >= i
     T H[NM * NS];
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ld_nt(mo, a.L.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
     // :190-216 Delta = [[sqrtR^T, 0],[S-^T H^T, S-^T]]
     T D[DD * DD];
 #pragma unroll
@@ -99,7 +93,7 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
             T val;
             if (c < NM) {
                 if (r < NM) {
-                    val = (c >= r) ? ld_nt(mo, a.L.mo_LR + symi(r, c)) : T(0);
+                    val = (c >= r) ? ldnt(mo, a.L.mo_LR + symi(r, c)) : T(0);
                 } else {
                     T s = T(0);  // (S-^T H^T)[r-NM][c] = sum_{l <= r-NM} Sm[l][r-NM] H[c][l]
 #pragma unroll
@@ -121,7 +115,7 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
 #pragma unroll
             for (int i = 0; i < NS; i++)
 #pragma unroll
-                for (int j = i; j < NS; j++) st_s(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
+                for (int j = i; j < NS; j++) stt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
         }
     }
     sqr_r<T, DD, DD, ActD<NM>>(D);
@@ -167,19 +161,19 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
     const bool ok = !(chk != chk);
     if (active && ok) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) st_s(st, i, xn[i]);
+        for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int j = 0; j <= i; j++) st_s(st, NS + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
+            for (int j = 0; j <= i; j++) stt(st, NS + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
         if constexpr (FULL) {
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll
             for (int i = 0; i < NS; i++)
 #pragma unroll
-                for (int c = 0; c < NM; c++) st_s(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
-            for (int r = 0; r < NM; r++) { st_s(es, a.L.es_innov + r, innov[r]); st_s(es, a.L.es_yhat + r, yhat[r]); }
+            for (int r = 0; r < NM; r++) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, yhat[r]); }
         }
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);

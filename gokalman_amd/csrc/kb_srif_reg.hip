@@ -20,12 +20,6 @@
 
 namespace kb {
 
-template <typename T>
-__device__ __forceinline__ T sl(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }
-template <typename T>
-__device__ __forceinline__ T snt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }
-template <typename T>
-__device__ __forceinline__ void ss(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
 // LU factorisation with partial pivoting in place (unit-lower L below the diagonal, U on and
 // above), recording every row exchange as one bit (exchange index = position in the (j, r) loop
@@ -111,9 +105,9 @@ __global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
     {   // State(prev) = R^-1 b (srif.go:223-234)
         T Rw[NS * NS];
 #pragma unroll
-        for (int i = 0; i < NS; i++) xprev[i] = sl(st, i);
+        for (int i = 0; i < NS; i++) xprev[i] = ldt(st, i);
 #pragma unroll
-        for (int e = 0; e < NS * NS; e++) Rw[e] = sl(st, NS + e);
+        for (int e = 0; e < NS * NS; e++) Rw[e] = ldt(st, NS + e);
         if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;
     }
     // keep the machine scheduler from hoisting the next phase's loads above this one: the phases are
@@ -122,7 +116,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
     T Phi[NS * NS], xBar[NS];
     unsigned bits[NB];
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) Phi[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : snt(mo, a.L.mo_F + e);
+    for (int e = 0; e < NS * NS; e++) Phi[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
     smv<T, NS, NS>(Phi, xprev, xBar);                      // :118 xBar = Phi State(prev)
     if (lu_factor_record<T, NS>(Phi, bits)) err |= KB_ST_SINGULAR;  // :111-114
     if (err) { if (active) atomicOr(a.status + fi, err); return; }
@@ -130,7 +124,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
     T bBar[NS], znext[NS];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int l = 0; l < NS; l++) znext[l] = sl(st, NS + l);  // row 0 of R again: cache hit
+    for (int l = 0; l < NS; l++) znext[l] = ldt(st, NS + l);  // row 0 of R again: cache hit
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         T z[NS];
@@ -138,7 +132,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
         for (int l = 0; l < NS; l++) z[l] = znext[l];
         if (i + 1 < NS) {
 #pragma unroll
-            for (int l = 0; l < NS; l++) znext[l] = sl(st, NS + (i + 1) * NS + l);  // prefetch the next row
+            for (int l = 0; l < NS; l++) znext[l] = ldt(st, NS + (i + 1) * NS + l);  // prefetch the next row
         }
         __builtin_amdgcn_sched_barrier(0);
         lu_row_solve<T, NS>(Phi, bits, z);                 // :115 row i of RBar = R Phi^-1
@@ -149,14 +143,14 @@ __global__ void __launch_bounds__(256, 1) srif_time_kernel(const StepArgs a) {
         if (active) {
 #pragma unroll
             for (int j = 0; j < NS; j++) {
-                ss(st, NS + i * NS + j, z[j]);
-                if constexpr (FULL) ss(es, a.L.es_ppred + i * NS + j, z[j]);
+                stt(st, NS + i * NS + j, z[j]);
+                if constexpr (FULL) stt(es, a.L.es_ppred + i * NS + j, z[j]);
             }
         }
     }
     if (active) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) ss(st, i, bBar[i]);
+        for (int i = 0; i < NS; i++) stt(st, i, bBar[i]);
     }
 }
 
@@ -193,9 +187,9 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
     {   // State(prev) = R^-1 b (srif.go:223-234), register LU solve
         T Rw[NS * NS];
 #pragma unroll
-        for (int i = 0; i < NS; i++) xprev[i] = sl(st, i);
+        for (int i = 0; i < NS; i++) xprev[i] = ldt(st, i);
 #pragma unroll
-        for (int e = 0; e < NS * NS; e++) Rw[e] = sl(st, NS + e);
+        for (int e = 0; e < NS * NS; e++) Rw[e] = ldt(st, NS + e);
         if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +199,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
             T s = T(0);
 #pragma unroll
             for (int j = 0; j < NS; j++) {
-                const T v = EXT ? __builtin_nontemporal_load(ephi + (int64_t)(i * NS + j) * a.ext_ld) : snt(mo, a.L.mo_F + i * NS + j);
+                const T v = EXT ? __builtin_nontemporal_load(ephi + (int64_t)(i * NS + j) * a.ext_ld) : ldnt(mo, a.L.mo_F + i * NS + j);
                 lu.put(i, j, v);
                 s += v * xprev[j];
             }
@@ -258,7 +252,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
 #pragma unroll
     for (int g = 0; g < RG; g++)
 #pragma unroll
-        for (int l = 0; l < NS; l++) znext[g][l] = sl(st, NS + g * NS + l);  // rows of R again: cache hits
+        for (int l = 0; l < NS; l++) znext[g][l] = ldt(st, NS + g * NS + l);  // rows of R again: cache hits
 #pragma unroll 1
     for (int i0 = 0; i0 < NS; i0 += RG) {
         T z[RG][NS];
@@ -270,7 +264,7 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
 #pragma unroll
             for (int g = 0; g < RG; g++)
 #pragma unroll
-                for (int l = 0; l < NS; l++) znext[g][l] = sl(st, NS + (i0 + RG + g) * NS + l);
+                for (int l = 0; l < NS; l++) znext[g][l] = ldt(st, NS + (i0 + RG + g) * NS + l);
         }
         // z Phi = r  with  P Phi = L U:  w U = r,  v L = w,  z[perm_r] = v_r   (srif.go:115)
 #pragma unroll
@@ -314,10 +308,10 @@ __global__ void __launch_bounds__(256, 1) srif_time_lds_kernel(const StepArgs a)
 #pragma unroll
                 for (int c = 0; c < NS; c++) {
                     const T v = ltmp[c * KB_TILE];
-                    ss(st, NS + (i0 + g) * NS + c, v);
-                    if constexpr (FULL) ss(es, a.L.es_ppred + (i0 + g) * NS + c, v);
+                    stt(st, NS + (i0 + g) * NS + c, v);
+                    if constexpr (FULL) stt(es, a.L.es_ppred + (i0 + g) * NS + c, v);
                 }
-                ss(st, i0 + g, bb);  // b <- bBar: rows i0.. of R and their b entries are not read again
+                stt(st, i0 + g, bb);  // b <- bBar: rows i0.. of R and their b entries are not read again
             }
         }
     }
@@ -344,13 +338,13 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     {
         T Lw[tri(NM)], yv[NM];
 #pragma unroll
-        for (int e = 0; e < tri(NM); e++) Lw[e] = snt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
+        for (int e = 0; e < tri(NM); e++) Lw[e] = ldnt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
 #pragma unroll
         for (int r = 0; r < NM; r++) {
             const T re = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
             const T co = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
             yv[r] = re - co;
-            if constexpr (FULL) { if (active) ss(es, a.L.es_yhat + r, re); }
+            if constexpr (FULL) { if (active) stt(es, a.L.es_yhat + r, re); }
         }
 #pragma unroll
         for (int r = 0; r < NM; r++)
@@ -360,7 +354,7 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
         for (int l = 0; l < NM; l++) {
             T Hl[NS];
 #pragma unroll
-            for (int j = 0; j < NS; j++) Hl[j] = EXT ? __builtin_nontemporal_load(eh + (int64_t)(l * NS + j) * a.ext_ld) : snt(mo, a.L.mo_H + l * NS + j);
+            for (int j = 0; j < NS; j++) Hl[j] = EXT ? __builtin_nontemporal_load(eh + (int64_t)(l * NS + j) * a.ext_ld) : ldnt(mo, a.L.mo_H + l * NS + j);
 #pragma unroll
             for (int r = l; r < NM; r++)
 #pragma unroll
@@ -372,15 +366,15 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
 #pragma unroll
             for (int l = 0; l <= r; l++) s += Lw[symi(l, r)] * yv[l];
             A[(NS + r) * COLS + NS] = s;
-            if constexpr (FULL) { if (active) ss(es, a.L.es_dobs + r, s); }
+            if constexpr (FULL) { if (active) stt(es, a.L.es_dobs + r, s); }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NS; i++) {
 #pragma unroll
-        for (int j = 0; j < NS; j++) A[i * COLS + j] = sl(st, NS + i * NS + j);
-        A[i * COLS + NS] = sl(st, i);
+        for (int j = 0; j < NS; j++) A[i * COLS + j] = ldt(st, NS + i * NS + j);
+        A[i * COLS + NS] = ldt(st, i);
     }
     shouseholder<T, NS, NM>(A);
     T chk = T(0);
@@ -391,14 +385,14 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     const bool bad = chk != chk;
     if (active && !bad) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) ss(st, i, A[i * COLS + NS]);
+        for (int i = 0; i < NS; i++) stt(st, i, A[i * COLS + NS]);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) ss(st, NS + i * NS + j, j >= i ? A[i * COLS + j] : T(0));
+            for (int j = 0; j < NS; j++) stt(st, NS + i * NS + j, j >= i ? A[i * COLS + j] : T(0));
         if constexpr (FULL) {
 #pragma unroll
-            for (int r = 0; r < NM; r++) ss(es, a.L.es_innov + r, A[(NS + r) * COLS + NS]);
+            for (int r = 0; r < NM; r++) stt(es, a.L.es_innov + r, A[(NS + r) * COLS + NS]);
         }
     }
     if (active && bad) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);

@@ -27,10 +27,6 @@ struct TilePtr {
     __device__ __forceinline__ TilePtr field(int first_elem) const { return TilePtr{base + (int64_t)first_elem * KB_TILE, lane}; }
 };
 template <typename T>
-__device__ __forceinline__ T ldt(const T *p, int e) { return p[(int64_t)e * KB_TILE]; }   // per-lane pointer form (generic kernel)
-template <typename T>
-__device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
-template <typename T>
 __device__ __forceinline__ T ldt(const TilePtr<T> &p, int e) { return p.ld(e); }
 template <typename T>
 __device__ __forceinline__ T ldt(const TilePtr<const T> &p, int e) { return p.ld(e); }
