@@ -68,6 +68,12 @@ int ensure_stage(Batch &b, size_t bytes) {
     return KB_OK;
 }
 
+int ensure_xp(Batch &b) {
+    if (b.d_xp) return KB_OK;
+    KB_HIP(hipMalloc(&b.d_xp, b.block_bytes(b.n + tri(b.n))));
+    return KB_OK;
+}
+
 int use_device(const Batch &b) {
     KB_HIP(hipSetDevice(b.device));
     return KB_OK;
@@ -260,7 +266,7 @@ void kb_destroy(kb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_est, b->d_model, b->d_status,
-                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas};
+                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -487,8 +493,9 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
     switch (field) {
     case KB_X: case KB_RAW_VEC: case KB_STATE:
         if (field == KB_STATE && (b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS)) {
-            KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
-            if ((rc = launch_materialise(*b, b->d_state, false, tmp))) { (void)hipFree(tmp); return rc; }
+            if ((rc = ensure_xp(*b))) return rc;
+            tmp = b->d_xp;
+            if ((rc = launch_materialise(*b, b->d_state, false, tmp))) return rc;
             block = tmp; block_elems = n + tri(n); out_elems = n; map_dense(1, n, 0, n, map);
         } else {
             block = b->d_state; block_elems = L.st_elems; out_elems = n; map_dense(1, n, L.st_vec, n, map);
@@ -497,9 +504,10 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
     case KB_P: case KB_COVAR: case KB_PRED_COVAR:
         if (field == KB_PRED_COVAR && (rc = need_full())) return rc;
         if (lazy) {
-            KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
+            if ((rc = ensure_xp(*b))) return rc;
+            tmp = b->d_xp;
             const bool pred = field == KB_PRED_COVAR;
-            if ((rc = launch_materialise(*b, pred ? b->d_est : b->d_state, pred, tmp))) { (void)hipFree(tmp); return rc; }
+            if ((rc = launch_materialise(*b, pred ? b->d_est : b->d_state, pred, tmp))) return rc;
             block = tmp; block_elems = n + tri(n); out_elems = n * n; map_sym_out(n, n, map);
         } else if (field == KB_PRED_COVAR) {
             block = b->d_est; block_elems = L.es_elems; out_elems = n * n; map_sym_out(n, L.es_ppred, map);
@@ -548,14 +556,13 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
         return KB_ERR_INVALID;
     }
     const size_t bytes = (size_t)count * out_elems * sizeof(double);
-    if ((rc = ensure_stage(*b, bytes))) { if (tmp) (void)hipFree(tmp); return rc; }
+    if ((rc = ensure_stage(*b, bytes))) return rc;
     rc = launch_unpack(*b, block, block_elems, map, out_elems, (double *)b->d_stage, first, count);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(host, b->d_stage, bytes, hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
         if (e != hipSuccess) rc = hip_fail(e, "kb_get copy");
     }
-    if (tmp) (void)hipFree(tmp);
     return rc;
 }
 
@@ -608,21 +615,20 @@ int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first
     const void *xp = b->d_state;
     const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS);
     if (lazy) {
-        KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
-        if ((rc = launch_materialise(*b, b->d_state, false, tmp))) { (void)hipFree(tmp); return rc; }
+        if ((rc = ensure_xp(*b))) return rc;
+        tmp = b->d_xp;
+        if ((rc = launch_materialise(*b, b->d_state, false, tmp))) return rc;
         xp = tmp;
     }
-    uint8_t *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_out, (size_t)b->ntiles * KB_TILE);
-    if (e != hipSuccess) { if (tmp) (void)hipFree(tmp); return hip_fail(e, "hipMalloc"); }
+    if (!b->d_flags) KB_HIP(hipMalloc((void **)&b->d_flags, (size_t)b->ntiles * KB_TILE));
+    uint8_t *d_out = b->d_flags;
+    hipError_t e = hipSuccess;
     rc = launch_within_nsigma(*b, xp, nsigma, d_out);
     if (!rc) {
         e = hipMemcpyAsync(host, d_out + first, (size_t)count, hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
         if (e != hipSuccess) rc = hip_fail(e, "copy");
     }
-    (void)hipFree(d_out);
-    if (tmp) (void)hipFree(tmp);
     return rc;
 }
 

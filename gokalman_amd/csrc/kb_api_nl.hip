@@ -145,12 +145,11 @@ int kb_smooth_all_dev(kb_batch *b, const void *phis, int64_t ld, int steps, void
     }
     const int n = b->n;
     if (b->kind == KB_SRIF) {
-        void *tmp = nullptr;
-        KB_HIP(hipMalloc(&tmp, b->block_bytes(n + tri(n))));
+        if ((rc = ensure_xp(*b))) return rc;
+        void *tmp = b->d_xp;
         rc = launch_materialise(*b, b->d_state, false, tmp);
         if (!rc) rc = launch_smooth(*b, tmp, n + tri(n), 0, n, phis, ld, steps, x_out, P_out);
         hipError_t e = hipStreamSynchronize(b->stream);
-        (void)hipFree(tmp);
         if (!rc && e != hipSuccess) rc = hip_fail(e, "kb_smooth_all_dev");
         return rc;
     }

@@ -46,6 +46,8 @@ struct Batch {
     size_t stage_bytes = 0;
     void *d_y = nullptr, *d_u = nullptr;  // AoSoA staging of host measurements / controls
     void *d_y2 = nullptr;
+    void *d_xp = nullptr;      // cached getter scratch: materialised State() | Covariance() (x[n] | P packed) per filter
+    uint8_t *d_flags = nullptr;  // cached IsWithinNsigma output
     double *d_mc = nullptr; size_t mc_bytes = 0;
     bool initialized = false;
     bool have[8] = {false, false, false, false, false, false, false, false};  // KB_X..KB_R staged
@@ -130,6 +132,7 @@ int mc_repl();
 // shared host helpers (kb_api.hip)
 int use_device(const Batch &b);
 int ensure_stage(Batch &b, size_t bytes);
+int ensure_xp(Batch &b);  // allocates Batch::d_xp on first use
 int stage_host_vec(Batch &b, const double *host, int rows, void **dblock);
 void fill_step_args(const Batch &b, StepArgs &a);
 int upload_field(Batch &b, int field, const double *host, int64_t count, int broadcast, int p_rows);
