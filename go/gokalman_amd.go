@@ -17,6 +17,7 @@ import "C"
 
 import (
 	"errors"
+	"fmt"
 	"math"
 	"runtime"
 	"time"
@@ -301,3 +302,26 @@ var _ gokalman.NLDKF = (*NLDKF)(nil)
 // MonteCarloRuns / NewMonteCarloRuns (montecarlo.go:12-59, 92-119) and NewChiSquare (chisquare.go:16-95)
 // bind kb_mc_run + kb_mc_stats and kb_chisquare the same way; the truth filter is a batch created with
 // nfilters = samples.
+
+// VanLoan computes F and Q from the continuous-time system A, Γ, W and the sampling period Δt
+// (gokalman.VanLoan, c2d.go:13-75) on the GPU.
+func VanLoan(A, Γ, W *mat64.Dense, Δt float64) (*mat64.Dense, *mat64.SymDense, error) {
+	n, _ := A.Dims()
+	_, q := Γ.Dims()
+	a, g, w := rowMajor(A), rowMajor(Γ), rowMajor(W)
+	f, qq := make([]float64, n*n), make([]float64, n*n)
+	var st C.uint32_t
+	dt := C.double(Δt)
+	if rc := C.kb_van_loan(0, C.KB_F64, C.int(n), C.int(q), 1, ptr(a), ptr(g), ptr(w), &dt, 15, ptr(f), ptr(qq), &st); rc != C.KB_OK {
+		return nil, nil, errors.New(C.GoString(C.kb_last_error()))
+	}
+	var err error
+	if st&C.KB_ST_NYQUIST != 0 {
+		err = fmt.Errorf("gokalman: Nyquist sampling criterion not fulfilled with Δt=%f", Δt)
+	}
+	var Q *mat64.SymDense
+	if st&C.KB_ST_ASYMMETRIC == 0 { // QSym, _ := AsSymDense(&Q): nil when asymmetric (c2d.go:73)
+		Q = mat64.NewSymDense(n, qq)
+	}
+	return mat64.NewDense(n, n, f), Q, err
+}

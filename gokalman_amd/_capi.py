@@ -13,7 +13,7 @@ VANILLA, VANILLA_PREDICT, SQUAREROOT, INFORMATION, SRIF, HYBRID, BATCH_LS = 1, 2
 F64, F32 = 0, 1
 FLAG_FULL_ESTIMATE, FLAG_STRICT_SYMCHECK, FLAG_INFO_FROM_STATE, FLAG_SRIF_NON_TRI_R = 1, 2, 4, 8
 OK, ERR_INVALID, ERR_DIMS, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_LOCKED, ERR_NOT_PD = 0, -1, -2, -3, -4, -5, -6, -7
-ST_SINGULAR, ST_ASYMMETRIC, ST_NONFINITE, ST_INFO_NOT_INVERTIBLE = 1, 2, 4, 8
+ST_SINGULAR, ST_ASYMMETRIC, ST_NONFINITE, ST_INFO_NOT_INVERTIBLE, ST_NYQUIST = 1, 2, 4, 8, 16
 X, P, F, G, H, Q, R = range(7)
 STATE, COVAR, PRED_COVAR, GAIN, INNOVATION, MEASUREMENT, RAW_VEC, RAW_MAT, RAW_PRED_MAT = range(16, 25)
 NOISE_NOISELESS, NOISE_AWGN, NOISE_BATCH = 0, 1, 2
@@ -61,6 +61,8 @@ SIGNATURES = {
     "kb_mc_run": (_i, [_vp, _i, _dp, _i, _i64, _dp]),
     "kb_chisquare": (_i, [_vp, _vp, _i, _dp, _i, _i64, _i, _i, _i, _dp]),
     "kb_mc_stats": (_i, [_dp, _i, _i, _i64, _dp, _dp]),
+    "kb_van_loan": (_i, [_i, _i, _i, _i, _i64, _dp, _dp, _dp, _dp, _i, _dp, _dp, C.POINTER(C.c_uint32)]),
+    "kb_van_loan_dev": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

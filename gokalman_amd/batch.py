@@ -339,3 +339,28 @@ def new_chi_square(kf, truth, steps, controls, with_nees=True, with_nis=True, fi
         sums = reduce(sums)
     runs = float(total_runs if total_runs is not None else truth.N)
     return sums[:, 0] / runs, sums[:, 1] / runs
+
+
+def van_loan(A, Gamma, W, dt, dtype=k.F64, device=0):
+    """VanLoan(A, Gamma, W, dt) (c2d.go:13-75) for one system or a batch: A [n][n] or [N][n][n], Gamma [..][n][q],
+    W [..][q][q], dt scalar or [N].  Returns (F, Q, status) with a leading batch axis iff any input had one;
+    status & ST_NYQUIST is the reference's "Nyquist sampling criterion not fulfilled" error value."""
+    A, Gamma, W, dt = (np.ascontiguousarray(v, dtype=np.float64) for v in (A, Gamma, W, dt))
+    n = A.shape[-1]
+    Gamma = Gamma.reshape(Gamma.shape[:-2] + (n, -1)) if Gamma.ndim >= 2 else Gamma.reshape(n, -1)
+    q = Gamma.shape[-1]
+    batched = [A.ndim == 3, Gamma.ndim == 3, W.ndim == 3, dt.ndim == 1]
+    sizes = {v.shape[0] for v, bt in zip((A, Gamma, W, dt), batched) if bt}
+    if len(sizes) > 1:
+        raise ValueError("van_loan: batched arguments disagree on N: %s" % sorted(sizes))
+    N = sizes.pop() if sizes else 1
+    if A.shape[-2:] != (n, n) or W.shape[-2:] != (q, q):
+        raise ValueError("van_loan: A must be n x n, Gamma n x q, W q x q")
+    bc = sum(bit for bit, bt in zip((1, 2, 4, 8), batched) if not bt)
+    F, Q = np.zeros((N, n, n)), np.zeros((N, n, n))
+    st = np.zeros(N, dtype=np.uint32)
+    k.check(k.lib().kb_van_loan(device, dtype, n, q, N, _ptr(A), _ptr(Gamma), _ptr(W), _ptr(dt.reshape(-1)), bc,
+                                _ptr(F), _ptr(Q), st.ctypes.data_as(C.POINTER(C.c_uint32))))
+    if not any(batched):
+        return F[0], Q[0], int(st[0])
+    return F, Q, st

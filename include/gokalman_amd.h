@@ -82,6 +82,7 @@ typedef enum {
 #define KB_ST_SINGULAR 0x1u   /* inverse failed or cond > 1e16: vanilla.go:164-167, hybrid.go:150-152, srif.go:112-114 */
 #define KB_ST_ASYMMETRIC 0x2u /* AsSymDense failure: vanilla.go:207-215, information.go:214-222 (a panic there)        */
 #define KB_ST_NONFINITE 0x4u  /* NaN/Inf reached the estimate                                                          */
+#define KB_ST_NYQUIST 0x10u   /* kb_van_loan: "Nyquist sampling criterion not fulfilled" (c2d.go:26-28); F, Q are still valid */
 #define KB_ST_INFO_NOT_INVERTIBLE 0x8u /* getter-side: information/SRIF matrix not (yet) invertible, covariance reported as zeros (information.go:284-288) */
 
 /* Fields for kb_set / kb_get. */
@@ -252,6 +253,23 @@ int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols,
 /* MonteCarloRuns.Mean / StdDev (montecarlo.go:18-59) from (all-reduced) sums over
  * `runs` runs: mean[steps][n], stddev[steps][n] (unbiased, n-1, as gonum stat.StdDev). */
 int kb_mc_stats(const double *sums, int steps, int n, int64_t runs, double *mean, double *stddev);
+
+/* ---- VanLoan continuous -> discrete conversion (c2d.go:13-75) ------------------------------ */
+/* VanLoan(A, Gamma, W, dt) for N independent systems: A n x n, Gamma n x q, W q x q (row-major), dt scalar
+ *   -> F = exp(A dt) n x n and Q n x n (symmetric: upper triangle mirrored, as AsSymDense returns it),
+ * computed from exp([[-A dt, Gamma W Gamma^T dt], [0, A^T dt]]) like the reference.  n <= 8.
+ * Host arrays hold N consecutive matrices, or one when the matching `broadcast` bit is set
+ * (1 = A, 2 = Gamma, 4 = W, 8 = dt).  status[i] (may be NULL): KB_ST_NYQUIST = the reference's error
+ * value (F and Q are valid next to it, c2d.go:26-28,74), KB_ST_ASYMMETRIC = the reference's QSym would
+ * be nil (c2d.go:73), KB_ST_SINGULAR / KB_ST_NONFINITE = the Pade system of the exponential broke down.
+ * The arithmetic runs in `dtype`. */
+int kb_van_loan(int device, int dtype, int n, int q, int64_t N, const double *A, const double *Gamma,
+                const double *W, const double *dt, int broadcast, double *F, double *Q, uint32_t *status);
+/* Same on HBM-resident planar arrays in `dtype` (element e of system i at ptr[e*ld + i], dt[i]); F and Q
+ * come out in the layout kb_set_dev(KB_F / KB_Q) reads.  Asynchronous on `stream` (a hipStream_t, e.g.
+ * kb_stream(b); NULL = the default stream) of the current device. */
+int kb_van_loan_dev(int dtype, int n, int q, int64_t N, const void *A, const void *Gamma, const void *W,
+                    const void *dt, int64_t ld, void *F, void *Q, uint32_t *status, void *stream);
 
 /* ---- chi-square consistency tests (chisquare.go:16-95) ------------------------------------- */
 /* NewChiSquare(kf, runs, controls, withNEES, withNIS) fused with the truth generation of

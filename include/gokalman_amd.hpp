@@ -322,4 +322,18 @@ inline std::pair<std::vector<double>, std::vector<double>> NewChiSquare(Vanilla 
     return {nis, nees};
 }
 
+// VanLoan(A, Gamma, W, dt) (F, Q, error)   c2d.go:13-75.  The reference returns its Nyquist error NEXT to valid F and Q;
+// here `nyquist` carries it ("gokalman: Nyquist sampling criterion not fulfilled with dt=...").
+struct VanLoanResult { Matrix F, Q; bool nyquist = false; };
+inline VanLoanResult VanLoan(const Matrix &A, const Matrix &Gamma, const Matrix &W, double dt, int device = 0) {
+    if (A.rows != A.cols || Gamma.rows != A.rows || W.rows != W.cols || W.rows != Gamma.cols)
+        throw Error(KB_ERR_DIMS, "dimensions must agree: A(nxn) Gamma(nxq) W(qxq)");
+    VanLoanResult r{Matrix(A.rows, A.rows), Matrix(A.rows, A.rows), false};
+    uint32_t st = 0;
+    check(kb_van_loan(device, KB_F64, A.rows, Gamma.cols, 1, A.data.data(), Gamma.data.data(), W.data.data(), &dt, 15, r.F.data.data(),
+                      r.Q.data.data(), &st));
+    r.nyquist = (st & KB_ST_NYQUIST) != 0;
+    return r;
+}
+
 }  // namespace gokalman

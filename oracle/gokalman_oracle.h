@@ -157,6 +157,13 @@ int orc_smooth_all(int n, int steps, const double *Phi, double *x, double *P);
 void orc_mc_mean_stddev(long runs, int n, const double *states,
                         double *mean, double *stddev);
 
+/* --- VanLoan (c2d.go:13-75), vanloan_oracle.c --------------------------------- */
+int orc_expm(int n, const double *A, double *E);                       /* mat64.Dense.Exp */
+int orc_eigvals(int n, const double *A, double *wr, double *wi);       /* mat64.Eigen values */
+/* returns bit 0 = Nyquist error, bit 1 = Q asymmetric (QSym nil) */
+int orc_van_loan(int n, int q, const double *A, const double *Gamma, const double *W, double dt,
+                 double *F, double *Q);
+
 #ifdef __cplusplus
 }
 #endif

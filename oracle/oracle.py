@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libgokalman_oracle.so")
-_SRC = [os.path.join(_HERE, "gokalman_oracle.c"), os.path.join(_HERE, "gokalman_oracle.h")]
+_SRC = [os.path.join(_HERE, f) for f in ("gokalman_oracle.c", "vanloan_oracle.c", "gokalman_oracle.h")]
 
 VANILLA, VANILLA_PREDICT, SQUAREROOT, INFORMATION, SRIF, HYBRID, BATCH_LS = 1, 2, 3, 4, 5, 6, 7
 OK, ERR_SINGULAR, ERR_ASYMMETRIC, ERR_LOCKED, ERR_DIMS, ERR_NOTPD = 0, 1, 2, 3, 4, 5
@@ -79,6 +79,9 @@ def lib():
         L.orc_max_threads.restype = C.c_int
         L.orc_mc_mean_stddev.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp]
         L.orc_smooth_all.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        L.orc_expm.argtypes = [C.c_int, _dp, _dp]
+        L.orc_eigvals.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.orc_van_loan.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp]
         _lib = L
     return _lib
 
@@ -355,3 +358,31 @@ def smooth_all(Phi, x_last, P_last):
     x[-1], P[-1] = x_last, P_last
     rc = lib().orc_smooth_all(n, steps, _p(Phi), x.ctypes.data_as(_dp), P.ctypes.data_as(_dp))
     return rc, x, P
+
+
+def expm(A):
+    """mat64.Dense.Exp (Higham 2005 scaling and squaring)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    E = np.zeros_like(A)
+    lib().orc_expm(A.shape[0], _p(A), E.ctypes.data_as(_dp))
+    return E
+
+
+def eigvals(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    wr, wi = np.zeros(n), np.zeros(n)
+    rc = lib().orc_eigvals(n, _p(A), wr.ctypes.data_as(_dp), wi.ctypes.data_as(_dp))
+    return rc, wr + 1j * wi
+
+
+def van_loan(A, Gamma, W, dt):
+    """VanLoan(A, Gamma, W, dt) (c2d.go:13-75) -> (rc, F, Q); rc bit 0 = Nyquist error, bit 1 = Q asymmetric."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    Gamma = np.ascontiguousarray(Gamma, dtype=np.float64).reshape(n, -1)
+    q = Gamma.shape[1]
+    W = np.ascontiguousarray(W, dtype=np.float64).reshape(q, q)
+    F, Q = np.zeros((n, n)), np.zeros((n, n))
+    rc = lib().orc_van_loan(n, q, _p(A), _p(Gamma), _p(W), float(dt), F.ctypes.data_as(_dp), Q.ctypes.data_as(_dp))
+    return rc, F, Q
