@@ -94,8 +94,11 @@ def _nl_models(N, n, p, steps, rng):
     return Phi, Ht, real, comp
 
 
+@pytest.mark.parametrize("pivoting", [False, True])
 @pytest.mark.parametrize("n,p,dtype,tol", [(6, 2, k.F64, 1e-9), (12, 6, k.F64, 1e-9), (12, 6, k.F32, 2e-3)])
-def test_srif_vs_oracle(n, p, dtype, tol):
+def test_srif_vs_oracle(n, p, dtype, tol, pivoting):
+    """pivoting: Phi = (a different row permutation per filter and step) x (I + noise), so the partial pivoting of
+    Phi's LU exchanges rows, differently in every lane of a wave."""
     rng = np.random.default_rng(7)
     N, steps = 96, 5
     x0 = rng.standard_normal((N, n))
@@ -104,6 +107,10 @@ def test_srif_vs_oracle(n, p, dtype, tol):
     R = np.zeros((N, p, p))
     R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
     Phi, Ht, real, comp = _nl_models(N, n, p, steps, rng)
+    if pivoting:
+        for t in range(steps):
+            for i in range(N):
+                Phi[t, i] = Phi[t, i][rng.permutation(n)]
     b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dtype, flags=k.FLAG_FULL_ESTIMATE)
     b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
     with pytest.raises(ga.KalmanError, match=r"kf is locked \(call Prepare\(\) first\)"):
