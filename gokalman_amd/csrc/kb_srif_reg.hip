@@ -29,7 +29,7 @@ __device__ __forceinline__ int nib(uint64_t perm, int r) { return (int)((perm >>
 // select, skipped wave-uniformly when no lane needs one), the factors stay there for the 12 row solves, and LDS
 // is only the scatter buffer that undoes the row permutation (24 floats per lane).
 template <typename T, int NS, bool FULL, bool EXT>
-__global__ void __launch_bounds__(256, 2) srif_time_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(256, (sizeof(T) * NS * NS > 600 ? 1 : 2)) srif_time_kernel(const StepArgs a) {
     constexpr int RG = 2;
     __shared__ T lds[4 * RG * NS * KB_TILE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -289,13 +289,13 @@ static bool srif_try(const Batch &b, const StepArgs &a) {
 
 bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if (b.dtype == KB_F32) return srif_shape_ok(a, 12, 6) || srif_shape_ok(a, 6, 2);
-    return srif_shape_ok(a, 6, 2);
+    return srif_shape_ok(a, 6, 2) || srif_shape_ok(a, 12, 6);
 }
 
 int launch_srif(const Batch &b, const StepArgs &a) {
     bool done = false;
     if (b.dtype == KB_F32) done = srif_try<float, 12, 6>(b, a) || srif_try<float, 6, 2>(b, a);
-    else done = srif_try<double, 6, 2>(b, a);
+    else done = srif_try<double, 6, 2>(b, a) || srif_try<double, 12, 6>(b, a);
     if (!done) return launch_srif_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;
