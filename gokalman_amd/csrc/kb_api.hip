@@ -167,7 +167,7 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     a.state = b.d_state; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status;
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
-    a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p;
+    a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p; a.srif_tri = b.srif_tri;
     a.ekf = b.ekf; a.snc = b.snc; a.predict = (b.kind == KB_VANILLA_PREDICT);
     a.noise_kind = b.noise_kind; a.seed = b.seed; a.epoch = b.epoch; a.step0 = b.step; a.first_filter = 0;
     a.bn_proc = b.d_bn_proc; a.bn_meas = b.d_bn_meas; a.bn_p = b.bn_p;
@@ -383,7 +383,7 @@ int kb_reset(kb_batch *b) {
     KB_HIP(hipStreamSynchronize(b->stream));
     b->step = 0;
     b->epoch++;  // AWGN.Reset re-seeds (noise.go:145-146)
-    if (is_nldkf(b->kind)) { b->locked = 1; b->snc = 0; }
+    if (is_nldkf(b->kind)) { b->locked = 1; b->snc = 0; b->srif_tri = 1; }
     return KB_OK;
 }
 

@@ -79,6 +79,7 @@ static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
     }
     if ((rc = launch_nl(b, a))) return rc;
     b->step++;
+    b->srif_tri = predict ? 0 : 1;  // Predict() leaves the full RBar in R (srif.go:134-141), an Update a triangular R_k
     b->snc = 0;     // hybrid.go:201
     b->locked = 1;  // srif.go:158, hybrid.go:202
     return KB_OK;

@@ -53,6 +53,7 @@ struct Batch {
     bool have[8] = {false, false, false, false, false, false, false, false};  // KB_X..KB_R staged
     int need_ctrl = 0;
     int64_t step = 0;
+    int srif_tri = 1;      // KB_SRIF: R is upper triangular (constructor / measurement update wrote it; Predict() stores the full RBar)
     int rinv_p = 0;        // KB_INFORMATION: dimension R^-1 was computed for (stale-Rinv quirk)
     int sqrt_p = 0;        // KB_SQUAREROOT: dimension of chol(R)
     int r_p = 0;           // dimension of the R last given to kb_set
@@ -92,6 +93,7 @@ struct StepArgs {
     unsigned flags;
     int need_ctrl;
     int rinv_p, sqrt_p;
+    int srif_tri;                               // KB_SRIF: R is upper triangular (last writer: constructor or a measurement update)
     int ekf, snc, predict;
     int noise_kind; uint64_t seed; int64_t epoch; int64_t step0; int64_t first_filter;
     const void *bn_proc, *bn_meas; int bn_p;     // BatchNoise: [step][n], [step][bn_p]

@@ -267,6 +267,219 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     if (active && bad) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
 }
 
+// ---- fused Update for an upper-triangular R (the steady state) -----------------------------------
+// R is upper triangular whenever its last writer was a measurement update (srif.go:334-337 zeroes the
+// sub-columns) or the constructor (R0 diagonal, srif.go:20-29); the host tracks that (Batch::srif_tri, cleared by
+// Predict(), which stores the full RBar).  Then the whole Update runs in one launch and RBar never goes to memory:
+//   A  x = R^-1 b by back substitution; Phi -> VGPRs, xBar = Phi x; P Phi = L U in VGPRs; rows of RBar = R Phi^-1 two at
+//      a time (the zeros of R's rows skipped), scattered with the row permutation undone into the LDS panel [RBar | bBar];
+//   B  bottom block [L Htilde | L y] -> VGPRs, the panel LDS -> VGPRs, Householder, store b and the upper triangle of R.
+// Per filter 339 values read, 90 written (1716 B in fp32) against the 2304 algorithmic bytes of the two-pass statement.
+// One private [element][lane] LDS array per lane (conflict-free, no barriers: a lane only reads what it wrote).
+template <typename T, int NS>
+constexpr bool srif_fused_fits() { return sizeof(T) * 4 * NS * (NS + 1) * KB_TILE <= 160 * 1024; }
+
+template <typename T, int NS, int NM, bool FULL, bool EXT>
+__global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
+    constexpr int COLS = NS + 1, RG = 2;
+    static_assert(NS % RG == 0, "row groups");
+    __shared__ T lds[srif_fused_fits<T, NS>() ? 4 * NS * COLS * KB_TILE : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool inb = fi < a.N;
+    const bool active = inb && (a.status[inb ? fi : 0] & (KB_ST_SINGULAR | KB_ST_ASYMMETRIC | KB_ST_NONFINITE)) == 0u;  // failed earlier: frozen
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *ephi = EXT ? (const T *)a.ext_phi + (inb ? fi : 0) : nullptr;
+    const T *eh = EXT ? (const T *)a.ext_h + (inb ? fi : 0) : nullptr;
+    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
+    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
+    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
+    T *panel = lds + wv * (NS * COLS * KB_TILE) + lane;   // element (i, c) at panel[(i * COLS + c) * KB_TILE]
+    unsigned err = 0;
+    T xprev[NS];
+    {   // State(prev) = R^-1 b by back substitution (srif.go:223-234); the rows of R wait in the LDS panel for phase A's solves
+        T Ru[tri(NS)];   // upper triangle of R, Ru[symi(i, j)], i <= j
+#pragma unroll
+        for (int i = 0; i < NS; i++) xprev[i] = ldt(st, i);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) Ru[symi(i, j)] = ldt(st, NS + i * NS + j);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) panel[(i * COLS + j) * KB_TILE] = Ru[symi(i, j)];
+#pragma unroll
+        for (int i = NS - 1; i >= 0; i--) {
+            T sum = xprev[i];
+#pragma unroll
+            for (int k2 = i + 1; k2 < NS; k2++) sum -= Ru[symi(i, k2)] * xprev[k2];
+            if (Ru[symi(i, i)] == T(0)) err |= KB_ST_SINGULAR;
+            xprev[i] = sum * (T(1) / Ru[symi(i, i)]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    T lu[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {   // xBar = Phi State(prev) (srif.go:118) -> LDS, read back in pivoted order below
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const T v = EXT ? __builtin_nontemporal_load(ephi + (int64_t)(i * NS + j) * a.ext_ld) : ldnt(mo, a.L.mo_F + i * NS + j);
+            lu[i * NS + j] = v;
+            s += v * xprev[j];
+        }
+        panel[(i * COLS + NS) * KB_TILE] = s;   // the bBar slots are free until the solves
+    }
+    // P Phi = L U (srif.go:111-114's Inverse = Dgetrf + ...): nibble k of perm = original index of the row now in position k
+    uint64_t perm = 0xBA9876543210ull;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+#pragma unroll
+        for (int r = j + 1; r < NS; r++) {
+            const bool sw = fabs(lu[r * NS + j]) > fabs(lu[j * NS + j]);
+            if (__any(sw)) {
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    const T t0 = lu[j * NS + c], t1 = lu[r * NS + c];
+                    lu[j * NS + c] = sw ? t1 : t0;
+                    lu[r * NS + c] = sw ? t0 : t1;
+                }
+                const uint64_t x = sw ? (((perm >> (4 * j)) ^ (perm >> (4 * r))) & 15u) : 0u;
+                perm ^= (x << (4 * j)) | (x << (4 * r));
+            }
+        }
+        const T piv = lu[j * NS + j];
+        if (piv == T(0)) err |= KB_ST_SINGULAR;
+        const T rp = T(1) / piv;
+        lu[j * NS + j] = rp;   // the solves multiply by the reciprocal
+#pragma unroll
+        for (int r = j + 1; r < NS; r++) {
+            const T l = lu[r * NS + j] * rp;
+            lu[r * NS + j] = l;
+#pragma unroll
+            for (int c = j + 1; c < NS; c++) lu[r * NS + c] -= l * lu[j * NS + c];
+        }
+    }
+    if (err) { if (active) atomicOr(a.status + fi, err); return; }
+    int poff[NS];
+    T xBarP[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+        poff[r] = nib(perm, r) * KB_TILE;
+        xBarP[r] = panel[nib(perm, r) * (COLS * KB_TILE) + NS * KB_TILE];
+    }
+    // RBar = R Phi^-1 (srif.go:115): row i solves z Phi = R[i,:], i.e. w U = r, v L = w, z[perm_k] = v_k; R[i, c] = 0 for c < i
+#pragma unroll
+    for (int i0 = 0; i0 < NS; i0 += RG) {
+        T z[RG][NS];
+#pragma unroll
+        for (int g = 0; g < RG; g++)
+#pragma unroll
+            for (int c = 0; c < NS; c++) z[g][c] = c >= i0 + g ? panel[((i0 + g) * COLS + c) * KB_TILE] : T(0);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {      // constant trip counts everywhere: the structural-zero tests fold after unrolling
+#pragma unroll
+            for (int g = 0; g < RG; g++) {
+                if (j >= i0 + g) {
+                    T sum = z[g][j];
+#pragma unroll
+                    for (int k2 = 0; k2 < NS; k2++)
+                        if (k2 >= i0 + g && k2 < j) sum -= z[g][k2] * lu[k2 * NS + j];
+                    z[g][j] = sum * lu[j * NS + j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = NS - 2; j >= 0; j--) {
+#pragma unroll
+            for (int g = 0; g < RG; g++) {
+                T sum = z[g][j];
+#pragma unroll
+                for (int k2 = j + 1; k2 < NS; k2++) sum -= z[g][k2] * lu[k2 * NS + j];
+                z[g][j] = sum;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < RG; g++) {
+            T bb = T(0);
+#pragma unroll
+            for (int r = 0; r < NS; r++) {
+                bb += z[g][r] * xBarP[r];                                   // :119 bBar = RBar xBar (pivoted order)
+                panel[poff[r] + (i0 + g) * COLS * KB_TILE] = z[g][r];       // row permutation undone by the scatter
+            }
+            panel[((i0 + g) * COLS + NS) * KB_TILE] = bb;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- measurement update (srif.go:143-156, :298-340): Householder on [[RBar bBar],[L Htilde, L y]]
+    T A[(NS + NM) * COLS];
+    {
+        T Lw[tri(NM)], yv[NM];
+#pragma unroll
+        for (int e = 0; e < tri(NM); e++) Lw[e] = ldnt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
+#pragma unroll
+        for (int r = 0; r < NM; r++) {
+            const T re = inb ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
+            const T co = inb ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
+            yv[r] = re - co;
+            if constexpr (FULL) { if (active) stt(es, a.L.es_yhat + r, re); }
+        }
+#pragma unroll
+        for (int r = 0; r < NM; r++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) A[(NS + r) * COLS + j] = T(0);
+#pragma unroll
+        for (int l = 0; l < NM; l++) {
+            T Hl[NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++) Hl[j] = EXT ? __builtin_nontemporal_load(eh + (int64_t)(l * NS + j) * a.ext_ld) : ldnt(mo, a.L.mo_H + l * NS + j);
+#pragma unroll
+            for (int r = l; r < NM; r++)
+#pragma unroll
+                for (int j = 0; j < NS; j++) A[(NS + r) * COLS + j] += Lw[symi(l, r)] * Hl[j];  // (L Htilde)[r][j], l <= r
+        }
+#pragma unroll
+        for (int r = 0; r < NM; r++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l <= r; l++) s += Lw[symi(l, r)] * yv[l];
+            A[(NS + r) * COLS + NS] = s;
+            if constexpr (FULL) { if (active) stt(es, a.L.es_dobs + r, s); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < COLS; j++) {
+            A[i * COLS + j] = panel[(i * COLS + j) * KB_TILE];
+            if constexpr (FULL) { if (active && j < NS) stt(es, a.L.es_ppred + i * NS + j, A[i * COLS + j]); }
+        }
+    shouseholder<T, NS, NM>(A);
+    T chk = T(0);
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = i; j < COLS; j++) chk += A[i * COLS + j] * T(0);
+    const bool bad = chk != chk;
+    if (active && !bad) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) stt(st, i, A[i * COLS + NS]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) stt(st, NS + i * NS + j, A[i * COLS + j]);   // the lower triangle holds zeros already
+        if constexpr (FULL) {
+#pragma unroll
+            for (int r = 0; r < NM; r++) stt(es, a.L.es_innov + r, A[(NS + r) * COLS + NS]);
+        }
+    }
+    if (active && bad) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
+}
+
 static bool srif_shape_ok(const StepArgs &a, int NS, int NM) { return a.n == NS && a.p == NM; }
 
 template <typename T, int NS, int NM>
@@ -274,6 +487,15 @@ static bool srif_try(const Batch &b, const StepArgs &a) {
     if (!srif_shape_ok(a, NS, NM)) return false;
     const dim3 grid = tile_grid(a.ntiles), block(256);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
+    if constexpr (srif_fused_fits<T, NS>()) {
+        if (!a.predict && a.srif_tri) {
+#define KB_F(F_, E_) hipLaunchKernelGGL((srif_fused_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
+            if (full) { if (ext) KB_F(true, true); else KB_F(true, false); }
+            else      { if (ext) KB_F(false, true); else KB_F(false, false); }
+#undef KB_F
+            return true;
+        }
+    }
 #define KB_T(F_, E_) hipLaunchKernelGGL((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a)
 #define KB_M(F_, E_) hipLaunchKernelGGL((srif_meas_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
     if (full) { if (ext) KB_T(true, true); else KB_T(true, false); }
