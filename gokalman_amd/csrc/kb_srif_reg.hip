@@ -276,17 +276,48 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
 //   B  bottom block [L Htilde | L y] -> VGPRs, the panel LDS -> VGPRs, Householder, store b and the upper triangle of R.
 // Per filter 339 values read, 90 written (1716 B in fp32) against the 2304 algorithmic bytes of the two-pass statement.
 // One private [element][lane] LDS array per lane (conflict-free, no barriers: a lane only reads what it wrote).
+// helper.go:142-172 HouseholderTransf like kb_static.h's shouseholder, calling row_done(k) as soon as row k is final
+// (after step k nothing touches it again), so that finished rows leave the register file early.
+template <typename T, int NN, int MM, typename F>
+__device__ __forceinline__ void shouseholder_rows(T (&A)[(NN + MM) * (NN + 1)], F &&row_done) {
+    constexpr int ROWS = NN + MM, COLS = NN + 1;
+#pragma unroll
+    for (int k = 0; k < NN; k++) {
+        T sigma = T(0);
+#pragma unroll
+        for (int i = k; i < ROWS; i++) sigma += A[i * COLS + k] * A[i * COLS + k];
+        const T akk = A[k * COLS + k];
+        const T sgn = (akk == T(0) || fabs(akk) <= T(1e-12)) ? T(1) : copysign(T(1), akk);  // helper.go:133-138 Sign
+        sigma = sqrt(sigma) * sgn;
+        const T uk = akk + sigma;
+        A[k * COLS + k] = -sigma;
+        const T beta = T(1) / (sigma * uk);
+#pragma unroll
+        for (int j = k + 1; j < COLS; j++) {
+            T gamma = uk * A[k * COLS + j];
+#pragma unroll
+            for (int i = k + 1; i < ROWS; i++) gamma += A[i * COLS + k] * A[i * COLS + j];
+            gamma *= beta;
+            A[k * COLS + j] = A[k * COLS + j] - gamma * uk;
+#pragma unroll
+            for (int i = k + 1; i < ROWS; i++) A[i * COLS + j] = A[i * COLS + j] - gamma * A[i * COLS + k];
+        }
+        row_done(k);
+    }
+}
+
 template <typename T, int NS>
 constexpr bool srif_fused_fits() { return sizeof(T) * 4 * NS * (NS + 1) * KB_TILE <= 160 * 1024; }
 
 template <typename T, int NS, int NM, bool FULL, bool EXT>
-__global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
     constexpr int COLS = NS + 1, RG = 2;
     static_assert(NS % RG == 0, "row groups");
-    __shared__ T lds[srif_fused_fits<T, NS>() ? 4 * NS * COLS * KB_TILE : 1];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
-    if (tile >= a.ntiles) return;
+    // one wave per workgroup: the four waves of a CU are scheduled independently and drift apart, so that one wave's
+    // load phase overlaps another's arithmetic (a 4-wave workgroup keeps them in lockstep)
+    __shared__ T lds[srif_fused_fits<T, NS>() ? NS * COLS * KB_TILE : 1];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
     const int64_t fi = tile * KB_TILE + lane;
     const bool inb = fi < a.N;
     const bool active = inb && (a.status[inb ? fi : 0] & (KB_ST_SINGULAR | KB_ST_ASYMMETRIC | KB_ST_NONFINITE)) == 0u;  // failed earlier: frozen
@@ -297,10 +328,13 @@ __global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
     const T *yr = (const T *)a.y + tile * a.y_ts + lane;
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
     T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
-    T *panel = lds + wv * (NS * COLS * KB_TILE) + lane;   // element (i, c) at panel[(i * COLS + c) * KB_TILE]
+    T *panel = lds + lane;   // element (i, c) at panel[(i * COLS + c) * KB_TILE]
     unsigned err = 0;
-    T xprev[NS];
-    {   // State(prev) = R^-1 b by back substitution (srif.go:223-234); the rows of R wait in the LDS panel for phase A's solves
+    // Every input of the step is requested before the first use (339 values per lane in flight; the 512-register budget
+    // of one wave per SIMD holds them), so a wave waits for memory once instead of once per phase.
+    T xprev[NS], lu[NS * NS], Hh[NM * NS], Lw[tri(NM)], yv[NM];
+    [[maybe_unused]] T yreal[NM];
+    {
         T Ru[tri(NS)];   // upper triangle of R, Ru[symi(i, j)], i <= j
 #pragma unroll
         for (int i = 0; i < NS; i++) xprev[i] = ldt(st, i);
@@ -308,6 +342,21 @@ __global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
         for (int i = 0; i < NS; i++)
 #pragma unroll
             for (int j = i; j < NS; j++) Ru[symi(i, j)] = ldt(st, NS + i * NS + j);
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) lu[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
+#pragma unroll
+        for (int e = 0; e < NM * NS; e++) Hh[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
+#pragma unroll
+        for (int e = 0; e < tri(NM); e++) Lw[e] = ldnt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
+#pragma unroll
+        for (int r = 0; r < NM; r++) {
+            const T re = inb ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
+            const T co = inb ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
+            yv[r] = re - co;
+            if constexpr (FULL) yreal[r] = re;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // State(prev) = R^-1 b by back substitution (srif.go:223-234); the rows of R wait in the LDS panel for the solves
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -321,17 +370,11 @@ __global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
             xprev[i] = sum * (T(1) / Ru[symi(i, i)]);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    T lu[NS * NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) {   // xBar = Phi State(prev) (srif.go:118) -> LDS, read back in pivoted order below
         T s = T(0);
 #pragma unroll
-        for (int j = 0; j < NS; j++) {
-            const T v = EXT ? __builtin_nontemporal_load(ephi + (int64_t)(i * NS + j) * a.ext_ld) : ldnt(mo, a.L.mo_F + i * NS + j);
-            lu[i * NS + j] = v;
-            s += v * xprev[j];
-        }
+        for (int j = 0; j < NS; j++) s += lu[i * NS + j] * xprev[j];
         panel[(i * COLS + NS) * KB_TILE] = s;   // the bBar slots are free until the solves
     }
     // P Phi = L U (srif.go:111-114's Inverse = Dgetrf + ...): nibble k of perm = original index of the row now in position k
@@ -418,30 +461,21 @@ __global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
     // ---- measurement update (srif.go:143-156, :298-340): Householder on [[RBar bBar],[L Htilde, L y]]
     T A[(NS + NM) * COLS];
     {
-        T Lw[tri(NM)], yv[NM];
+        if constexpr (FULL) {
+            if (active) {
 #pragma unroll
-        for (int e = 0; e < tri(NM); e++) Lw[e] = ldnt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
-#pragma unroll
-        for (int r = 0; r < NM; r++) {
-            const T re = inb ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
-            const T co = inb ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
-            yv[r] = re - co;
-            if constexpr (FULL) { if (active) stt(es, a.L.es_yhat + r, re); }
+                for (int r = 0; r < NM; r++) stt(es, a.L.es_yhat + r, yreal[r]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < NM; r++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) A[(NS + r) * COLS + j] = T(0);
+            for (int j = 0; j < NS; j++) {
+                T s = T(0);
 #pragma unroll
-        for (int l = 0; l < NM; l++) {
-            T Hl[NS];
-#pragma unroll
-            for (int j = 0; j < NS; j++) Hl[j] = EXT ? __builtin_nontemporal_load(eh + (int64_t)(l * NS + j) * a.ext_ld) : ldnt(mo, a.L.mo_H + l * NS + j);
-#pragma unroll
-            for (int r = l; r < NM; r++)
-#pragma unroll
-                for (int j = 0; j < NS; j++) A[(NS + r) * COLS + j] += Lw[symi(l, r)] * Hl[j];  // (L Htilde)[r][j], l <= r
-        }
+                for (int l = 0; l <= r; l++) s += Lw[symi(l, r)] * Hh[l * NS + j];  // (L Htilde)[r][j], l <= r
+                A[(NS + r) * COLS + j] = s;
+            }
 #pragma unroll
         for (int r = 0; r < NM; r++) {
             T s = T(0);
@@ -458,26 +492,27 @@ __global__ void __launch_bounds__(256, 1) srif_fused_kernel(const StepArgs a) {
             A[i * COLS + j] = panel[(i * COLS + j) * KB_TILE];
             if constexpr (FULL) { if (active && j < NS) stt(es, a.L.es_ppred + i * NS + j, A[i * COLS + j]); }
         }
-    shouseholder<T, NS, NM>(A);
+    // A non-finite result is stored as it is (what the reference's unguarded HouseholderTransf leaves behind,
+    // helper.go:142-172) and flagged in the status word.
     T chk = T(0);
+    shouseholder_rows<T, NS, NM>(A, [&](int k) {
 #pragma unroll
-    for (int i = 0; i < NS; i++)
+        for (int j = 0; j < COLS; j++)
+            if (j >= k) chk += A[k * COLS + j] * T(0);
+        if (active) {
+            stt(st, k, A[k * COLS + NS]);
 #pragma unroll
-        for (int j = i; j < COLS; j++) chk += A[i * COLS + j] * T(0);
-    const bool bad = chk != chk;
-    if (active && !bad) {
-#pragma unroll
-        for (int i = 0; i < NS; i++) stt(st, i, A[i * COLS + NS]);
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i; j < NS; j++) stt(st, NS + i * NS + j, A[i * COLS + j]);   // the lower triangle holds zeros already
-        if constexpr (FULL) {
+            for (int j = 0; j < NS; j++)
+                if (j >= k) stt(st, NS + k * NS + j, A[k * COLS + j]);   // the lower triangle holds zeros already
+        }
+    });
+    if constexpr (FULL) {
+        if (active) {
 #pragma unroll
             for (int r = 0; r < NM; r++) stt(es, a.L.es_innov + r, A[(NS + r) * COLS + NS]);
         }
     }
-    if (active && bad) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
+    if (active && chk != chk) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
 }
 
 static bool srif_shape_ok(const StepArgs &a, int NS, int NM) { return a.n == NS && a.p == NM; }
@@ -489,7 +524,7 @@ static bool srif_try(const Batch &b, const StepArgs &a) {
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
     if constexpr (srif_fused_fits<T, NS>()) {
         if (!a.predict && a.srif_tri) {
-#define KB_F(F_, E_) hipLaunchKernelGGL((srif_fused_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
+#define KB_F(F_, E_) hipLaunchKernelGGL((srif_fused_kernel<T, NS, NM, F_, E_>), dim3((unsigned)a.ntiles), dim3(64), 0, b.stream, a)
             if (full) { if (ext) KB_F(true, true); else KB_F(true, false); }
             else      { if (ext) KB_F(false, true); else KB_F(false, false); }
 #undef KB_F
