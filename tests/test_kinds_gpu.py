@@ -121,14 +121,15 @@ def test_srif_vs_oracle(n, p, dtype, tol, pivoting):
             est = b.predict_nl()
         else:
             est = b.update_nl(real[t], comp[t])
-    bs, Rs, xs, Ps = [], [], [], []
+    bs, Rs, xs, Ps, Pm = [], [], [], [], []
     for i in range(N):
         f = orc.Filter.srif(x0[i], P0[i], R[i], p)
         for t in range(steps):
             f.prepare(Phi[t, i], Ht[t, i])
             assert (f.predict_nl() if t == 2 else f.update_nl(real[t, i], comp[t, i])) == orc.OK
-        bs.append(f.raw_vec()); Rs.append(f.raw_mat()); xs.append(f.state()); Ps.append(f.covariance())
+        bs.append(f.raw_vec()); Rs.append(f.raw_mat()); xs.append(f.state()); Ps.append(f.covariance()); Pm.append(f.pred_covariance())
     assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array(Rs)) <= tol
+    assert synth.rel_frobenius(est.pred_covariance(), np.array(Pm)) <= tol * 10     # from RBar (FULL_ESTIMATE extras)
     assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array(bs)) <= tol
     assert synth.rel_frobenius(est.state(), np.array(xs)) <= tol * 10
     assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= tol * 10
