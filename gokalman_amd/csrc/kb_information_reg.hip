@@ -8,16 +8,19 @@
 #include "kb_static.h"
 
 namespace kb {
+#ifndef INFO_WPB
+#define INFO_WPB 1   // waves per workgroup
+#endif
 #ifndef INFO_WAVES
 #define INFO_WAVES 1
 #endif
 
 
 template <typename T, int NS, int NM, int NC, bool SCALAR_RINV>
-__global__ void __launch_bounds__(256, INFO_WAVES) information_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * INFO_WPB + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
@@ -173,8 +176,8 @@ static bool info_try(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || (a.rinv_p != NM && a.rinv_p != 1) || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 ||
         (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) || a.noise_kind != KB_NOISE_NOISELESS)
         return false;
-    if (a.rinv_p == 1) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, true>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a);
-    else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, false>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a);
+    if (a.rinv_p == 1) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, true>), dim3((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), dim3(64 * INFO_WPB), 0, b.stream, a);
+    else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, false>), dim3((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), dim3(64 * INFO_WPB), 0, b.stream, a);
     return true;
 }
 

@@ -12,6 +12,9 @@
 #include "kb_static.h"
 
 namespace kb {
+#ifndef SQRT_WPB
+#define SQRT_WPB 1   // waves per workgroup
+#endif
 #ifndef SQRT_WAVES
 #define SQRT_WAVES 1
 #endif
@@ -27,10 +30,10 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 };
 
 template <typename T, int NS, int NM, int NC, bool FULL>
-__global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * SQRT_WPB + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(256, SQRT_WAVES) squareroot_reg_kernel(const S
 template <typename T, int NS, int NM, int NC = 0>
 static bool sqrt_try(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || a.sqrt_p != NM || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
-    const dim3 grid = tile_grid(a.ntiles), block(256);
+    const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
     if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true>), grid, block, 0, b.stream, a);
     else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false>), grid, block, 0, b.stream, a);
     return true;
