@@ -18,10 +18,24 @@ namespace kb {
 constexpr int MC_REPL = 32;
 
 
-__device__ __forceinline__ double wave_sum(double v) {
+// Sums V values (V a power of two <= 64) over the 64 lanes with V - 1 + log2(64 / V) exchanges instead of 6 V: while
+// more than one value is left, a lane keeps one of each pair of values and hands the other to its partner, so every
+// exchange halves the number of values per lane.  On return lane l holds the wave total of value l & (V - 1) in v[0].
+template <int V>
+__device__ __forceinline__ void wave_sum_multi(double (&v)[V], int lane) {
+    int off = 1;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int nv = V; nv > 1; nv >>= 1, off <<= 1) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int j = 0; j < nv / 2; j++) {
+            const double send = hi ? v[2 * j] : v[2 * j + 1];
+            const double keep = hi ? v[2 * j + 1] : v[2 * j];
+            v[j] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+#pragma unroll
+    for (int o = V; o < 64; o <<= 1) v[0] += __shfl_xor(v[0], o, 64);
 }
 
 template <typename T, int NS, int NC>
@@ -87,15 +101,16 @@ __global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__re
             x[i] = xn[i] + s;
             c[i] = cn[i];
         }
+        constexpr int V = NS <= 2 ? 4 : (NS <= 4 ? 8 : 16);   // 2 NS values, padded to a power of two
+        double acc[V];
 #pragma unroll
-        for (int i = 0; i < NS; i++) {
-            const double dlt = active ? (double)x[i] - (double)c[i] : 0.0;
-            const double s1 = wave_sum(dlt), s2 = wave_sum(dlt * dlt);
-            if (lane == 0) {
-                atomicAdd(my + ((size_t)t * 2 + 0) * NS + i, s1);
-                atomicAdd(my + ((size_t)t * 2 + 1) * NS + i, s2);
-            }
+        for (int i = 0; i < V / 2; i++) {
+            const double dlt = (i < NS && active) ? (double)x[i < NS ? i : 0] - (double)c[i < NS ? i : 0] : 0.0;
+            acc[2 * i] = dlt;
+            acc[2 * i + 1] = dlt * dlt;
         }
+        wave_sum_multi<V>(acc, lane);
+        if (lane < 2 * NS) atomicAdd(my + ((size_t)t * 2 + (lane & 1)) * NS + (lane >> 1), acc[0]);   // one instruction, 2 NS lanes
         if (tile == 0 && lane == 0) {
 #pragma unroll
             for (int i = 0; i < NS; i++) shift[(size_t)t * NS + i] = (double)c[i];
