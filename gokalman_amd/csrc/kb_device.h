@@ -51,8 +51,9 @@ __device__ __forceinline__ bool sym_close(T a, T b) {
 // reference would return a Condition error: exact zero pivot, or
 // cond_inf = |A|_inf |A^-1|_inf > 1e16 (gonum matrix.ConditionTolerance), or NaN.
 // ---------------------------------------------------------------------------
+// `nreal`: rows >= nreal are identity padding (kb_vanilla_reg.h PAD) and stay out of the norms.
 template <typename T, int P>
-__device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P]) {
+__device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P], int nreal = P) {
     T a[P * P], b[P * P];
     T anorm = T(0);
 #pragma unroll
@@ -64,7 +65,7 @@ __device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P])
             b[i * P + j] = (i == j) ? T(1) : T(0);
             s += fabs(Ain[i * P + j]);
         }
-        anorm = (s > anorm || s != s) ? s : anorm;
+        if (i < nreal) anorm = (s > anorm || s != s) ? s : anorm;
     }
     bool bad = false;
 #pragma unroll
@@ -115,7 +116,7 @@ __device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P])
         T s = T(0);
 #pragma unroll
         for (int c = 0; c < P; c++) s += fabs(X[i * P + c]);
-        inorm = (s > inorm || s != s) ? s : inorm;
+        if (i < nreal) inorm = (s > inorm || s != s) ? s : inorm;
     }
     const T cond = anorm * inorm;
     return bad || !(cond <= T(1e16));

@@ -246,6 +246,7 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
     if (special) {
         done = try_reg<T, 6, 3, 0>(b, a, fused) || try_reg<T, 4, 2, 0>(b, a, fused);
         if (!done && b.dtype == KB_F64) done = launch_vanilla_extra_shapes(b, a, fused);
+        if (!done && b.dtype == KB_F64 && !fused) done = launch_vanilla_padded(b, a) || launch_vanilla_padded8(b, a);
     }
     if (!done) {
         const int d = a.n > a.p ? (a.n > a.m ? a.n : a.m) : (a.p > a.m ? a.p : a.m);

@@ -47,16 +47,22 @@ __device__ __forceinline__ void stnt(const TilePtr<T> &p, int e, T v) { p.stnt(e
 // ---------------------------------------------------------------------------------
 // register-resident kernel
 // ---------------------------------------------------------------------------------
-template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED>
-__global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
+// PAD: the batch's run-time dimensions (a.n, a.p, a.m) may be smaller than the compile-time ones; the arithmetic runs
+// on the padded operands -- zeros, and an identity block in R so that the innovation covariance stays invertible --
+// which leaves every real entry of the result unchanged (the extra terms are exact zeros); only loads, stores and
+// the condition-number test see the real sizes.  This is how shapes without an exact instantiation still get a
+// register-resident kernel (kb_vanilla_pad.hip).
+template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false>
+__global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(T) * NS * NS > 300)) ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     constexpr int TM = tri(NM);
+    const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;   // real sizes (compile-time constants unless PAD)
     const unsigned lane = threadIdx.x & 63u;
     const int64_t tile = (int64_t)blockIdx.x * KB_VANILLA_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
 
-    const TilePtr<T> st{(T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)), lane};
+    const TilePtr<T> st{(T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))), lane};
     const TilePtr<const T> mo{(const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems), lane};
     const TilePtr<const T> moF = mo.field(a.L.mo_F), moH = mo.field(a.L.mo_H), moQ = mo.field(a.L.mo_Q), moR = mo.field(a.L.mo_R),
                            moG = mo.field(a.L.mo_G);
@@ -66,11 +72,15 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
     // ---- state + transition model
     T x[NS], P[TR], F[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
+    for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldt(st, i) : T(0);
 #pragma unroll
-    for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
+    for (int j = 0; j < NS; j++)
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(moF, e);
+        for (int i = 0; i <= j; i++) P[symi(i, j)] = (j < rn) ? ldt(st, rn + symi(i, j)) : T(0);   // packed index does not depend on n
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(moF, i * rn + j) : T(0);
 
     // Issue order is pinned with scheduling barriers: (1) x, P, F -- everything the prediction
     // needs -- then (2) Q, H, R [, G] and the first measurement, then the arithmetic.  The
@@ -79,18 +89,26 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
     __builtin_amdgcn_sched_barrier(0);
     [[maybe_unused]] T H[NM * NS], Q[TR], R[TM], G[NC > 0 ? NS * NC : 1], y0[NM];
 #pragma unroll
-    for (int e = 0; e < TR; e++) Q[e] = ldnt(moQ, e);
+    for (int j = 0; j < NS; j++)
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(moH, e);
+        for (int i = 0; i <= j; i++) Q[symi(i, j)] = (j < rn) ? ldnt(moQ, symi(i, j)) : T(0);
 #pragma unroll
-    for (int e = 0; e < TM; e++) R[e] = ldnt(moR, e);
+    for (int r = 0; r < NM; r++)
+#pragma unroll
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldnt(moH, r * rn + l) : T(0);
+#pragma unroll
+    for (int c = 0; c < NM; c++)
+#pragma unroll
+        for (int r = 0; r <= c; r++) R[symi(r, c)] = (c < rp) ? ldnt(moR, symi(r, c)) : (r == c ? T(1) : T(0));
     if constexpr (NC > 0) {
 #pragma unroll
-        for (int e = 0; e < NS * NC; e++) G[e] = ldnt(moG, e);
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) G[i * NC + c] = (i < rn && c < rm) ? ldnt(moG, i * rm + c) : T(0);
     }
     if constexpr (!PREDICT) {
 #pragma unroll
-        for (int r = 0; r < NM; r++) y0[r] = active ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
+        for (int r = 0; r < NM; r++) y0[r] = (active && r < rp) ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -109,7 +127,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
         if constexpr (NC > 0) {
             T u[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) u[c] = active ? ldnt_at(up + (int64_t)t * a.u_step + (int64_t)c * a.u_es) : T(0);
+            for (int c = 0; c < NC; c++) u[c] = (active && c < rm) ? ldnt_at(up + (int64_t)t * a.u_step + (int64_t)c * a.u_es) : T(0);
 #pragma unroll
             for (int i = 0; i < NS; i++) {
                 T s = T(0);
@@ -173,7 +191,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
                 for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
                 S[r * NM + c] = s + R[symi(r, c)];
             }
-        unsigned err = inverse_lu<T, NM>(S, Si) ? KB_ST_SINGULAR : 0u;
+        unsigned err = inverse_lu<T, NM>(S, Si, rp) ? KB_ST_SINGULAR : 0u;
         T K[NS * NM];
 #pragma unroll
         for (int i = 0; i < NS; i++)
@@ -199,7 +217,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
             // ---- innovation and state update
 #pragma unroll
             for (int r = 0; r < NM; r++) {
-                const T yv = (t == 0) ? y0[r] : (active ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
+                const T yv = (t == 0) ? y0[r] : ((active && r < rp) ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
                 T s = T(0);
 #pragma unroll
                 for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
@@ -277,15 +295,21 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
                 const TilePtr<T> es0{(T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems), lane};
                 const TilePtr<T> esP = es0.field(a.L.es_ppred), esK = es0.field(a.L.es_gain), esI = es0.field(a.L.es_innov), esY = es0.field(a.L.es_yhat);
 #pragma unroll
-                for (int e = 0; e < TR; e++) stnt(esP, e, Pm[e]);
+                for (int j = 0; j < NS; j++)
+#pragma unroll
+                    for (int i = 0; i <= j; i++)
+                        if (j < rn) stnt(esP, symi(i, j), Pm[symi(i, j)]);
 #pragma unroll
                 for (int i = 0; i < NS; i++)
 #pragma unroll
-                    for (int c = 0; c < NM; c++) stnt(esK, i * a.pmax + c, K[i * NM + c]);
+                    for (int c = 0; c < NM; c++)
+                        if (i < rn && c < rp) stnt(esK, i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
                 for (int r = 0; r < NM; r++) {
-                    stnt(esI, r, innov[r]);
-                    stnt(esY, r, yhat[r]);
+                    if (r < rp) {
+                        stnt(esI, r, innov[r]);
+                        stnt(esY, r, yhat[r]);
+                    }
                 }
             }
         }
@@ -297,18 +321,26 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, FUSED ? 1 : 2) vanilla_re
         } else {
             if (active && ok) {
 #pragma unroll
-                for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
+                for (int i = 0; i < NS; i++)
+                    if (i < rn) stt(st, i, xn[i]);
 #pragma unroll
-                for (int e = 0; e < TR; e++) stt(st, NS + e, Pn[e]);
+                for (int j = 0; j < NS; j++)
+#pragma unroll
+                    for (int i = 0; i <= j; i++)
+                        if (j < rn) stt(st, rn + symi(i, j), Pn[symi(i, j)]);
             }
         }
     }
     if constexpr (FUSED) {
         if (active) {
 #pragma unroll
-            for (int i = 0; i < NS; i++) stt(st, i, x[i]);
+            for (int i = 0; i < NS; i++)
+                if (i < rn) stt(st, i, x[i]);
 #pragma unroll
-            for (int e = 0; e < TR; e++) stt(st, NS + e, P[e]);
+            for (int j = 0; j < NS; j++)
+#pragma unroll
+                for (int i = 0; i <= j; i++)
+                    if (j < rn) stt(st, rn + symi(i, j), P[symi(i, j)]);
         }
     }
     if (active && err_acc) atomicOr(a.status + tile * KB_TILE + lane, err_acc);
@@ -335,7 +367,23 @@ static inline bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
     return true;
 }
 
-// shapes instantiated in kb_vanilla_shapes.hip
+// Padded launch: any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input), one step per launch.
+template <typename T, int NS, int NM, int NC>
+static inline bool try_pad(const Batch &b, const StepArgs &a) {
+    const int m = a.need_ctrl ? a.m : 0;
+    if (a.n > NS || a.p > NM || m > NC || (NC == 0) != (m == 0)) return false;
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
+#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true>), grid, block, 0, b.stream, a)
+    if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
+    else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
+#undef KB_GO
+    return true;
+}
+
+// shapes instantiated in kb_vanilla_shapes.hip / kb_vanilla_pad*.hip
 bool launch_vanilla_extra_shapes(const Batch &b, const StepArgs &a, bool fused);
+bool launch_vanilla_padded(const Batch &b, const StepArgs &a);
+bool launch_vanilla_padded8(const Batch &b, const StepArgs &a);
 
 }  // namespace kb

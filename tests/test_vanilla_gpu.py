@@ -160,3 +160,41 @@ def test_vanilla_batch_noise_replay():
     assert synth.rel_frobenius(est.measurement(), np.array(ys)) <= 1e-9
     with pytest.raises(ga.KalmanError, match=r"no process noise defined at step k=6"):
         b.update(d["y"][0])
+
+
+def _random_model(rng, N, n, p, m, steps):
+    F = np.eye(n) + 0.05 * rng.standard_normal((N, n, n))
+    H = rng.standard_normal((N, p, n))
+    A = rng.standard_normal((N, n, n)); Q = 1e-3 * (A @ np.swapaxes(A, 1, 2)) + 1e-4 * np.eye(n)
+    B = rng.standard_normal((N, p, p)); R = 1e-2 * (B @ np.swapaxes(B, 1, 2)) + 1e-2 * np.eye(p)
+    G = rng.standard_normal((N, n, m)) if m else None
+    x0 = rng.standard_normal((N, n)); P0 = np.tile(np.eye(n) * 2.0, (N, 1, 1))
+    y = rng.standard_normal((steps, N, p)); u = rng.standard_normal((steps, N, m)) if m else None
+    return F, G, H, Q, R, x0, P0, y, u
+
+
+@pytest.mark.parametrize("n,p,m", [(1, 1, 0), (3, 2, 0), (5, 2, 0), (5, 3, 0), (5, 4, 0), (7, 1, 0), (7, 3, 0), (8, 4, 0), (6, 4, 0),
+                                   (3, 1, 2), (5, 3, 1), (8, 4, 2), (2, 2, 1)])
+@pytest.mark.parametrize("full", [False, True])
+def test_vanilla_padded_register_kernels_vs_oracle(n, p, m, full):
+    """Shapes without an exact register kernel run on the next larger padded instantiation (kb_vanilla_pad.hip):
+    results must be those of the oracle at the real dimensions, extras included."""
+    rng = np.random.default_rng(1000 * n + 10 * p + m)
+    N, steps = 130, 5
+    F, G, H, Q, R, x0, P0, y, u = _random_model(rng, N, n, p, m, steps)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, flags=k.FLAG_FULL_ESTIMATE if full else 0)
+    for t in range(steps):
+        est = b.update(y[t], u[t] if m else None)
+    xs, Ps, Ks, Pm, inn = [], [], [], [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.VANILLA, x0[i], P0[i], F[i], G[i] if m else None, H[i], Q[i], R[i])
+        for t in range(steps):
+            assert f.update(y[t, i], u[t, i] if m else None) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); Ks.append(f.gain()); Pm.append(f.pred_covariance()); inn.append(f.innovation())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= TOL
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= TOL
+    if full:
+        assert synth.rel_frobenius(est.gain(), np.array(Ks)) <= TOL
+        assert synth.rel_frobenius(est.pred_covariance(), np.array(Pm)) <= TOL
+        assert synth.rel_frobenius(est.innovation(), np.array(inn)) <= TOL
+    assert not b.status().any()
