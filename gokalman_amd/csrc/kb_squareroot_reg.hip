@@ -29,24 +29,32 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
     static constexpr bool active(int k, int r) { return k >= NM || r >= NM; }
 };
 
-template <typename T, int NS, int NM, int NC, bool FULL>
+// PAD: run-time dimensions a.n <= NS, a.p <= NM, a.m <= NC on operands padded with zeros (and an identity block in
+// chol(R)): zero rows / columns of a QR panel produce no reflection (sqr_r's `refl` test) and leave the real entries
+// untouched, so only loads and stores see the real sizes (cf. kb_vanilla_reg.h).
+template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false>
 __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
+    const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * SQRT_WPB + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
-    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
 
     T x[NS], S[TR], F[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
+    for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldt(st, i) : T(0);
 #pragma unroll
-    for (int e = 0; e < TR; e++) S[e] = ldt(st, NS + e);  // S[i][k], k <= i, at symi(k, i)
+    for (int i = 0; i < NS; i++)
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = ldnt(mo, a.L.mo_F + e);
+        for (int k2 = 0; k2 <= i; k2++) S[symi(k2, i)] = (i < rn) ? ldt(st, rn + symi(k2, i)) : T(0);  // S[i][k], k <= i, at symi(k, i)
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_F + i * rn + j) : T(0);
 
     // :139-147 x- = F x [+ G u]
     T xm[NS];
@@ -57,7 +65,8 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
         for (int i = 0; i < NS; i++) {
             T s = T(0);
 #pragma unroll
-            for (int c = 0; c < NC; c++) s += ldnt(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+            for (int c = 0; c < NC; c++)
+                if (i < rn && c < rm) s += ldnt(mo, a.L.mo_G + i * rm + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
             xm[i] = xm[i] + s;
         }
     }
@@ -80,13 +89,15 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i) ? ldnt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
+        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i && j < rn) ? ldnt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
     sqr_r<T, 2 * NS, NS, ActC<NS>>(C);
     __builtin_amdgcn_sched_barrier(0);  // H, chol(R) loads and the Delta panel stay below the C phase
     // Sm[i][j] = C[i*NS+j], j >= i
     T H[NM * NS];
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
+    for (int r = 0; r < NM; r++)
+#pragma unroll
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0);
     // :190-216 Delta = [[sqrtR^T, 0],[S-^T H^T, S-^T]]
     T D[DD * DD];
 #pragma unroll
@@ -96,7 +107,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
             T val;
             if (c < NM) {
                 if (r < NM) {
-                    val = (c >= r) ? ldnt(mo, a.L.mo_LR + symi(r, c)) : T(0);
+                    val = (c >= r) ? (c < rp ? ldnt(mo, a.L.mo_LR + symi(r, c)) : (r == c ? T(1) : T(0))) : T(0);
                 } else {
                     T s = T(0);  // (S-^T H^T)[r-NM][c] = sum_{l <= r-NM} Sm[l][r-NM] H[c][l]
 #pragma unroll
@@ -118,7 +129,8 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
 #pragma unroll
             for (int i = 0; i < NS; i++)
 #pragma unroll
-                for (int j = i; j < NS; j++) stt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
+                for (int j = i; j < NS; j++)
+                    if (j < rn) stt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
         }
     }
     sqr_r<T, DD, DD, ActD<NM>>(D);
@@ -128,7 +140,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
     for (int i = 0; i < NM; i++)
 #pragma unroll
         for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? D[j * DD + i] : T(0);
-    inverse_lu<T, NM>(Syy, SyyI);
+    inverse_lu<T, NM>(Syy, SyyI, rp);
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
     T innov[NM], xn[NS];
 #pragma unroll
     for (int r = 0; r < NM; r++) {
-        const T yv = active ? __builtin_nontemporal_load(yp + (int64_t)r * a.y_es) : T(0);
+        const T yv = (active && r < rp) ? __builtin_nontemporal_load(yp + (int64_t)r * a.y_es) : T(0);
         T s = T(0);
 #pragma unroll
         for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
@@ -164,19 +176,23 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
     const bool ok = !(chk != chk);
     if (active && ok) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
+        for (int i = 0; i < NS; i++)
+            if (i < rn) stt(st, i, xn[i]);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int j = 0; j <= i; j++) stt(st, NS + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
+            for (int j = 0; j <= i; j++)
+                if (i < rn) stt(st, rn + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
         if constexpr (FULL) {
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll
             for (int i = 0; i < NS; i++)
 #pragma unroll
-                for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                for (int c = 0; c < NM; c++)
+                    if (i < rn && c < rp) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
-            for (int r = 0; r < NM; r++) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, yhat[r]); }
+            for (int r = 0; r < NM; r++)
+                if (r < rp) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, yhat[r]); }
         }
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
@@ -191,12 +207,26 @@ static bool sqrt_try(const Batch &b, const StepArgs &a) {
     return true;
 }
 
+// any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input) on the padded instantiation
+template <typename T, int NS, int NM, int NC>
+static bool sqrt_try_pad(const Batch &b, const StepArgs &a) {
+    const int m = a.need_ctrl ? a.m : 0;
+    if (a.n > NS || a.p > NM || a.sqrt_p != a.p || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, true>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, true>), grid, block, 0, b.stream, a);
+    return true;
+}
+
 int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
     bool done = false;
     if (b.dtype == KB_F64)
         done = sqrt_try<double, 6, 3>(b, a) || sqrt_try<double, 4, 2>(b, a) ||
                sqrt_try<double, 4, 1, 1>(b, a) || sqrt_try<double, 4, 2, 1>(b, a);  // examples/jerkcar: 1- and 2-row H, one control
     else done = sqrt_try<float, 6, 3>(b, a);
+    if (!done && b.dtype == KB_F64)   // shapes without an exact instantiation: padded register kernels up to 6 / 4 / 2
+        done = sqrt_try_pad<double, 4, 2, 0>(b, a) || sqrt_try_pad<double, 4, 2, 2>(b, a) || sqrt_try_pad<double, 6, 4, 0>(b, a) ||
+               sqrt_try_pad<double, 6, 4, 2>(b, a);
     if (!done) return launch_squareroot_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -66,6 +66,32 @@ def test_squareroot_random_batch_vs_oracle(n, p):
     assert not b.status().any()
 
 
+@pytest.mark.parametrize("n,p,m", [(1, 1, 0), (3, 2, 0), (5, 2, 0), (5, 4, 0), (6, 4, 0), (6, 1, 0), (2, 2, 1), (5, 3, 2), (6, 3, 1)])
+@pytest.mark.parametrize("full", [False, True])
+def test_squareroot_padded_register_kernels_vs_oracle(n, p, m, full):
+    """SquareRoot shapes without an exact register kernel run on the padded instantiations (kb_squareroot_reg.hip, PAD)."""
+    from tests.test_vanilla_gpu import _random_model
+    rng = np.random.default_rng(2000 * n + 10 * p + m)
+    N, steps = 130, 5
+    F, G, H, Q, R, x0, P0, y, u = _random_model(rng, N, n, p, m, steps)
+    b = ga.FilterBatch.new_ldkf(k.SQUAREROOT, x0, P0, F, G, H, Q, R, flags=k.FLAG_FULL_ESTIMATE if full else 0)
+    for t in range(steps):
+        est = b.update(y[t], u[t] if m else None)
+    xs, Ps, Ss, Ks, Pm = [], [], [], [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.SQUAREROOT, x0[i], P0[i], F[i], G[i] if m else None, H[i], Q[i], R[i])
+        for t in range(steps):
+            assert f.update(y[t, i], u[t, i] if m else None) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); Ss.append(f.raw_mat()); Ks.append(f.gain()); Pm.append(f.pred_covariance())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= TOL
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= TOL
+    assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array(Ss)) <= TOL
+    if full:
+        assert synth.rel_frobenius(est.gain(), np.array(Ks)) <= TOL
+        assert synth.rel_frobenius(est.pred_covariance(), np.array(Pm)) <= TOL
+    assert not b.status().any()
+
+
 def test_information_from_state_random_batch_vs_oracle():
     N, steps, n, p = 150, 8, 6, 3
     d = synth.linear_batch(N, n, p, steps)
