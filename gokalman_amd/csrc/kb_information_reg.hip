@@ -16,23 +16,31 @@ namespace kb {
 #endif
 
 
-template <typename T, int NS, int NM, int NC, bool SCALAR_RINV>
+// PAD: run-time dimensions a.n <= NS, a.p <= NM, a.m <= NC on operands padded with zeros and an identity block in
+// Q^-1 (so that M + Q^-1 stays invertible; Z, I- and i- keep exact zeros in the padding): only loads and stores see
+// the real sizes (cf. kb_vanilla_reg.h).
+template <typename T, int NS, int NM, int NC, bool SCALAR_RINV, bool PAD = false>
 __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
+    const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * INFO_WPB + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
-    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
     T iv[NS], I[TR], Fi[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) iv[i] = ldt(st, i);
+    for (int i = 0; i < NS; i++) iv[i] = (i < rn) ? ldt(st, i) : T(0);
 #pragma unroll
-    for (int e = 0; e < TR; e++) I[e] = ldt(st, NS + e);
+    for (int j = 0; j < NS; j++)
 #pragma unroll
-    for (int e = 0; e < NS * NS; e++) Fi[e] = ldnt(mo, a.L.mo_Finv + e);
+        for (int i = 0; i <= j; i++) I[symi(i, j)] = (j < rn) ? ldt(st, rn + symi(i, j)) : T(0);
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_Finv + i * rn + j) : T(0);
     // :163-165 zk = Finv^T (I Finv)
     T t1[NS * NS], zk[NS * NS];
 #pragma unroll
@@ -70,7 +78,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            zqT[j * NS + i] = zk[i * NS + j] + ldnt(mo, a.L.mo_Qinv + i * NS + j);
+            zqT[j * NS + i] = zk[i * NS + j] + ((i < rn && j < rn) ? ldnt(mo, a.L.mo_Qinv + i * rn + j) : (i == j ? T(1) : T(0)));
             X[j * NS + i] = zk[i * NS + j];
         }
     lu_solve_inplace<T, NS, NS>(zqT, X);
@@ -85,7 +93,8 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         for (int i = 0; i < NS; i++) {
             T s = T(0);
 #pragma unroll
-            for (int c = 0; c < NC; c++) s += ldnt(mo, a.L.mo_G + i * NC + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+            for (int c = 0; c < NC; c++)
+                if (i < rn && c < rm) s += ldnt(mo, a.L.mo_G + i * rm + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
             gu[i] = s;
         }
 #pragma unroll
@@ -119,7 +128,9 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     // :197-212 HTR = H^T Rinv; i+ = HTR y + i-; I+ = I- + HTR H
     T H[NM * NS], HTR[NS * NM];
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = ldnt(mo, a.L.mo_H + e);
+    for (int r = 0; r < NM; r++)
+#pragma unroll
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0);
     if constexpr (SCALAR_RINV) {  // QUIRK information.go:198-200: a (stale) 1x1 R^-1 scales H^T whatever p is
         const T r0 = ldnt(mo, a.L.mo_Rinv);
 #pragma unroll
@@ -129,7 +140,9 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     } else {
         T Ri[NM * NM];
 #pragma unroll
-        for (int e = 0; e < NM * NM; e++) Ri[e] = ldnt(mo, a.L.mo_Rinv + e);
+        for (int l = 0; l < NM; l++)
+#pragma unroll
+            for (int j = 0; j < NM; j++) Ri[l * NM + j] = (l < rp && j < rp) ? ldnt(mo, a.L.mo_Rinv + l * rp + j) : T(0);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -147,7 +160,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         T s = T(0);
 #pragma unroll
         for (int j = 0; j < NM; j++) {
-            const T yv = active ? __builtin_nontemporal_load(yp + (int64_t)j * a.y_es) : T(0);
+            const T yv = (active && j < rp) ? __builtin_nontemporal_load(yp + (int64_t)j * a.y_es) : T(0);
             s += HTR[i * NM + j] * yv;
         }
         ip[i] = s + imn[i];
@@ -164,9 +177,13 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     const bool ok = !(chk != chk);
     if (active && ok) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) stt(st, i, ip[i]);
+        for (int i = 0; i < NS; i++)
+            if (i < rn) stt(st, i, ip[i]);
 #pragma unroll
-        for (int e = 0; e < TR; e++) stt(st, NS + e, Ip[e]);
+        for (int j = 0; j < NS; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++)
+                if (j < rn) stt(st, rn + symi(i, j), Ip[symi(i, j)]);
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
 }
@@ -181,11 +198,27 @@ static bool info_try(const Batch &b, const StepArgs &a) {
     return true;
 }
 
+// any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input) on the padded instantiation
+template <typename T, int NS, int NM, int NC>
+static bool info_try_pad(const Batch &b, const StepArgs &a) {
+    const int m = a.need_ctrl ? a.m : 0;
+    if (a.n > NS || a.p > NM || (a.rinv_p != a.p && a.rinv_p != 1) || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1 ||
+        (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) || a.noise_kind != KB_NOISE_NOISELESS)
+        return false;
+    const dim3 grid((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), block(64 * INFO_WPB);
+    if (a.rinv_p == 1 && a.p != 1) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, true, true>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, false, true>), grid, block, 0, b.stream, a);
+    return true;
+}
+
 int launch_information(const Batch &b, const StepArgs &a) {
     bool done = false;
     if (b.dtype == KB_F64)
         done = info_try<double, 6, 3>(b, a) || info_try<double, 4, 2>(b, a) ||
                info_try<double, 4, 1, 1>(b, a) || info_try<double, 4, 2, 1>(b, a);  // examples/jerkcar
+    if (!done && b.dtype == KB_F64)   // shapes without an exact instantiation: padded register kernels up to 6 / 4 / 2
+        done = info_try_pad<double, 4, 2, 0>(b, a) || info_try_pad<double, 4, 2, 2>(b, a) || info_try_pad<double, 6, 4, 0>(b, a) ||
+               info_try_pad<double, 6, 4, 2>(b, a);
     if (!done) return launch_information_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -92,6 +92,29 @@ def test_squareroot_padded_register_kernels_vs_oracle(n, p, m, full):
     assert not b.status().any()
 
 
+@pytest.mark.parametrize("n,p,m", [(1, 1, 0), (3, 2, 0), (5, 2, 0), (5, 4, 0), (6, 4, 0), (6, 1, 0), (2, 2, 1), (5, 3, 2), (6, 3, 1)])
+def test_information_padded_register_kernels_vs_oracle(n, p, m):
+    """Information shapes without an exact register kernel run on the padded instantiations (kb_information_reg.hip, PAD)."""
+    from tests.test_vanilla_gpu import _random_model
+    rng = np.random.default_rng(3000 * n + 10 * p + m)
+    N, steps = 130, 5
+    F, G, H, Q, R, x0, P0, y, u = _random_model(rng, N, n, p, m, steps)
+    b = ga.FilterBatch.new_ldkf(k.INFORMATION, x0, P0, F, G, H, Q, R, flags=k.FLAG_INFO_FROM_STATE)
+    for t in range(steps):
+        est = b.update(y[t], u[t] if m else None)
+    xs, Ps, Is, iv = [], [], [], []
+    for i in range(N):
+        f = orc.Filter.information_from_state(x0[i], P0[i], F[i], G[i] if m else None, H[i], Q[i], R[i])
+        for t in range(steps):
+            assert f.update(y[t, i], u[t, i] if m else None) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); Is.append(f.raw_mat()); iv.append(f.raw_vec())
+    assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array(Is)) <= TOL
+    assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array(iv)) <= TOL
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-8       # one more inversion on both sides
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= 1e-8
+    assert not (b.status() & ~np.uint32(k.ST_INFO_NOT_INVERTIBLE)).any()
+
+
 def test_information_from_state_random_batch_vs_oracle():
     N, steps, n, p = 150, 8, 6, 3
     d = synth.linear_batch(N, n, p, steps)
