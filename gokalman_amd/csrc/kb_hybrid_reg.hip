@@ -1,6 +1,7 @@
 // kb_hybrid_reg.hip -- register-resident HybridKF update (hybrid.go:104-204) for the statOD-sized
 // ensemble (n = 6, p = 2): CKF or EKF, per-step Phi and H-tilde streamed from HBM (non-temporal),
-// x and packed P read and rewritten.  SNC (PreparePNT) and Predict() go through the generic kernel.
+// x and packed P read and rewritten, SNC (PreparePNT, q <= 3) as a wave-uniform branch.  Predict() goes through the
+// generic kernel.
 // Algorithmic bytes per filter-step: x 6 + P 36 + Phi 36 + Htilde 12 + R 4 + real 2 + computed 2
 // read, x 6 + P 36 written = 1120 B.
 #include "kb_internal.h"
@@ -49,6 +50,37 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
             for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
             Pm[symi(i, j)] = s;
         }
+    }
+    if (a.snc) {   // :117-123 PBar += Gamma Q Gamma^T (PreparePNT was called for this step; wave-uniform), q <= 3
+        constexpr int NQ = 3;
+        const int q = a.L.nq;
+        T Gm[NS * NQ], Qs[tri(NQ)], GQ[NS * NQ];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int c = 0; c < NQ; c++) Gm[i * NQ + c] = (c < q) ? ldnt(mo, a.L.mo_G + i * q + c) : T(0);
+#pragma unroll
+        for (int c = 0; c < NQ; c++)
+#pragma unroll
+            for (int l = 0; l <= c; l++) Qs[symi(l, c)] = (c < q) ? ldnt(mo, a.L.mo_Q + symi(l, c)) : T(0);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int c = 0; c < NQ; c++) {
+                T s2 = T(0);
+#pragma unroll
+                for (int l = 0; l < NQ; l++) s2 += Gm[i * NQ + l] * Qs[symi(l, c)];
+                GQ[i * NQ + c] = s2;
+            }
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = i; j < NS; j++) {
+                T s2 = T(0);
+#pragma unroll
+                for (int c = 0; c < NQ; c++) s2 += GQ[i * NQ + c] * Gm[j * NQ + c];
+                Pm[symi(i, j)] += s2;
+            }
     }
     [[maybe_unused]] T xb[NS];
     if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
@@ -179,7 +211,7 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
 }
 
 static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {
-    return a.n == NS && a.p == NM && !a.snc && !a.predict && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
+    return a.n == NS && a.p == NM && (!a.snc || a.L.nq <= 3) && !a.predict && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
 }
 
 template <typename T, int NS, int NM>
