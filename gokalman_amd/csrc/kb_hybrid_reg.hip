@@ -1,7 +1,6 @@
 // kb_hybrid_reg.hip -- register-resident HybridKF update (hybrid.go:104-204) for the statOD-sized
 // ensemble (n = 6, p = 2): CKF or EKF, per-step Phi and H-tilde streamed from HBM (non-temporal),
-// x and packed P read and rewritten, SNC (PreparePNT, q <= 3) as a wave-uniform branch.  Predict() goes through the
-// generic kernel.
+// x and packed P read and rewritten, SNC (PreparePNT, q <= 3) and Predict() as wave-uniform branches.
 // Algorithmic bytes per filter-step: x 6 + P 36 + Phi 36 + Htilde 12 + R 4 + real 2 + computed 2
 // read, x 6 + P 36 written = 1120 B.
 #include "kb_internal.h"
@@ -84,6 +83,32 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
     }
     [[maybe_unused]] T xb[NS];
     if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
+    if (a.predict) {   // Predict() (hybrid.go:125-143, wave-uniform): estimate = {xBar (CKF) or the hard-coded zero vector (EKF), PBar}
+        T chk0 = T(0);
+#pragma unroll
+        for (int e = 0; e < TR; e++) chk0 += Pm[e] * T(0);
+        if (chk0 != chk0) { if (active) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE); return; }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                if constexpr (EKF) stt(st, i, T(0)); else stt(st, i, xb[i]);
+            }
+#pragma unroll
+            for (int e = 0; e < TR; e++) stt(st, NS + e, Pm[e]);
+            if constexpr (FULL) {
+                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+#pragma unroll
+                for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
+#pragma unroll
+                for (int i = 0; i < NS; i++)
+#pragma unroll
+                    for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, T(0));
+#pragma unroll
+                for (int r = 0; r < NM; r++) { stt(es, a.L.es_innov + r, T(0)); stt(es, a.L.es_yhat + r, T(0)); stt(es, a.L.es_dobs + r, T(0)); }
+            }
+        }
+        return;
+    }
     T H[NM * NS], R[tri(NM)];
 #pragma unroll
     for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
@@ -211,7 +236,7 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
 }
 
 static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {
-    return a.n == NS && a.p == NM && (!a.snc || a.L.nq <= 3) && !a.predict && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
+    return a.n == NS && a.p == NM && (!a.snc || a.L.nq <= 3) && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
 }
 
 template <typename T, int NS, int NM>
