@@ -9,7 +9,9 @@
 namespace kb {
 
 
-template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT>
+// SNCP: the instantiation that also handles SNC (PreparePNT) and Predict(); the plain update stays free of their
+// branches and registers (it is the D(ii) benchmark path).
+template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT, bool SNCP = false>
 __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     const int lane = threadIdx.x & 63;
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
             Pm[symi(i, j)] = s;
         }
     }
-    if (a.snc) {   // :117-123 PBar += Gamma Q Gamma^T (PreparePNT was called for this step; wave-uniform), q <= 3
+    if (SNCP && a.snc) {   // :117-123 PBar += Gamma Q Gamma^T (PreparePNT was called for this step; wave-uniform), q <= 3
         constexpr int NQ = 3;
         const int q = a.L.nq;
         T Gm[NS * NQ], Qs[tri(NQ)], GQ[NS * NQ];
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
     }
     [[maybe_unused]] T xb[NS];
     if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
-    if (a.predict) {   // Predict() (hybrid.go:125-143, wave-uniform): estimate = {xBar (CKF) or the hard-coded zero vector (EKF), PBar}
+    if (SNCP && a.predict) {   // Predict() (hybrid.go:125-143, wave-uniform): estimate = {xBar (CKF) or the hard-coded zero vector (EKF), PBar}
         T chk0 = T(0);
 #pragma unroll
         for (int e = 0; e < TR; e++) chk0 += Pm[e] * T(0);
@@ -244,7 +246,10 @@ static bool hybrid_try(const Batch &b, const StepArgs &a) {
     if (!hybrid_shape_ok(a, NS, NM)) return false;
     const dim3 grid = tile_grid(a.ntiles), block(256);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
-#define KB_H(E_, F_) do { if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true>), grid, block, 0, b.stream, a); \
+    const bool sncp = a.snc || a.predict;
+#define KB_H(E_, F_) do { if (sncp) { if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true, true>), grid, block, 0, b.stream, a); \
+                                      else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false, true>), grid, block, 0, b.stream, a); } \
+                          else if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true>), grid, block, 0, b.stream, a); \
                           else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false>), grid, block, 0, b.stream, a); } while (0)
     if (a.ekf) { if (full) KB_H(true, true); else KB_H(true, false); }
     else       { if (full) KB_H(false, true); else KB_H(false, false); }
