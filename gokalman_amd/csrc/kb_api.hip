@@ -419,6 +419,12 @@ static int ready_ldkf(kb_batch *b) {
     if (!b) { set_error("null batch"); return KB_ERR_INVALID; }
     if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
     if (!is_ldkf(b->kind)) { set_error("kb_update is the LDKF entry point; use kb_update_nl for SRIF / Hybrid"); return KB_ERR_INVALID; }
+    if (b->kind == KB_INFORMATION && b->rinv_p != 1 && b->rinv_p != b->p) {
+        // information.go:197-203: H^T R^-1 with the R^-1 cached at construction (SetNoise never refreshes it, :136-138);
+        // only a 1x1 R^-1 takes the scalar branch, anything else is a mat64 shape panic in the reference
+        set_error("matrix: dimension mismatch: H^T(...x%d) R^-1(%dx%d) (R^-1 is cached at construction)", b->p, b->rinv_p, b->rinv_p);
+        return KB_ERR_DIMS;
+    }
     return use_device(*b);
 }
 

@@ -1,0 +1,91 @@
+"""Seeded random call sequences through the LDKF surface (update / SetMeasurementMatrix with a changing row count /
+SetNoise / SetStateTransition / Reset), mirrored call by call on the oracle: the setters' side effects
+(squareroot.go:100-114 re-Cholesky, information.go:117-138 F^-1 refresh and stale R^-1) and the register / padded /
+generic kernel switches they trigger must never diverge from the reference order of operations."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(rng, N, d, scale):
+    A = rng.standard_normal((N, d, d))
+    return scale * (A @ np.swapaxes(A, 1, 2)) + scale * np.eye(d)
+
+
+@pytest.mark.parametrize("kind,okind,tol", [(k.VANILLA, orc.VANILLA, 1e-9), (k.SQUAREROOT, orc.SQUAREROOT, 1e-9), (k.INFORMATION, orc.INFORMATION, 1e-8)])
+@pytest.mark.parametrize("n,m,seed", [(4, 1, 1), (6, 0, 2), (5, 2, 3), (3, 0, 4)])
+def test_random_call_sequences_match_the_oracle(kind, okind, tol, n, m, seed):
+    rng = np.random.default_rng(seed)
+    N, nops = 70, 40
+    F = np.eye(n) + 0.05 * rng.standard_normal((N, n, n))
+    G = rng.standard_normal((N, n, m)) if m else None
+    Hs = {1: rng.standard_normal((N, 1, n)), 2: rng.standard_normal((N, 2, n))}
+    Q = _spd(rng, N, n, 1e-3)
+    Rs = {1: _spd(rng, N, 1, 1e-2), 2: _spd(rng, N, 2, 1e-2)}
+    x0 = rng.standard_normal((N, n)); P0 = _spd(rng, N, n, 1.0)
+    # Information caches R^-1 at construction and never refreshes it: only a 1x1 R^-1 (scalar branch, information.go:198-200)
+    # survives a change of H's row count, so that kind starts with the 1-row H like examples/jerkcar does
+    p = 1 if kind == k.INFORMATION else 2
+    flags = k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0
+    b = ga.FilterBatch.new_ldkf(kind, x0, P0, F, G, Hs[p], Q, Rs[p], flags=flags, pmax=2)
+    mk = (lambda i: orc.Filter.information_from_state(x0[i], P0[i], F[i], G[i] if m else None, Hs[1][i], Q[i], Rs[1][i])) \
+        if kind == k.INFORMATION else (lambda i: orc.Filter.ldkf(okind, x0[i], P0[i], F[i], G[i] if m else None, Hs[2][i], Q[i], Rs[2][i]))
+    fs = [mk(i) for i in range(N)]
+    nupd = 0
+    for _ in range(nops):
+        op = rng.choice(["update", "update", "update", "swap_h", "set_noise", "set_f", "reset"])
+        if op == "update":
+            y = rng.standard_normal((N, p)); u = rng.standard_normal((N, m)) if m else None
+            b.update(y, u)
+            for i, f in enumerate(fs):
+                assert f.update(y[i], u[i] if m else None) == orc.OK
+            nupd += 1
+        elif op == "swap_h":
+            p = 3 - p
+            b.set_measurement_matrix(Hs[p]); b.set_noise(Q, Rs[p])      # jerkcar's protocol: H and the noise change together
+            for i, f in enumerate(fs):
+                f.set_measurement_matrix(Hs[p][i]); f.set_noise(Q[i], Rs[p][i])
+        elif op == "set_noise":
+            Q = _spd(rng, N, n, 1e-3); Rs[p] = _spd(rng, N, p, 1e-2)
+            b.set_noise(Q, Rs[p])
+            for i, f in enumerate(fs):
+                f.set_noise(Q[i], Rs[p][i])
+        elif op == "set_f":
+            F = np.eye(n) + 0.05 * rng.standard_normal((N, n, n))
+            b.set_state_transition(F)
+            for i, f in enumerate(fs):
+                f.set_state_transition(F[i])
+        else:
+            b.reset()
+            for f in fs:
+                f.reset()
+    y = rng.standard_normal((N, p)); u = rng.standard_normal((N, m)) if m else None
+    est = b.update(y, u)
+    xs, Ps = [], []
+    for i, f in enumerate(fs):
+        assert f.update(y[i], u[i] if m else None) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= tol, nupd
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= tol, nupd
+    assert not (b.status() & ~np.uint32(k.ST_INFO_NOT_INVERTIBLE)).any()
+
+
+def test_information_stale_rinv_shape_mismatch_is_an_error():
+    """Information built with a 2x2 R and then given a 1-row H: H^T R^-1 is a shape panic in the reference
+    (information.go:197-203, R^-1 is never refreshed); the oracle reports ERR_DIMS, the engine KB_ERR_DIMS."""
+    rng = np.random.default_rng(5)
+    n = 4
+    F = np.eye(n); H2 = rng.standard_normal((2, n)); H1 = rng.standard_normal((1, n))
+    b = ga.FilterBatch.new_ldkf(k.INFORMATION, np.zeros(n), np.eye(n), F, None, H2, 1e-3 * np.eye(n), 1e-2 * np.eye(2),
+                                flags=k.FLAG_INFO_FROM_STATE, pmax=2)
+    f = orc.Filter.information_from_state(np.zeros(n), np.eye(n), F, None, H2, 1e-3 * np.eye(n), 1e-2 * np.eye(2))
+    b.set_measurement_matrix(H1); b.set_noise(1e-3 * np.eye(n), np.array([[1e-2]]))
+    f.set_measurement_matrix(H1); f.set_noise(1e-3 * np.eye(n), np.array([[1e-2]]))
+    assert f.update(np.array([0.5])) == orc.ERR_DIMS
+    with pytest.raises(ga.KalmanError, match="dimension mismatch"):
+        b.update(np.array([0.5]))
