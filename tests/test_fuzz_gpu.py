@@ -89,3 +89,67 @@ def test_information_stale_rinv_shape_mismatch_is_an_error():
     assert f.update(np.array([0.5])) == orc.ERR_DIMS
     with pytest.raises(ga.KalmanError, match="dimension mismatch"):
         b.update(np.array([0.5]))
+
+
+@pytest.mark.parametrize("kind,n,p,dtype,tol", [(k.HYBRID, 6, 2, k.F64, 1e-8), (k.SRIF, 6, 2, k.F64, 1e-8), (k.SRIF, 12, 6, k.F64, 1e-8),
+                                                (k.SRIF, 12, 6, k.F32, 5e-3)])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_nldkf_call_sequences_match_the_oracle(kind, n, p, dtype, tol, seed):
+    """Prepare / PreparePNT / Update / Predict / EnableEKF / DisableEKF / Reset in random order (hybrid.go, srif.go): covers the
+    host-side bookkeeping behind the kernel choice (SRIF's triangular-R tracking, the SNC / Predict instantiation of the
+    Hybrid kernel, lock / unlock)."""
+    rng = np.random.default_rng(100 * seed + n)
+    N, nops, q = 70, 30, 3
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-3), np.log(1e-1), size=(N, p)))
+    Aq = rng.standard_normal((N, q, q)); Q = 1e-6 * (Aq @ np.swapaxes(Aq, 1, 2) + np.eye(q))
+    hyb = kind == k.HYBRID
+    b = ga.FilterBatch(kind, n, p, q if hyb else 0, N, dtype=dtype)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p)
+    if hyb:
+        b.set(k.Q, Q, 2)
+    b.init()
+    fs = [orc.Filter.hybrid(x0[i], P0[i], Q[i], R[i], p) if hyb else orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+    for _ in range(nops):
+        op = rng.choice(["update", "update", "update", "predict", "ekf", "reset", "pnt"])
+        if op in ("update", "predict", "pnt"):
+            Phi = np.eye(n) + 1e-2 * rng.standard_normal((N, n, n)); Ht = rng.standard_normal((N, p, n))
+            b.prepare(Phi, Ht)
+            for i, f in enumerate(fs):
+                f.prepare(Phi[i], Ht[i])
+            if op == "pnt" and hyb:
+                Gam = rng.standard_normal((N, n, q))
+                b.prepare_pnt(Gam)
+                for i, f in enumerate(fs):
+                    f.prepare_pnt(Gam[i])
+            if op == "predict":
+                b.predict_nl()
+                for f in fs:
+                    assert f.predict_nl() == orc.OK
+            else:
+                real = rng.standard_normal((N, p)); comp = real + 1e-2 * rng.standard_normal((N, p))
+                b.update_nl(real, comp)
+                for i, f in enumerate(fs):
+                    assert f.update_nl(real[i], comp[i]) == orc.OK
+        elif op == "ekf" and hyb:
+            on = bool(rng.integers(2))
+            b.enable_ekf() if on else b.disable_ekf()
+            for f in fs:
+                f.enable_ekf(on)
+        elif op == "reset":
+            b.reset()
+            for f in fs:
+                f.reset()
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((N, n, n)); Ht = rng.standard_normal((N, p, n))
+    real = rng.standard_normal((N, p)); comp = real + 1e-2 * rng.standard_normal((N, p))
+    b.prepare(Phi, Ht)
+    est = b.update_nl(real, comp)
+    xs, Ps = [], []
+    for i, f in enumerate(fs):
+        f.prepare(Phi[i], Ht[i])
+        assert f.update_nl(real[i], comp[i]) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= tol
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= tol
+    assert not b.status().any()
