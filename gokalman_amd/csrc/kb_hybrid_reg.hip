@@ -12,7 +12,7 @@ namespace kb {
 // SNCP: the instantiation that also handles SNC (PreparePNT) and Predict(); the plain update stays free of their
 // branches and registers (it is the D(ii) benchmark path).
 template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT, bool SNCP = false>
-__global__ void __launch_bounds__(256, 2) hybrid_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(256, (SNCP && FULL) ? 1 : 2) hybrid_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -53,7 +53,7 @@ __device__ __forceinline__ void stnt(const TilePtr<T> &p, int e, T v) { p.stnt(e
 // the condition-number test see the real sizes.  This is how shapes without an exact instantiation still get a
 // register-resident kernel (kb_vanilla_pad.hip).
 template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false>
-__global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(T) * NS * NS > 300)) ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(T) * (NS * NS + NS * NM) > 8 * 56)) ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     constexpr int TM = tri(NM);
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;   // real sizes (compile-time constants unless PAD)
