@@ -95,17 +95,19 @@ __device__ __forceinline__ bool lu_solve_inplace(T (&a)[P * P], T (&b)[P * C]) {
 #pragma unroll
         for (int r = j + 1; r < P; r++) {
             const bool sw = fabs(a[r * P + j]) > fabs(a[j * P + j]);
+            if (__any(sw)) {   // wave-uniform: the exchange code (2 selects per element) only runs when some lane needs it
 #pragma unroll
-            for (int c = j; c < P; c++) {
-                const T t0 = a[j * P + c], t1 = a[r * P + c];
-                a[j * P + c] = sw ? t1 : t0;
-                a[r * P + c] = sw ? t0 : t1;
-            }
+                for (int c = j; c < P; c++) {
+                    const T t0 = a[j * P + c], t1 = a[r * P + c];
+                    a[j * P + c] = sw ? t1 : t0;
+                    a[r * P + c] = sw ? t0 : t1;
+                }
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                const T u0 = b[j * C + c], u1 = b[r * C + c];
-                b[j * C + c] = sw ? u1 : u0;
-                b[r * C + c] = sw ? u0 : u1;
+                for (int c = 0; c < C; c++) {
+                    const T u0 = b[j * C + c], u1 = b[r * C + c];
+                    b[j * C + c] = sw ? u1 : u0;
+                    b[r * C + c] = sw ? u0 : u1;
+                }
             }
         }
         const T piv = a[j * P + j];
