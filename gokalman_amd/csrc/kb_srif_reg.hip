@@ -307,33 +307,22 @@ __device__ __forceinline__ void shouseholder_rows(T (&A)[(NN + MM) * (NN + 1)], 
 }
 
 template <typename T, int NS>
-constexpr bool srif_fused_fits() { return sizeof(T) * 4 * NS * (NS + 1) * KB_TILE <= 160 * 1024; }
+constexpr bool srif_fused_fits() { return sizeof(T) * 4 * (NS * (NS + 1) + 1) * KB_TILE + 64 <= 160 * 1024; }
 
-template <typename T, int NS, int NM, bool FULL, bool EXT>
-__global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
+// Phase A for one tile: (b, R upper, Phi) -> the LDS panel [RBar | bBar] plus an "ok" slot (0 when the filter is frozen
+// by an earlier failure or Phi / R turned out singular; the status word is updated here).
+template <typename T, int NS, bool EXT>
+__device__ __forceinline__ void srif_time_to_panel(const StepArgs &a, int64_t tile, int lane, T *panel) {
     constexpr int COLS = NS + 1, RG = 2;
     static_assert(NS % RG == 0, "row groups");
-    // one wave per workgroup: the four waves of a CU are scheduled independently and drift apart, so that one wave's
-    // load phase overlaps another's arithmetic (a 4-wave workgroup keeps them in lockstep)
-    __shared__ T lds[srif_fused_fits<T, NS>() ? NS * COLS * KB_TILE : 1];
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.x;
     const int64_t fi = tile * KB_TILE + lane;
     const bool inb = fi < a.N;
     const bool active = inb && (a.status[inb ? fi : 0] & (KB_ST_SINGULAR | KB_ST_ASYMMETRIC | KB_ST_NONFINITE)) == 0u;  // failed earlier: frozen
-    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
+    const T *st = (const T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *ephi = EXT ? (const T *)a.ext_phi + (inb ? fi : 0) : nullptr;
-    const T *eh = EXT ? (const T *)a.ext_h + (inb ? fi : 0) : nullptr;
-    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
-    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
-    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
-    T *panel = lds + lane;   // element (i, c) at panel[(i * COLS + c) * KB_TILE]
     unsigned err = 0;
-    // Every input of the step is requested before the first use (339 values per lane in flight; the 512-register budget
-    // of one wave per SIMD holds them), so a wave waits for memory once instead of once per phase.
-    T xprev[NS], lu[NS * NS], Hh[NM * NS], Lw[tri(NM)], yv[NM];
-    [[maybe_unused]] T yreal[NM];
+    T xprev[NS], lu[NS * NS];
     {
         T Ru[tri(NS)];   // upper triangle of R, Ru[symi(i, j)], i <= j
 #pragma unroll
@@ -344,17 +333,6 @@ __global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
             for (int j = i; j < NS; j++) Ru[symi(i, j)] = ldt(st, NS + i * NS + j);
 #pragma unroll
         for (int e = 0; e < NS * NS; e++) lu[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
-#pragma unroll
-        for (int e = 0; e < NM * NS; e++) Hh[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
-#pragma unroll
-        for (int e = 0; e < tri(NM); e++) Lw[e] = ldnt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
-#pragma unroll
-        for (int r = 0; r < NM; r++) {
-            const T re = inb ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
-            const T co = inb ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
-            yv[r] = re - co;
-            if constexpr (FULL) yreal[r] = re;
-        }
         __builtin_amdgcn_sched_barrier(0);
         // State(prev) = R^-1 b by back substitution (srif.go:223-234); the rows of R wait in the LDS panel for the solves
 #pragma unroll
@@ -407,7 +385,8 @@ __global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
             for (int c = j + 1; c < NS; c++) lu[r * NS + c] -= l * lu[j * NS + c];
         }
     }
-    if (err) { if (active) atomicOr(a.status + fi, err); return; }
+    if (err && active) atomicOr(a.status + fi, err);
+    panel[NS * COLS * KB_TILE] = (active && !err) ? T(1) : T(0);   // a failed filter keeps its estimate: the measurement half skips it
     int poff[NS];
     T xBarP[NS];
 #pragma unroll
@@ -457,7 +436,35 @@ __global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
             panel[((i0 + g) * COLS + NS) * KB_TILE] = bb;
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Phase B for one tile: the LDS panel [RBar | bBar] + (Htilde, chol_L(R), real, computed) -> Householder -> b, R (upper).
+template <typename T, int NS, int NM, bool FULL, bool EXT, typename W, typename F>
+__device__ __forceinline__ void srif_meas_from_panel(const StepArgs &a, int64_t tile, int lane, const T *panel, W &&wait_panel, F &&panel_consumed) {
+    constexpr int COLS = NS + 1;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool inb = fi < a.N;
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    const T *eh = EXT ? (const T *)a.ext_h + (inb ? fi : 0) : nullptr;
+    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
+    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
+    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
+    T Hh[NM * NS], Lw[tri(NM)], yv[NM];
+    [[maybe_unused]] T yreal[NM];
+#pragma unroll
+    for (int e = 0; e < NM * NS; e++) Hh[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
+#pragma unroll
+    for (int e = 0; e < tri(NM); e++) Lw[e] = ldnt(mo, a.L.mo_LR + e);  // QUIRK srif.go:48: chol_L(R), not its inverse
+#pragma unroll
+    for (int r = 0; r < NM; r++) {
+        const T re = inb ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
+        const T co = inb ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
+        yv[r] = re - co;
+        if constexpr (FULL) yreal[r] = re;
+    }
+    wait_panel();   // the loads above are in flight while phase A of this tile finishes
+    const bool active = inb && panel[NS * COLS * KB_TILE] != T(0);
     // ---- measurement update (srif.go:143-156, :298-340): Householder on [[RBar bBar],[L Htilde, L y]]
     T A[(NS + NM) * COLS];
     {
@@ -492,6 +499,7 @@ __global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
             A[i * COLS + j] = panel[(i * COLS + j) * KB_TILE];
             if constexpr (FULL) { if (active && j < NS) stt(es, a.L.es_ppred + i * NS + j, A[i * COLS + j]); }
         }
+    panel_consumed();   // the buffer may be refilled while the Householder runs on registers
     // A non-finite result is stored as it is (what the reference's unguarded HouseholderTransf leaves behind,
     // helper.go:142-172) and flagged in the status word.
     T chk = T(0);
@@ -515,6 +523,52 @@ __global__ void __launch_bounds__(64, 1) srif_fused_kernel(const StepArgs a) {
     if (active && chk != chk) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
 }
 
+// The fused Update as a two-stage pipeline inside a workgroup of two waves: wave 0 runs phase A (time update) of the
+// workgroup's tiles into two LDS panel buffers, wave 1 runs phase B (measurement update) out of them.  The waves hand
+// buffers over through LDS flags, not barriers, so that they drift apart: one wave's loads are in flight while its
+// partner computes, which a single wave doing both halves cannot arrange (no registers left to prefetch into) and a
+// barrier per tile would undo (both would load, then both compute).  Persistent grid (two workgroups per CU:
+// 2 x 2 x 39 KB of LDS), tiles strided by the grid size.
+template <typename T, int NS, int NM, bool FULL, bool EXT>
+__global__ void __launch_bounds__(128, 1) srif_fused_kernel(const StepArgs a) {
+    constexpr int SLOTS = NS * (NS + 1) + 1;
+    __shared__ T lds[srif_fused_fits<T, NS>() ? 2 * SLOTS * KB_TILE : 1];
+    __shared__ int full[2];   // 1: the panel buffer holds a tile for wave 1; 0: wave 0 may (re)fill it
+    const int lane = threadIdx.x & 63;
+    const bool first_half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+    if (threadIdx.x < 2) full[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = gridDim.x;
+    int it = 0;
+    for (int64_t cur = blockIdx.x; cur < a.ntiles; cur += stride, it++) {
+        const int bsel = it & 1;
+        T *panel = lds + bsel * (SLOTS * KB_TILE) + lane;
+        auto wait_for = [&](int want) {
+            while (__hip_atomic_load(&full[bsel], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+        };
+        if (first_half) {
+            wait_for(0);
+            srif_time_to_panel<T, NS, EXT>(a, cur, lane, panel);
+            __hip_atomic_store(&full[bsel], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            srif_meas_from_panel<T, NS, NM, FULL, EXT>(a, cur, lane, panel, [&]() { wait_for(1); }, [&]() {
+                __hip_atomic_store(&full[bsel], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            });
+        }
+    }
+}
+
+static int num_cus(int device) {
+    static int cached[64] = {0};
+    if (device < 0 || device >= 64) return 256;
+    if (!cached[device]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+        cached[device] = n;
+    }
+    return cached[device];
+}
+
 static bool srif_shape_ok(const StepArgs &a, int NS, int NM) { return a.n == NS && a.p == NM; }
 
 template <typename T, int NS, int NM>
@@ -524,7 +578,8 @@ static bool srif_try(const Batch &b, const StepArgs &a) {
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
     if constexpr (srif_fused_fits<T, NS>()) {
         if (!a.predict && a.srif_tri) {
-#define KB_F(F_, E_) hipLaunchKernelGGL((srif_fused_kernel<T, NS, NM, F_, E_>), dim3((unsigned)a.ntiles), dim3(64), 0, b.stream, a)
+            const int64_t slots = 2 * (int64_t)num_cus(b.device);   // two resident workgroups per CU
+#define KB_F(F_, E_) hipLaunchKernelGGL((srif_fused_kernel<T, NS, NM, F_, E_>), dim3((unsigned)(a.ntiles < slots ? a.ntiles : slots)), dim3(128), 0, b.stream, a)
             if (full) { if (ext) KB_F(true, true); else KB_F(true, false); }
             else      { if (ext) KB_F(false, true); else KB_F(false, false); }
 #undef KB_F
