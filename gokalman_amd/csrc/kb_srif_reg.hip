@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(128, 1) srif_fused_kernel(const StepArgs a) {
         const int bsel = it & 1;
         T *panel = lds + bsel * (SLOTS * KB_TILE) + lane;
         auto wait_for = [&](int want) {
-            while (__hip_atomic_load(&full[bsel], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(&full[bsel], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(8);
         };
         if (first_half) {
             wait_for(0);
