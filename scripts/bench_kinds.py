@@ -34,9 +34,16 @@ def timed(b, fn, K=20, warm=3):
     return e0.elapsed_time(e1) / K
 
 
-def report(name, N, ms, bytes_per, extra=None):
+def report(name, N, ms, bytes_per, extra=None, dtype="f64"):
+    """One JSON line per config, with the keys of bench.py's contract line (value = filter-update steps/s with the inputs
+    resident in HBM; roofline.achieved = BASELINE.md section 4's algorithmic bytes x filters / kernel time)."""
+    gbps = N * bytes_per / (ms * 1e-3) / 1e9
     out = {"config": name, "filters": N, "ms_per_step": ms, "steps_per_s": N / (ms * 1e-3),
-           "algorithmic_GBps": N * bytes_per / (ms * 1e-3) / 1e9, "frac_of_8TBps": N * bytes_per / (ms * 1e-3) / 8e12}
+           "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0,
+           "metric": "filter-update steps/s", "value": N / (ms * 1e-3), "unit": "filter-update steps/s", "n_gpus": 1,
+           "higher_is_better": True, "dtype": dtype, "data": "synthetic",
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
+                        "algorithmic_bytes_per_launch": N * bytes_per}}
     if extra:
         out.update(extra)
     print(json.dumps(out), flush=True)
@@ -81,7 +88,7 @@ if "srif" in which:
             k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
         ms = timed(b, step, K=10)
         # update only (model already resident): re-arm the lock without re-uploading
-        report(nm + " (prepare_dev + update_nl_dev)", N, ms, 576 * w, {"errors": int(np.count_nonzero(b.status()))})
+        report(nm + " (prepare_dev + update_nl_dev)", N, ms, 576 * w, {"errors": int(np.count_nonzero(b.status()))}, dtype="f32" if dt == k.F32 else "f64")
         del b
 
 if "hybrid" in which:
