@@ -198,3 +198,23 @@ def test_vanilla_padded_register_kernels_vs_oracle(n, p, m, full):
         assert synth.rel_frobenius(est.pred_covariance(), np.array(Pm)) <= TOL
         assert synth.rel_frobenius(est.innovation(), np.array(inn)) <= TOL
     assert not b.status().any()
+
+
+@pytest.mark.parametrize("kind,okind", [(k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)])
+def test_parity_gate_4096_filters_100_steps(kind, okind):
+    """SURVEY 8d's parity gate for configs B and C as written: the first 4096 filters x 100 steps of the benchmark batch
+    (same generator, same seed), device-resident measurements, max relative Frobenius error <= 1e-9 for x and P."""
+    import torch
+    N, T, n, p = 4096, 100, 6, 3
+    d = synth.linear_batch(N, n, p, T)
+    b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()      # planar [T][p][N]
+    for t in range(T):
+        b.update_dev(y[t].data_ptr(), N)
+    b.synchronize()
+    xo, Po, nerr = orc.ldkf_batch(okind, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+    assert nerr == 0 and not b.status().any()
+    x, P = b.get(k.STATE), b.get(k.COVAR)
+    ex = np.linalg.norm(x - xo, axis=1) / np.linalg.norm(xo, axis=1)
+    eP = np.linalg.norm((P - Po).reshape(N, -1), axis=1) / np.linalg.norm(Po.reshape(N, -1), axis=1)
+    assert ex.max() <= 1e-9 and eP.max() <= 1e-9, (ex.max(), eP.max())
