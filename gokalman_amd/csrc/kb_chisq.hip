@@ -22,12 +22,6 @@ namespace kb {
 constexpr int CHI_REPL = 32;
 
 
-__device__ __forceinline__ double chi_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 struct ChiArgs {
     const void *t_state, *t_model;  // truth batch (pure predictor, AWGN factors in its model block)
     const void *k_state, *k_model;  // filter batch (initial estimate + model)
@@ -276,11 +270,14 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
             }
             nees = (double)s;
         }
-        const double s1 = chi_wave_sum(active ? nis : 0.0), s2 = chi_wave_sum(active ? nees : 0.0);
-        if (lane == 0) {
-            atomicAdd(my + (size_t)t * 2 + 0, s1);
-            atomicAdd(my + (size_t)t * 2 + 1, s2);
-        }
+        // both sums in one butterfly: lanes swap one of the two values first, so 1 + 5 exchanges instead of 2 x 6; even
+        // lanes end with the NIS total, odd lanes with the NEES total, and lanes 0 / 1 add them with one atomic instruction
+        const double v0 = active ? nis : 0.0, v1 = active ? nees : 0.0;
+        const bool odd = (lane & 1) != 0;
+        double acc = (odd ? v1 : v0) + __shfl_xor(odd ? v0 : v1, 1, 64);
+#pragma unroll
+        for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane < 2) atomicAdd(my + (size_t)t * 2 + lane, acc);
     }
 }
 
