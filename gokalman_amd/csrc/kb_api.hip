@@ -68,6 +68,18 @@ int ensure_stage(Batch &b, size_t bytes) {
     return KB_OK;
 }
 
+int ensure_pin(Batch &b) {
+    if (b.h_pin) return KB_OK;
+    KB_HIP(hipHostMalloc(&b.h_pin, 3 * KB_PIN_TILE_BYTES + KB_PIN_OUT_BYTES, hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&b.d_pin, b.h_pin, 0) != hipSuccess) {
+        (void)hipHostFree(b.h_pin);
+        b.h_pin = b.d_pin = nullptr;
+        set_error("hipHostGetDevicePointer failed");
+        return KB_ERR_HIP;
+    }
+    return KB_OK;
+}
+
 int ensure_xp(Batch &b) {
     if (b.d_xp) return KB_OK;
     KB_HIP(hipMalloc(&b.d_xp, b.block_bytes(b.n + tri(b.n))));
@@ -185,7 +197,19 @@ static int launch_step(Batch &b, const StepArgs &a, bool fused) {
 }
 
 // host [N][rows] -> AoSoA staging block with `rows` elements per filter
-int stage_host_vec(Batch &b, const double *host, int rows, void **dblock) {
+int stage_host_vec(Batch &b, const double *host, int rows, void **dblock, int slot, const void **tile) {
+    if (b.N <= KB_TILE) {   // one tile: the host transposes straight into the pinned buffer, no copy, no pack launch
+        int rc = ensure_pin(b);
+        if (rc) return rc;
+        char *dst = (char *)b.h_pin + (size_t)slot * KB_PIN_TILE_BYTES;
+        for (int e = 0; e < rows; e++)
+            for (int64_t f = 0; f < b.N; f++) {
+                if (b.dtype == KB_F64) ((double *)dst)[e * KB_TILE + f] = host[f * rows + e];
+                else ((float *)dst)[e * KB_TILE + f] = (float)host[f * rows + e];
+            }
+        *tile = (const char *)b.d_pin + (size_t)slot * KB_PIN_TILE_BYTES;
+        return KB_OK;
+    }
     const size_t bytes = (size_t)b.N * rows * sizeof(double);
     int rc = ensure_stage(b, bytes);
     if (rc) return rc;
@@ -196,6 +220,7 @@ int stage_host_vec(Batch &b, const double *host, int rows, void **dblock) {
     }
     int16_t map[KB_MAX_DIM * KB_MAX_DIM];
     map_dense(1, rows, 0, rows, map);
+    *tile = *dblock;
     return launch_pack(b, b.d_stage, rows, b.N, false, *dblock, rows, map);
 }
 
@@ -269,6 +294,7 @@ void kb_destroy(kb_batch *b) {
                     b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (b->h_pin) (void)hipHostFree(b->h_pin);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -434,15 +460,16 @@ int kb_update(kb_batch *b, const double *meas, int meas_rows, const double *ctrl
     if (!meas) { set_error("measurement is NULL"); return KB_ERR_INVALID; }
     if ((rc = check_update_dims(b, meas_rows, ctrl_rows, ctrl != nullptr))) return rc;
     if ((rc = check_batch_noise(b, 1))) return rc;
-    if ((rc = stage_host_vec(*b, meas, meas_rows, &b->d_y))) return rc;
+    const void *ytile = nullptr, *utile = nullptr;
+    if ((rc = stage_host_vec(*b, meas, meas_rows, &b->d_y, 0, &ytile))) return rc;
     if (b->need_ctrl) {
         // the staging buffer is reused: order the two packs on the stream
-        if ((rc = stage_host_vec(*b, ctrl, ctrl_rows, &b->d_u))) return rc;
+        if ((rc = stage_host_vec(*b, ctrl, ctrl_rows, &b->d_u, 1, &utile))) return rc;
     }
     StepArgs a;
     fill_step_args(*b, a);
-    a.y = b->d_y; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * meas_rows; a.y_step = 0;
-    if (b->need_ctrl) { a.u = b->d_u; a.u_es = KB_TILE; a.u_ts = (int64_t)KB_TILE * ctrl_rows; a.u_step = 0; }
+    a.y = ytile; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * meas_rows; a.y_step = 0;
+    if (b->need_ctrl) { a.u = utile; a.u_es = KB_TILE; a.u_ts = (int64_t)KB_TILE * ctrl_rows; a.u_step = 0; }
     if ((rc = launch_step(*b, a, false))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));
     b->step++;
@@ -562,6 +589,16 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
         return KB_ERR_INVALID;
     }
     const size_t bytes = (size_t)count * out_elems * sizeof(double);
+    if (bytes <= KB_PIN_OUT_BYTES && !ensure_pin(*b)) {   // small read-back: the kernel writes the pinned host buffer itself
+        const size_t off = 3 * KB_PIN_TILE_BYTES;
+        rc = launch_unpack(*b, block, block_elems, map, out_elems, (double *)((char *)b->d_pin + off), first, count);
+        if (!rc) {
+            const hipError_t e = hipStreamSynchronize(b->stream);
+            if (e != hipSuccess) return hip_fail(e, "kb_get");
+            memcpy(host, (const char *)b->h_pin + off, bytes);
+        }
+        return rc;
+    }
     if ((rc = ensure_stage(*b, bytes))) return rc;
     rc = launch_unpack(*b, block, block_elems, map, out_elems, (double *)b->d_stage, first, count);
     if (!rc) {

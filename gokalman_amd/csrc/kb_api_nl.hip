@@ -99,12 +99,13 @@ int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const doubl
         set_error("dimensions must agree: observation(%dx1) Htilde(%dx...)", real_rows, b->p);
         return KB_ERR_DIMS;
     }
-    if ((rc = stage_host_vec(*b, real_obs, real_rows, &b->d_y))) return rc;
-    if ((rc = stage_host_vec(*b, computed_obs, computed_rows, &b->d_y2))) return rc;
+    const void *rtile = nullptr, *ctile = nullptr;
+    if ((rc = stage_host_vec(*b, real_obs, real_rows, &b->d_y, 0, &rtile))) return rc;
+    if ((rc = stage_host_vec(*b, computed_obs, computed_rows, &b->d_y2, 2, &ctile))) return rc;
     StepArgs a;
     fill_step_args(*b, a);
-    a.y = b->d_y; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * real_rows;
-    a.y2 = b->d_y2; a.y2_es = KB_TILE; a.y2_ts = (int64_t)KB_TILE * real_rows;
+    a.y = rtile; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * real_rows;
+    a.y2 = ctile; a.y2_es = KB_TILE; a.y2_ts = (int64_t)KB_TILE * real_rows;
     if ((rc = nl_common(b, a, false))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));
     return KB_OK;

@@ -45,6 +45,9 @@ struct Batch {
     void *d_stage = nullptr;   // AoS staging for host <-> device transfers
     size_t stage_bytes = 0;
     void *d_y = nullptr, *d_u = nullptr;  // AoSoA staging of host measurements / controls
+    // Batches of at most one tile (the reference's own use: one filter) skip the staging copies: the host writes / reads a
+    // pinned, device-mapped buffer the kernels access directly (3 input tiles + one read-back area).
+    void *h_pin = nullptr, *d_pin = nullptr;
     void *d_y2 = nullptr;
     void *d_xp = nullptr;      // cached getter scratch: materialised State() | Covariance() (x[n] | P packed) per filter
     uint8_t *d_flags = nullptr;  // cached IsWithinNsigma output
@@ -135,7 +138,10 @@ int mc_repl();
 int use_device(const Batch &b);
 int ensure_stage(Batch &b, size_t bytes);
 int ensure_xp(Batch &b);  // allocates Batch::d_xp on first use
-int stage_host_vec(Batch &b, const double *host, int rows, void **dblock);
+int stage_host_vec(Batch &b, const double *host, int rows, void **dblock, int slot, const void **tile);  // *tile: the AoSoA tile(s) the step kernel reads
+int ensure_pin(Batch &b);
+constexpr size_t KB_PIN_TILE_BYTES = (size_t)KB_MAX_DIM * KB_TILE * sizeof(double);
+constexpr size_t KB_PIN_OUT_BYTES = (size_t)KB_TILE * KB_MAX_DIM * KB_MAX_DIM * sizeof(double);
 void fill_step_args(const Batch &b, StepArgs &a);
 int upload_field(Batch &b, int field, const double *host, int64_t count, int broadcast, int p_rows);
 
