@@ -258,12 +258,12 @@ static bool hybrid_try(const Batch &b, const StepArgs &a) {
 }
 
 bool hybrid_reg_ok(const Batch &b, const StepArgs &a) {
-    return b.dtype == KB_F64 && (hybrid_shape_ok(a, 6, 2) || hybrid_shape_ok(a, 6, 3));
+    return b.dtype == KB_F64 && (hybrid_shape_ok(a, 6, 2) || hybrid_shape_ok(a, 6, 3) || hybrid_shape_ok(a, 6, 1));
 }
 
 int launch_hybrid(const Batch &b, const StepArgs &a) {
     bool done = false;
-    if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a);
+    if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a) || hybrid_try<double, 6, 1>(b, a);
     if (!done) return launch_hybrid_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

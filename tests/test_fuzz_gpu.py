@@ -91,7 +91,7 @@ def test_information_stale_rinv_shape_mismatch_is_an_error():
         b.update(np.array([0.5]))
 
 
-@pytest.mark.parametrize("kind,n,p,dtype,tol", [(k.HYBRID, 6, 2, k.F64, 1e-8), (k.SRIF, 6, 2, k.F64, 1e-8), (k.SRIF, 12, 6, k.F64, 1e-8),
+@pytest.mark.parametrize("kind,n,p,dtype,tol", [(k.HYBRID, 6, 2, k.F64, 1e-8), (k.HYBRID, 6, 1, k.F64, 1e-8), (k.HYBRID, 6, 3, k.F64, 1e-8), (k.SRIF, 6, 2, k.F64, 1e-8), (k.SRIF, 12, 6, k.F64, 1e-8),
                                                 (k.SRIF, 12, 6, k.F32, 5e-3)])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_nldkf_call_sequences_match_the_oracle(kind, n, p, dtype, tol, seed):

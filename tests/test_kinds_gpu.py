@@ -309,7 +309,7 @@ def test_awgn_moments_and_vanilla_awgn_replay():
                                 noise=k.NOISE_AWGN)
 
 
-@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32)])
+@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
     import torch
