@@ -214,3 +214,32 @@ def test_nan_measurement_is_contained_to_its_filter():
     ok = np.arange(N) != 77
     xo, Po, _ = orc.ldkf_batch(orc.VANILLA, d["x0"][ok], d["P0"][ok], d["F"][ok], d["H"][ok], d["Q"][ok], d["R"][ok], d["y"][:1, ok])
     assert synth.rel_frobenius(b.get(k.STATE)[ok], xo) <= 1e-9
+
+
+def test_two_handles_driven_from_two_threads_concurrently():
+    """Threading contract of the C ABI (include/gokalman_amd.h): a handle is single-threaded like a reference filter, distinct
+    handles may be driven from distinct threads (one HIP stream each).  Two threads step two batches at the same time; each
+    must end bit-identical to the same batch stepped alone."""
+    import threading
+    N, steps = 4096, 40
+    data = [synth.linear_batch(N, 6, 3, steps, seed=synth.SEED + 10 + i) for i in range(2)]
+    kinds = [k.VANILLA, k.SQUAREROOT]
+
+    def run(i, out):
+        d = data[i]
+        b = ga.FilterBatch.new_ldkf(kinds[i], d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        for t in range(steps):
+            b.update(d["y"][t])
+        out[i] = (b.get(k.STATE), b.get(k.COVAR), int(np.count_nonzero(b.status())))
+
+    alone, together = {}, {}
+    for i in range(2):
+        run(i, alone)
+    threads = [threading.Thread(target=run, args=(i, together)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        assert together[i][2] == 0
+        assert np.array_equal(alone[i][0], together[i][0]) and np.array_equal(alone[i][1], together[i][1])
