@@ -3,16 +3,28 @@
 
 One "step" = one LDKF.Update over this rank's batch of independent filters, i.e. ONE launch
 of the Vanilla step kernel through the C ABI (kb_update_dev), measurements already in HBM.
-Weak scaling: every GPU owns `--filters` filters (default 2^20); no data-path collective
-(filters are independent).
+Weak scaling: every GPU owns `--filters` filters (default 2^20); no collective in the update
+path (filters are independent).  The job's epilogue holds the collectives
+the path does have: an all-reduce of the per-rank step / error counts, and the Monte-Carlo
+statistics reduction of montecarlo.go:18-59 (config D, `extra.mc`).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (vanilla_reg_kernel<f64,6,3>) vs the HBM roof, measured live
-                  with HIP events on the kernel's own stream; algorithmic bytes = 1488 B per
-                  filter-step x filters per launch.
+With --gpus N > 1 and no WORLD_SIZE in the environment this process starts N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, before
+anything here touches the GPU) and forwards their exit code; under torchrun it is one rank.
+It never reports a 1-rank number for an N-rank request: fewer visible GPUs than ranks is an error.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline     -- dominant kernel (vanilla_reg_kernel<f64,6,3>) against the HBM roof.  `frac` is
+                  PHYSICAL: bytes the launch moves (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of the
+                  committed profile, = the packed working set of 1104 B per filter) / kernel time
+                  (HIP events on the kernel's stream, live) / 8 TB/s.  The contract's algorithmic
+                  figure (1488 B per filter-step, full matrices) is `frac_algorithmic`; it can
+                  exceed 1 because a SymDense carries only its upper triangle.
+  out_of_cache -- the same kernel on a batch whose state block cannot stay in the Infinity Cache.
+  fused        -- the caller loop inside one launch (VALU-issue-bound), with its issue-rate roofline.
+  extra.mc / extra.hybrid_ekf -- config D sharded over the same ranks.
   cpu_baseline -- the CPU oracle (reference-order C restatement of vanilla.go:128-220, the
                   reference's Go toolchain is absent) timed on this host's cores on a bounded
                   sample of the same workload.  A reported baseline, not the target.
@@ -20,16 +32,61 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_FILTER_STEP = 1488      # 8 B x (4n^2 + pn + p^2 + 2n + p), n=6, p=3
-HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_STATE, N_MEAS = 6, 3
+HEADLINE_KERNEL = "vanilla_reg_kernel<double, 6, 3, 0"
+# fp64 FMA-class VALU instructions per filter tile and step of vanilla_reg_kernel<..., FUSED> (static count of the
+# fully unrolled step body; scripts/resource_usage.py prints it, profiles/r02*/valu_counters.md confirms it with SQ_INSTS_VALU)
+FUSED_VALU_PER_STEP = None  # filled from profiles/valu_latest.json when present
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--filters", type=int, default=1 << 20, help="filters per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-steps", type=int, default=16, help="T of the extra time-fused measurement (0 = skip)")
+    ap.add_argument("--ooc-filters", type=int, default=1 << 22,
+                    help="filters of the out-of-Infinity-Cache measurement of the same kernel (0 = skip)")
+    ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")
+    ap.add_argument("--mc-steps", type=int, default=1086)
+    ap.add_argument("--hybrid-filters", type=int, default=1 << 20, help="Hybrid EKF filters per GPU for extra.hybrid_ekf (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, one GPU per rank) or gloo (testing the N>1 path with several ranks on one GPU)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a child job.  Nothing in this process has
+    touched the GPU (torch.cuda.device_count() does not initialise it on this image); no exec."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.dist_backend == "nccl" and ndev < args.gpus:
+        raise SystemExit("--gpus %d requested but only %d GPU(s) visible: RCCL needs one GPU per rank" % (args.gpus, ndev))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _cpu_baseline(d, budget_s=8.0):
@@ -60,24 +117,30 @@ def _cpu_baseline(d, budget_s=8.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--filters", type=int, default=1 << 20, help="filters per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused-steps", type=int, default=16, help="T of the extra time-fused measurement (0 = skip)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing the N>1 path on fewer GPUs)")
-    args = ap.parse_args()
+STATOD = dict(  # examples/statOD5044/main.go:36-57
+    F=[[1, 0.1, 0, 7.726e-2], [4.015e-7, 1, 0, 1.545], [-2.319e-16, -1.732e-9, 1, 0.1], [-6.956e-15, -3.465e-8, 0, 1]],
+    G=[[5e-3, 3.85e-7], [0.1, 1.157e-5], [-5.775e-11, 7.487e-7], [1.732e-9, 1.498e-5]],
+    H=[[1.0, 0, 0, 0], [0, 0, 1, 0]],
+    Q=[[6.669e-16, 1.001e-14, 3.823e-19, 5.150e-18], [1.001e-14, 2.002e-13, 1.030e-17, 1.545e-16],
+       [3.862e-19, 1.030e-17, 6.667e-19, 1.000e-17], [5.150e-18, 1.545e-16, 1.000e-17, 2.000e-16]],
+    R=[[2e-2, 0], [0, 2e-4]], x0=[2, 0.5, 0, 0.0], P0=[[5, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0.01, 0], [0, 0, 0, 1e-5]])
 
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -86,55 +149,74 @@ def main():
         raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank" % (world, ndev))
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.dist_backend)
 
     import gokalman_amd as ga
     from gokalman_amd import _capi as k
+    from gokalman_amd import dist as kd
+    from gokalman_amd import roofline as rl
     from gokalman_amd import synth
-
-    N = args.filters
-    n, p = 6, 3
-    POOL = 4  # distinct measurement sets cycled through the timed steps
-    d = synth.linear_batch(N, n, p, POOL, seed=synth.SEED + rank)
-    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], device=local_rank)
-    y_dev = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda(local_rank)  # planar [POOL][p][N]
-    ptrs = [y_dev[t].data_ptr() for t in range(POOL)]
-    kstream = torch.cuda.ExternalStream(b.stream(), device=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        b.synchronize()
 
-    for t in range(args.warmup):
-        b.update_dev(ptrs[t % POOL], N)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(kstream)
-    for t in range(args.steps):
-        b.update_dev(ptrs[t % POOL], N)
-    ev1.record(kstream)
-    b.synchronize()
-    torch.cuda.synchronize()
-    local_s = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the kernel's stream
-    if world > 1:
-        tt = torch.tensor([local_s], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall_s = float(tt.item())
-        dist.barrier()
-    else:
-        wall_s = local_s
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds, [seconds]
+        t = torch.tensor([seconds], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [float(e.item()) for e in every]
+        return max(per_rank), per_rank
+
+    N = args.filters
+    n, p = N_STATE, N_MEAS
+    POOL = 4  # distinct measurement sets cycled through the timed steps
+    d = synth.linear_batch(N, n, p, POOL, seed=synth.SEED + rank)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], device=local_rank)
+    y_dev = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).to(dev)  # planar [POOL][p][N]
+    ptrs = [y_dev[t].data_ptr() for t in range(POOL)]
+    kstream = torch.cuda.ExternalStream(b.stream(), device=dev)
+
+    def timed_steps(batch, stream, pointers, ld, steps, warmup):
+        """warmup untimed steps, then EXACTLY `steps` launches bracketed by barrier + synchronize; returns
+        (wall seconds of this rank, HIP-event ms per launch on the kernel's stream)."""
+        for t in range(warmup):
+            batch.update_dev(pointers[t % len(pointers)], ld)
+        batch.synchronize()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for t in range(steps):
+            batch.update_dev(pointers[t % len(pointers)], ld)
+        ev1.record(stream)
+        batch.synchronize()
+        torch.cuda.synchronize()
+        local = time.perf_counter() - t0
+        barrier()
+        return local, ev0.elapsed_time(ev1) / steps
+
+    local_s, kernel_ms = timed_steps(b, kstream, ptrs, N, args.steps, args.warmup)
+    wall_s, per_rank_s = max_over_ranks(local_s)
     nbad = int(np.count_nonzero(b.status()))
 
-    # extra: the caller loop fused into one launch (x, P, model resident in registers)
+    # ---- epilogue collective: what every rank did, summed over RCCL (the update path itself has no exchange) --------
+    counts = torch.tensor([float(N) * args.steps, float(nbad), 1.0], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    total_filter_steps, total_bad, ranks_seen = float(counts[0].item()), int(counts[1].item()), int(counts[2].item())
+
+    # ---- extra: the caller loop fused into one launch (x, P, model resident in registers) ---------------------------
     fused = None
     if args.fused_steps > 0:
         T = args.fused_steps
@@ -151,18 +233,120 @@ def main():
         fms = f0.elapsed_time(f1) / reps
         fused = {"steps_per_launch": T, "ms_per_launch": fms, "value": N * T / (fms * 1e-3),
                  "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev)"}
+        try:
+            vj = json.load(open(os.path.join(ROOT, "profiles", "valu_latest.json")))
+            e = vj["kernels"]["vanilla_fused"]
+            fused["roofline"] = rl.valu_roofline(fms, (N + 63) // 64, e["valu_insts_per_wave_per_step"] * T,
+                                                 {"file": "profiles/valu_latest.json", "profile_tag": vj.get("tag"),
+                                                  "counter": "SQ_INSTS_VALU / SQ_WAVES", "live": False})
+        except Exception:
+            pass
+        del yy
+    del b, y_dev
+    torch.cuda.empty_cache()
+
+    # ---- extra: the same kernel with the state block far outside the 256 MiB Infinity Cache -------------------------
+    ooc = None
+    if args.ooc_filters > N and rank == 0:
+        M = args.ooc_filters
+        reps_n = (M + N - 1) // N
+        tile = lambda a: np.ascontiguousarray(np.concatenate([a] * reps_n, axis=0)[:M])
+        b2 = ga.FilterBatch.new_ldkf(k.VANILLA, tile(d["x0"]), tile(d["P0"]), tile(d["F"]), None, tile(d["H"]),
+                                     tile(d["Q"]), tile(d["R"]), device=local_rank)
+        y2 = torch.from_numpy(np.ascontiguousarray(np.concatenate([d["y"][0]] * reps_n, axis=0)[:M].T)).to(dev)  # [p][M]
+        s2 = torch.cuda.ExternalStream(b2.stream(), device=dev)
+        for _ in range(3):
+            b2.update_dev(y2.data_ptr(), M)
+        b2.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K2 = 20
+        e0.record(s2)
+        for _ in range(K2):
+            b2.update_dev(y2.data_ptr(), M)
+        e1.record(s2)
+        b2.synchronize()
+        ms2 = e0.elapsed_time(e1) / K2
+        moved = rl.moved_bytes("vanilla", n, p)
+        ooc = {"filters": M, "state_block_MB": M * (n + rl.tri(n)) * 8 / 1e6, "kernel_ms": ms2,
+               "value": M / (ms2 * 1e-3), "unit": "filter-update steps/s (1 GPU)",
+               "achieved": moved * M / (ms2 * 1e-3) / 1e9, "frac": moved * M / (ms2 * 1e-3) / 1e9 / rl.HBM_PEAK_GBPS,
+               "frac_of_achievable": moved * M / (ms2 * 1e-3) / 1e9 / rl.HBM_ACHIEVABLE_GBPS,
+               "note": "same kernel, state block >> 256 MiB Infinity Cache: every byte comes from / goes to HBM"}
+        del b2, y2
+        torch.cuda.empty_cache()
+    barrier()
+
+    # ---- extra: config D(i), montecarlo.go sharded by run index; the ONE collective of the path (montecarlo.go:18-59) --
+    extra = {}
+    if args.mc_runs > 0:
+        s = {kk: np.array(v, dtype=np.float64) for kk, v in STATOD.items()}
+        kf = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, s["x0"], s["P0"], s["F"], s["G"], s["H"], s["Q"], s["R"],
+                                     nfilters=args.mc_runs, device=local_rank, noise=k.NOISE_AWGN, seed=2016)
+        first = rank * args.mc_runs  # a run's noise depends only on its global index
+        ga.new_monte_carlo_runs(args.mc_runs, 4, 2, np.zeros((1, 2)), kf, first_run=first)  # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        mc = ga.new_monte_carlo_runs(args.mc_runs * world, args.mc_steps, 2, np.zeros((1, 2)), kf, first_run=first,
+                                     reduce=kd.allreduce_sum if world > 1 else None)
+        torch.cuda.synchronize()
+        mc_s, _ = max_over_ranks(time.perf_counter() - t0)
+        extra["mc"] = {"config": "configs[3] D(i): montecarlo.go pure-predictor statOD5044 (n=4, AWGN), runs sharded by global index",
+                       "runs_total": world * args.mc_runs, "steps": args.mc_steps, "seconds": mc_s,
+                       "value": world * args.mc_runs * args.mc_steps / mc_s, "unit": "run-steps/s (whole job)",
+                       "collective": "all_reduce(SUM) of %d doubles over %s" % (args.mc_steps * 2 * 4,
+                                                                                  "RCCL" if args.dist_backend == "nccl" and world > 1 else
+                                                                                  (args.dist_backend if world > 1 else "one rank (identity)")),
+                       "stddev_last": mc.stddev(args.mc_steps - 1).tolist()}
+        del kf
+    # ---- extra: config D(ii), Hybrid EKF ensemble sharded the same way ---------------------------------------------
+    if args.hybrid_filters > 0:
+        M = args.hybrid_filters
+        hn, hp = 6, 2
+        g = torch.Generator(device=dev)
+        g.manual_seed(7 + rank)
+        x0 = np.random.default_rng(6 + rank).standard_normal((M, hn))
+        P0 = np.zeros((M, hn, hn))
+        P0[:, np.arange(hn), np.arange(hn)] = [10, 10, 10, 1, 1, 1]  # hybrid_test.go:174-180
+        hb = ga.FilterBatch(k.HYBRID, hn, hp, 0, M, device=local_rank)
+        hb.set(k.X, x0, 1); hb.set(k.P, P0, 2); hb.set(k.R, np.diag([1e-6, 1e-6]), 2, p_rows=hp); hb.init(); hb.enable_ekf()
+        Phi = (torch.eye(hn, dtype=torch.float64, device=dev).reshape(hn * hn, 1)
+               + 1e-2 * torch.randn(hn * hn, M, dtype=torch.float64, device=dev, generator=g)).contiguous()
+        Ht = torch.randn(hp * hn, M, dtype=torch.float64, device=dev, generator=g)
+        real = torch.randn(hp, M, dtype=torch.float64, device=dev, generator=g)
+        comp = real + 1e-3 * torch.randn(hp, M, dtype=torch.float64, device=dev, generator=g)
+        hs = torch.cuda.ExternalStream(hb.stream(), device=dev)
+
+        def hstep():
+            k.check(k.lib().kb_prepare_dev(hb._h, Phi.data_ptr(), Ht.data_ptr(), M))
+            k.check(k.lib().kb_update_nl_dev(hb._h, real.data_ptr(), comp.data_ptr(), M))
+        for _ in range(3):
+            hstep()
+        hb.synchronize()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K3 = 50
+        t0 = time.perf_counter()
+        e0.record(hs)
+        for _ in range(K3):
+            hstep()
+        e1.record(hs)
+        hb.synchronize()
+        h_s, _ = max_over_ranks(time.perf_counter() - t0)
+        hms = e0.elapsed_time(e1) / K3
+        hbad = torch.tensor([float(np.count_nonzero(hb.status()))], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(hbad, op=dist.ReduceOp.SUM)
+        extra["hybrid_ekf"] = {"config": "configs[3] D(ii): HybridKF EKF 6/2 fp64 ensemble, per-step Phi/Htilde read in place, filters sharded",
+                               "filters_total": world * M, "steps": K3, "value": world * M * K3 / h_s,
+                               "unit": "filter-update steps/s (whole job)", "kernel_ms": hms,
+                               "roofline": rl.hbm_roofline(hms, M, rl.algorithmic_bytes("hybrid", hn, hp), rl.moved_bytes("hybrid", hn, hp)),
+                               "filters_with_error_status": int(hbad.item())}
+        del hb, Phi, Ht, real, comp
 
     if rank == 0:
-        value = world * N * args.steps / wall_s
-        achieved = ALGO_BYTES_PER_FILTER_STEP * N / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))  # measured at tj["filters"] filters per launch; scales linearly with the batch
-                traffic = tj["hbm_bytes_per_launch"] * (N / float(tj.get("filters", 1 << 20)))
-            except Exception:
-                traffic = None
+        value = total_filter_steps / wall_s
+        counter_bpf, src = rl.load_traffic(ROOT, HEADLINE_KERNEL)
+        roof = rl.hbm_roofline(kernel_ms, N, rl.algorithmic_bytes("vanilla", n, p), rl.moved_bytes("vanilla", n, p), counter_bpf, src)
         out = {
             "metric": "filter-update steps/s (whole node), 1M x 6-state Vanilla",
             "value": value, "unit": "filter-update steps/s", "n_gpus": world, "steps": args.steps,
@@ -171,19 +355,24 @@ def main():
             "config": {"workload": "configs[1]: %d independent 6-state/3-meas Vanilla filters per GPU, fp64, "
                                    "per-filter F/H/Q/R, Noiseless, one kb_update_dev launch per step" % N,
                        "filters_per_gpu": N, "n": n, "p": p, "kernel": "vanilla_reg_kernel<double,6,3,0>",
-                       "sharding": "independent filter shards, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FILTER_STEP * N},
-            "filters_with_error_status": nbad,
+                       "sharding": "independent filter shards, no collective in the update path; epilogue all-reduce of counts"},
+            "roofline": roof,
+            "filters_with_error_status": total_bad,
+            "ranks": {"launched": world, "rccl_ranks_seen": ranks_seen, "backend": args.dist_backend if world > 1 else "none",
+                      "per_rank_ms_per_step": [s_ / args.steps * 1e3 for s_ in per_rank_s],
+                      "filter_steps_counted": total_filter_steps},
         }
+        if ooc:
+            out["out_of_cache"] = ooc
         if fused:
             out["fused"] = fused
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = _cpu_baseline(d)
         elif world > 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,6 +9,10 @@
 
 namespace kb {
 
+// Transient bit of the per-filter status word, private to the library: set by the first kernel of a two-launch step whose
+// time update failed for that filter, consumed (and cleared) by the second kernel of the same step.  Never reported.
+constexpr uint32_t KB_ST_SKIP_STEP = 0x80000000u;
+
 // ---------------------------------------------------------------------------
 // HBM layout of one batch (all blocks AoSoA-64, see kb_device.h).
 //

@@ -368,8 +368,9 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
     bool finite = true;
     for (int i = 0; i < n; i++)
         for (int j = 0; j <= n; j++) finite = finite && (A[i * PC + j] * T(0) == T(0));
-    if (!finite) err |= KB_ST_NONFINITE;
-    if (err) { atomicOr(a.status + fi, err); return; }
+    if (err) { atomicOr(a.status + fi, err); return; }   // singular Phi / R: srif.go:111-114 returns before any assignment
+    // a non-finite Householder result is stored as it is (helper.go:142-172 has no guard) and flagged, as on the register paths
+    if (!finite) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
     for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, A[i * PC + n]);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) stt(st, a.L.st_mat + i * n + j, A[i * PC + j]);

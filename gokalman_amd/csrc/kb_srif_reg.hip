@@ -10,8 +10,12 @@
 // Differences from the statement-by-statement generic kernel (rounding level only):
 //   State(prev) = R^-1 b and RBar = R Phi^-1 are obtained by LU solves instead of
 //   inverse-then-multiply (srif.go:111-115, :223-234); only exact singularity / non-finite
-//   results are flagged (the generic kernel also applies gonum's cond > 1e16 test); a filter
-//   whose status word is non-zero is skipped by the measurement kernel until kb_clear_status.
+//   results are flagged (the generic kernel also applies gonum's cond > 1e16 test).
+// Failure semantics, the same on every SRIF path (fused, time + meas, generic) and the reference's (srif.go:111-114:
+// `return nil, err` before anything is assigned): a filter whose Phi (or R, in State(prev)) is singular at step k gets
+// KB_ST_SINGULAR and keeps its estimate for THAT step only; step k+1 runs normally (the status word is a sticky
+// report, not a gate).  A non-finite Householder result is stored as it is -- helper.go:142-172 has no guard -- and
+// flagged KB_ST_NONFINITE.
 // Algorithmic bytes per filter-step: b 12 + R 144 + Phi 144 + Htilde 72 +
 // L 36 + real 6 + computed 6 read, b 12 + R 144 written = 576 elements = 2304 B in fp32.
 #include "kb_internal.h"
@@ -113,7 +117,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) * NS * NS > 600 ? 1 : 2)) srif
             for (int c = j + 1; c < NS; c++) lu[r * NS + c] -= l * lu[j * NS + c];
         }
     }
-    if (err) { if (active) atomicOr(a.status + fi, err); return; }
+    // failed: (b, R) stay as they are (srif.go:111-114 returns before any assignment); the measurement kernel of the same
+    // Update finds KB_ST_SKIP_STEP, leaves the filter alone and clears the bit again
+    if (err) { if (active) atomicOr(a.status + fi, err | (a.predict ? 0u : KB_ST_SKIP_STEP)); return; }
     T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane : nullptr;
     int poff[NS];  // LDS element offset of original row perm_k
     T xBarP[NS];   // xBar in pivoted order
@@ -195,7 +201,10 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     if (tile >= a.ntiles) return;
     const int64_t fi = tile * KB_TILE + lane;
     const bool active = fi < a.N;
-    if (active && (a.status[fi] & (KB_ST_SINGULAR | KB_ST_ASYMMETRIC | KB_ST_NONFINITE)) != 0u) return;  // failed (now or earlier): the estimate stays frozen
+    if (active && (a.status[fi] & KB_ST_SKIP_STEP) != 0u) {   // the time update of THIS step failed: the estimate stays as it was
+        atomicAnd(a.status + fi, ~KB_ST_SKIP_STEP);
+        return;
+    }
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
@@ -251,8 +260,8 @@ __global__ void __launch_bounds__(256, 1) srif_meas_kernel(const StepArgs a) {
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = i; j < COLS; j++) chk += A[i * COLS + j] * T(0);
-    const bool bad = chk != chk;
-    if (active && !bad) {
+    const bool bad = chk != chk;   // stored as it is (helper.go:142-172 has no guard) and flagged
+    if (active) {
 #pragma unroll
         for (int i = 0; i < NS; i++) stt(st, i, A[i * COLS + NS]);
 #pragma unroll
@@ -309,15 +318,15 @@ __device__ __forceinline__ void shouseholder_rows(T (&A)[(NN + MM) * (NN + 1)], 
 template <typename T, int NS>
 constexpr bool srif_fused_fits() { return sizeof(T) * 4 * (NS * (NS + 1) + 1) * KB_TILE + 64 <= 160 * 1024; }
 
-// Phase A for one tile: (b, R upper, Phi) -> the LDS panel [RBar | bBar] plus an "ok" slot (0 when the filter is frozen
-// by an earlier failure or Phi / R turned out singular; the status word is updated here).
+// Phase A for one tile: (b, R upper, Phi) -> the LDS panel [RBar | bBar] plus an "ok" slot (0 when Phi / R turned out
+// singular at this step: the filter keeps its estimate for this step; the status word is updated here).
 template <typename T, int NS, bool EXT>
 __device__ __forceinline__ void srif_time_to_panel(const StepArgs &a, int64_t tile, int lane, T *panel) {
     constexpr int COLS = NS + 1, RG = 2;
     static_assert(NS % RG == 0, "row groups");
     const int64_t fi = tile * KB_TILE + lane;
     const bool inb = fi < a.N;
-    const bool active = inb && (a.status[inb ? fi : 0] & (KB_ST_SINGULAR | KB_ST_ASYMMETRIC | KB_ST_NONFINITE)) == 0u;  // failed earlier: frozen
+    const bool active = inb;
     const T *st = (const T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *ephi = EXT ? (const T *)a.ext_phi + (inb ? fi : 0) : nullptr;

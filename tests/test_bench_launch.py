@@ -1,0 +1,83 @@
+"""bench.py's N-rank contract: `--gpus N` yields N ranks or a non-zero exit, never a
+silently smaller job.  The CPU half checks the refusal; the GPU half runs two ranks on ONE GPU over gloo
+(every rank drives its own FilterBatch shard through the C ABI; the epilogue all-reduce and the Monte-Carlo
+statistics reduction of montecarlo.go:18-59 really run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_more_ranks_than_gpus_is_refused_not_downgraded():
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev >= 8:
+        pytest.skip("8 GPUs visible: the request is satisfiable")
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--filters", "4096"], timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no bench line may be printed for a refused job"
+    assert "GPU" in (r.stderr + r.stdout) or "MI355X" in (r.stderr + r.stdout)
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+SMALL = ["--steps", "30", "--warmup", "5", "--filters", "65536", "--fused-steps", "0", "--ooc-filters", "0",
+         "--mc-runs", "16384", "--mc-steps", "64", "--hybrid-filters", "16384", "--no-cpu-baseline"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_self_launched_over_gloo_on_one_gpu():
+    one = _json_line(_run(["--gpus", "1"] + SMALL).stdout)
+    r = _run(["--gpus", "2", "--dist-backend", "gloo"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = _json_line(r.stdout)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["ranks"]["launched"] == 2 and two["ranks"]["rccl_ranks_seen"] == 2
+    assert len(two["ranks"]["per_rank_ms_per_step"]) == 2
+    # every rank's 65536 filters x 30 steps were counted by the epilogue all-reduce
+    assert two["ranks"]["filter_steps_counted"] == 2 * 65536 * 30
+    assert two["filters_with_error_status"] == 0
+    # value is the whole job: both ranks share one GPU here, so between ~1x and ~2x of the one-rank figure
+    assert 0.4 * one["value"] < two["value"] < 2.6 * one["value"]
+    # the Monte-Carlo statistics are those of the union of the shards: 2 x 16384 runs, same per-step spread
+    mc1, mc2 = one["extra"]["mc"], two["extra"]["mc"]
+    assert mc2["runs_total"] == 2 * mc1["runs_total"]
+    for a, b in zip(mc1["stddev_last"], mc2["stddev_last"]):
+        assert abs(a - b) <= 0.05 * abs(a)
+    assert two["extra"]["hybrid_ekf"]["filters_total"] == 2 * 16384
+    assert two["roofline"]["frac"] <= 1.0 and one["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_line_roofline_is_physical():
+    out = _json_line(_run(["--steps", "50", "--warmup", "5", "--ooc-filters", "0", "--mc-runs", "0", "--hybrid-filters", "0",
+                           "--no-cpu-baseline"]).stdout)
+    roof = out["roofline"]
+    assert 0.0 < roof["frac"] <= 1.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert roof["frac_algorithmic"] > roof["frac"]      # full-matrix convention overcounts the packed traffic
+    assert roof["bytes_convention"]["algorithmic_bytes_per_filter_step"] == 1488
+    assert roof["bytes_convention"]["moved_bytes_per_filter_step"] == 1104
+    assert "traffic_source" in roof

@@ -1,0 +1,126 @@
+"""SRIF (srif.go:101-160, :298-340) at the benchmark size and through its failure path.
+
+* config E at size: 262 144 filters x 12/6 (fp32 and fp64), inputs from a seeded device generator, handed over zero-copy
+  (kb_prepare_dev / kb_update_nl_dev).  Sampled filters (first tile, last tile, random tiles) are checked against the
+  oracle, and the WHOLE batch must be bit-equal to the same data run in 4096-filter chunks -- the fused kernel is a
+  persistent grid whose workgroups take >= 8 tiles each at this size (LDS double buffer + flag hand-over), a 4096-filter
+  batch gives every workgroup exactly one tile.
+* per-step failure semantics (srif.go:111-114 returns before anything is assigned): a filter whose Phi is singular at
+  step k keeps its estimate for that step only, on every SRIF kernel path."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from gokalman_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _srif_batch(N, n, p, dtype, x0, P0, R, flags=0):
+    b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dtype, flags=flags)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+    return b
+
+
+@pytest.mark.parametrize("dtype,tol", [(k.F32, 2e-3), (k.F64, 1e-9)])
+def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
+    import torch
+    N, n, p, CH = 1 << 18, 12, 6, 4096
+    tdt = torch.float32 if dtype == k.F32 else torch.float64
+    g = torch.Generator(device="cuda"); g.manual_seed(20260)
+    rng = np.random.default_rng(17)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    # sequence: Update (fused kernel where it exists), Predict (time kernel, R no longer triangular), Update (time + meas
+    # kernels), Update (fused again)
+    SEQ = ["update", "predict", "update", "update"]
+    eye = torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1)
+    Phi = [(eye + 1e-2 * torch.randn(n * n, N, dtype=tdt, device="cuda", generator=g)).contiguous() for _ in SEQ]
+    Ht = [torch.randn(p * n, N, dtype=tdt, device="cuda", generator=g) for _ in SEQ]
+    real = [torch.randn(p, N, dtype=tdt, device="cuda", generator=g) for _ in SEQ]
+    comp = [(real[t] + 1e-2 * torch.randn(p, N, dtype=tdt, device="cuda", generator=g)).contiguous() for t in range(len(SEQ))]
+    es = 4 if dtype == k.F32 else 8
+
+    def drive(b, first, count):
+        for t, what in enumerate(SEQ):
+            k.check(k.lib().kb_prepare_dev(b._h, Phi[t].data_ptr() + first * es, Ht[t].data_ptr() + first * es, N))
+            if what == "predict":
+                b.predict_nl()
+            else:
+                k.check(k.lib().kb_update_nl_dev(b._h, real[t].data_ptr() + first * es, comp[t].data_ptr() + first * es, N))
+        b.synchronize()
+
+    big = _srif_batch(N, n, p, dtype, x0, P0, R)
+    drive(big, 0, N)
+    assert not big.status().any()
+    bvec, bmat = big.get(k.RAW_VEC), big.get(k.RAW_MAT)
+    assert np.isfinite(bvec).all() and np.isfinite(bmat).all()
+
+    # the whole batch against 4096-filter chunks: bit for bit
+    for c0 in range(0, N, CH):
+        small = _srif_batch(CH, n, p, dtype, x0[c0:c0 + CH], P0[c0:c0 + CH], R[c0:c0 + CH])
+        drive(small, c0, CH)
+        assert np.array_equal(small.get(k.RAW_VEC), bvec[c0:c0 + CH]), "b differs in chunk at %d" % c0
+        assert np.array_equal(small.get(k.RAW_MAT), bmat[c0:c0 + CH]), "R differs in chunk at %d" % c0
+        small.close()
+
+    # sampled filters against the oracle (fp64, reference order)
+    tiles = np.concatenate([[0, N // 64 - 1], rng.choice(N // 64, size=6, replace=False)])
+    idx = np.unique(np.concatenate([np.arange(t * 64, t * 64 + 64) for t in tiles]))
+    assert idx.size == 512
+    ti = torch.from_numpy(idx).cuda()
+    hPhi = [P_[:, ti].T.double().cpu().numpy().reshape(-1, n, n) for P_ in Phi]
+    hHt = [H_[:, ti].T.double().cpu().numpy().reshape(-1, p, n) for H_ in Ht]
+    hre = [r_[:, ti].T.double().cpu().numpy() for r_ in real]
+    hco = [c_[:, ti].T.double().cpu().numpy() for c_ in comp]
+    bs, Rs = [], []
+    for j, i in enumerate(idx):
+        f = orc.Filter.srif(x0[i], P0[i], R[i], p)
+        for t, what in enumerate(SEQ):
+            f.prepare(hPhi[t][j], hHt[t][j])
+            assert (f.predict_nl() if what == "predict" else f.update_nl(hre[t][j], hco[t][j])) == orc.OK
+        bs.append(f.raw_vec()); Rs.append(f.raw_mat())
+    assert synth.rel_frobenius(bmat[idx], np.array(Rs)) <= tol
+    assert synth.rel_frobenius(bvec[idx], np.array(bs)) <= tol
+
+
+@pytest.mark.parametrize("fail_step", [1, 3])   # 1: steady state (fused kernel where the shape has one); 3: right after a Predict() (time + meas kernels)
+@pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F32, 2e-3), (12, 6, k.F64, 1e-9), (6, 2, k.F64, 1e-9), (6, 2, k.F32, 2e-3), (5, 2, k.F64, 1e-9)])
+def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
+    """(5, 2) has no register kernel: the generic one must behave the same."""
+    rng = np.random.default_rng(100 * n + fail_step)
+    N, steps = 130, 6
+    bad = [7, 70, 129]
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((steps, N, n, n))
+    Ht = rng.standard_normal((steps, N, p, n))
+    real = rng.standard_normal((steps, N, p))
+    comp = real + 1e-2 * rng.standard_normal((steps, N, p))
+    for i in bad:
+        Phi[fail_step, i, 2, :] = 0.0    # exactly singular: gonum's Inverse returns an error (srif.go:112-114)
+    b = _srif_batch(N, n, p, dtype, x0, P0, R)
+    filters = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+    for t in range(steps):
+        b.prepare(Phi[t], Ht[t])
+        predict = t == 2
+        if predict:
+            b.predict_nl()
+        else:
+            b.update_nl(real[t], comp[t])
+        for i, f in enumerate(filters):
+            f.prepare(Phi[t, i], Ht[t, i])
+            rc = f.predict_nl() if predict else f.update_nl(real[t, i], comp[t, i])
+            assert rc == (orc.ERR_SINGULAR if (t == fail_step and i in bad) else orc.OK)
+        st = b.status()
+        if t < fail_step:
+            assert not st.any()
+        else:   # a sticky report, not a gate
+            assert sorted(np.nonzero(st)[0].tolist()) == bad and set(st[bad].tolist()) == {k.ST_SINGULAR}
+        if t >= fail_step:   # the failing step itself (estimate untouched), then k+1, k+2 ... run normally
+            assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in filters])) <= tol, t
+            assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in filters])) <= tol, t
