@@ -45,6 +45,7 @@ SIGNATURES = {
     "kb_smooth_all_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "kb_get": (_i, [_vp, _i, _dp, _i64, _i64]),
     "kb_get_dev": (_i, [_vp, _i, _vp, _i64]),
+    "kb_get_estimate": (_i, [_vp, _i64, _i64, _vp]),
     "kb_get_status": (_i, [_vp, C.POINTER(C.c_uint32), _i64, _i64]),
     "kb_clear_status": (_i, [_vp]),
     "kb_is_within_nsigma": (_i, [_vp, C.c_double, C.POINTER(C.c_uint8), _i64, _i64]),
@@ -64,6 +65,14 @@ SIGNATURES = {
     "kb_van_loan": (_i, [_i, _i, _i, _i, _i64, _dp, _dp, _dp, _dp, _i, _dp, _dp, C.POINTER(C.c_uint32)]),
     "kb_van_loan_dev": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
+
+
+
+class EstimateView(C.Structure):
+    """kb_estimate_view (include/gokalman_amd.h)."""
+    _fields_ = [("state", _dp), ("covariance", _dp), ("pred_covariance", _dp), ("gain", _dp), ("innovation", _dp),
+                ("measurement", _dp), ("status", C.POINTER(C.c_uint32)), ("clear_status", _i)]
+
 
 _lib = None
 

@@ -24,35 +24,115 @@ def _ptr(a):
     return a.ctypes.data_as(_dp)
 
 
+SNAPSHOT_MAX_FILTERS = 4096   # update() returns an owning snapshot up to this batch size, a guarded view above it
+
+
+class StaleEstimateError(RuntimeError):
+    """A non-owning Estimate was read after its batch had moved on to a later step."""
+
+
 class Estimate:
-    """The Estimate interface (kalman.go:64-72) for every filter of the batch at one step.
+    """The Estimate interface (kalman.go:64-72) for filters [first, first+count) of the batch at ONE step.
 
-    Getters download from HBM on demand (the reference's SquareRoot / Information / SRIF
-    estimates are lazy in the same way)."""
+    The reference's Update returns a freshly allocated, immutable estimate (vanilla.go:216-218) that callers keep and
+    read later (examples/jerkcar/main.go:71-90, montecarlo.go:108-117).  `snapshot=True` gives exactly that: every member
+    is downloaded once (kb_get_estimate: one device synchronisation) and owned by this object.  `snapshot=False` is the
+    cheap form for batches too large to copy every step: getters download on demand, and raise StaleEstimateError once
+    the batch has advanced (never a silent read of a later step); `freeze()` turns it into an owning snapshot."""
 
-    def __init__(self, batch):
+    def __init__(self, batch, snapshot=False, first=0, count=None, clear_status=False):
         self._b = batch
+        self._first = first
+        self._count = batch.N - first if count is None else count
+        self._step = batch.step()
+        self._epoch = batch._resets
+        self._own = None
+        if snapshot:
+            self._download(clear_status)
+
+    # ---- owning form -------------------------------------------------------------------
+    def _download(self, clear_status=False):
+        b = self._b
+        n, p, cnt = b.n, b.meas_dim(), self._count
+        info = b.kind in (k.INFORMATION, k.SRIF)
+        full = bool(b.flags & k.FLAG_FULL_ESTIMATE)
+        lazy = b.kind in (k.SQUAREROOT, k.INFORMATION, k.SRIF, k.BATCH_LS)
+        own = {"state": np.zeros((cnt, n)), "covariance": np.zeros((cnt, n, n)), "status": np.zeros(cnt, dtype=np.uint32)}
+        if full:
+            own["pred_covariance"] = np.zeros((cnt, n, n))
+            if not lazy or b.kind == k.SQUAREROOT:
+                own["gain"] = np.zeros((cnt, n, p))
+            own["measurement"] = np.zeros((cnt, p))
+        if info or full:
+            own["innovation"] = np.zeros((cnt, n if info else p))
+        v = k.EstimateView()
+        for name in ("state", "covariance", "pred_covariance", "gain", "innovation", "measurement"):
+            if name in own:
+                setattr(v, name, _ptr(own[name]))
+        v.status = own["status"].ctypes.data_as(C.POINTER(C.c_uint32))
+        v.clear_status = 1 if clear_status else 0
+        k.check(k.lib().kb_get_estimate(b._h, self._first, cnt, C.byref(v)))
+        self._own = own
+
+    def freeze(self):
+        """Turn a view into an owning snapshot (must still be the batch's current step)."""
+        if self._own is None:
+            self._check_live()
+            self._download()
+        return self
+
+    @property
+    def owning(self):
+        return self._own is not None
+
+    def _check_live(self):
+        if self._b.step() != self._step or self._b._resets != self._epoch:
+            raise StaleEstimateError(
+                "this Estimate is a view of step %d but the batch is at step %d: ask update(..., snapshot=True) or call "
+                "freeze() before the next Update to keep an estimate (vanilla.go:216-218 semantics)" % (self._step, self._b.step()))
+
+    def _get(self, name, field):
+        if self._own is not None:
+            if name not in self._own:
+                raise k.KalmanError(k.ERR_INVALID, "field %d needs a batch created with KB_FLAG_FULL_ESTIMATE" % field)
+            return self._own[name]
+        self._check_live()
+        return self._b.get(field, self._first, self._count)
 
     def state(self):
-        return self._b.get(k.STATE)
+        return self._get("state", k.STATE)
 
     def measurement(self):
-        return self._b.get(k.MEASUREMENT)
+        return self._get("measurement", k.MEASUREMENT)
 
     def innovation(self):
-        return self._b.get(k.INNOVATION)
+        return self._get("innovation", k.INNOVATION)
 
     def covariance(self):
-        return self._b.get(k.COVAR)
+        return self._get("covariance", k.COVAR)
 
     def pred_covariance(self):
-        return self._b.get(k.PRED_COVAR)
+        return self._get("pred_covariance", k.PRED_COVAR)
 
     def gain(self):
-        return self._b.get(k.GAIN)
+        return self._get("gain", k.GAIN)
+
+    def status(self):
+        """Per-filter status bits at this step (0 = the reference's `err == nil`)."""
+        if self._own is not None:
+            return self._own["status"]
+        self._check_live()
+        return self._b.status(self._first, self._count)
 
     def is_within_nsigma(self, nsigma):
-        return self._b.is_within_nsigma(nsigma)
+        """vanilla.go:231-239: |x_i| <= N sqrt(P_ii) for every component."""
+        if self._own is not None:
+            x, P = self._own["state"], self._own["covariance"]
+            with np.errstate(invalid="ignore"):
+                d = nsigma * np.sqrt(np.diagonal(P, axis1=1, axis2=2))
+                return ~np.any((x > d) | (x < -d), axis=1)
+        self._check_live()
+        return self._b.is_within_nsigma(nsigma, self._first, self._count)
 
     def is_within_2sigma(self):
         return self.is_within_nsigma(2.0)
@@ -64,6 +144,7 @@ class FilterBatch:
     def __init__(self, kind, n, p, m=0, nfilters=1, dtype=k.F64, device=0, flags=0):
         self._h = C.c_void_p()
         self.kind, self.n, self.pmax, self.m, self.N, self.dtype = kind, n, p, m, int(nfilters), dtype
+        self.flags, self._resets = flags, 0
         k.check(k.lib().kb_create(C.byref(self._h), kind, n, p, m, int(nfilters), dtype, device, flags))
 
     # ---- constructors mirroring NewVanilla / NewPurePredictorVanilla / NewSquareRoot /
@@ -118,17 +199,30 @@ class FilterBatch:
             self._h = C.c_void_p()
 
     # ---- uploads -------------------------------------------------------------------
+    def _item_shape(self, field, p_rows):
+        n, m, p = self.n, self.m, (p_rows or self.pmax)
+        q = self.m if self.kind == k.HYBRID else n
+        return {k.X: (n,), k.P: (n, n), k.F: (n, n), k.G: (n, m), k.H: (p, n), k.Q: (q, q), k.R: (p, p)}.get(field)
+
     def set(self, field, arr, item_ndim, p_rows=0):
-        """kb_set: arr is [N, ...item] per filter or [...item] shared (broadcast)."""
+        """kb_set: arr is [N, ...item] per filter or [...item] shared (broadcast).  The C ABI carries no element
+        count, so the item shape is checked here against the batch dimensions."""
         arr = _f64(arr)
         if arr.ndim == item_ndim:
             count, bcast = 1, 1
+            item = arr.shape
         elif arr.ndim == item_ndim + 1:
             count, bcast = arr.shape[0], 0
+            item = arr.shape[1:]
             if count == 1 and self.N != 1:
                 bcast = 1
         else:
             raise ValueError("array rank %d does not match field rank %d" % (arr.ndim, item_ndim))
+        want = self._item_shape(field, p_rows)
+        if want is not None and tuple(item) != want:
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: field %d expects items of shape %s, got %s" % (field, want, tuple(item)))
+        if not bcast and count != self.N:
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: field %d needs 1 or N=%d items, got %d" % (field, self.N, count))
         k.check(k.lib().kb_set(self._h, field, _ptr(arr), count, bcast, p_rows))
 
     def set_dev(self, field, ptr, ld, p_rows=0):
@@ -160,29 +254,45 @@ class FilterBatch:
         k.check(k.lib().kb_set_noise_kind(self._h, kind, seed))
 
     def set_batch_noise(self, process, measurement):
-        """SetNoise(BatchNoise{process, measurement}) (noise.go:67-106); give zero Q, R as BatchNoise reports."""
+        """SetNoise(BatchNoise{process, measurement}) (noise.go:67-106); Q and R become zero, as BatchNoise reports them."""
         pr, me = _f64(process), _f64(measurement)
+        if pr.ndim != 2 or pr.shape[1] != self.n or me.ndim != 2 or me.shape[1] != self.meas_dim():
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: BatchNoise needs process [steps, %d] and measurement [steps, %d]"
+                                % (self.n, self.meas_dim()))
         k.check(k.lib().kb_set_batch_noise(self._h, _ptr(pr), pr.shape[0], _ptr(me), me.shape[0]))
 
     def reset(self):
         k.check(k.lib().kb_reset(self._h))
+        self._resets += 1
 
     # ---- the hot path ----------------------------------------------------------------
-    def update(self, measurement, control=None):
-        """LDKF.Update(measurement, control) for every filter; returns the batch Estimate."""
-        y = _f64(measurement)
-        if y.ndim == 1:
-            y = np.broadcast_to(y, (self.N, y.shape[0]))
-        y = _f64(y)
+    def _per_filter(self, v, rows_name, expect_rows=None):
+        """A vector argument as [N, rows] float64: one vector (broadcast to every filter) or exactly N of them.  The C ABI
+        reads N * rows doubles from the pointer, so any other leading dimension is rejected here."""
+        v = _f64(v)
+        if v.ndim == 1:
+            v = np.broadcast_to(v, (self.N, v.shape[0]))
+        elif v.ndim != 2 or v.shape[0] != self.N:
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: %s must be [rows] or [N=%d, rows], got %s"
+                                % (rows_name, self.N, tuple(np.shape(v))))
+        return _f64(v)
+
+    def _estimate(self, snapshot):
+        if snapshot is None:
+            snapshot = self.N <= SNAPSHOT_MAX_FILTERS
+        return Estimate(self, snapshot=snapshot)
+
+    def update(self, measurement, control=None, snapshot=None):
+        """LDKF.Update(measurement, control) for every filter; returns the batch Estimate of this step: an owning
+        snapshot (the reference's immutable estimate) for batches up to SNAPSHOT_MAX_FILTERS or with snapshot=True,
+        a guarded view otherwise (see Estimate)."""
+        y = self._per_filter(measurement, "measurement (y)")
         u, urows = None, 0
         if control is not None:
-            u = _f64(control)
-            if u.ndim == 1:
-                u = np.broadcast_to(u, (self.N, u.shape[0]))
-            u = _f64(u)
+            u = self._per_filter(control, "control (u)")
             urows = u.shape[1]
         k.check(k.lib().kb_update(self._h, _ptr(y), y.shape[1], None if u is None else _ptr(u), urows))
-        return Estimate(self)
+        return self._estimate(snapshot)
 
     def update_dev(self, meas_ptr, ld_meas, ctrl_ptr=None, ld_ctrl=0):
         k.check(k.lib().kb_update_dev(self._h, C.c_void_p(meas_ptr), ld_meas,
@@ -196,11 +306,18 @@ class FilterBatch:
     def prepare(self, phi, htilde):
         phi, htilde = _f64(phi), _f64(htilde)
         bcast = 1 if phi.ndim == 2 else 0
+        lead = () if bcast else (self.N,)
+        if phi.shape != lead + (self.n, self.n) or htilde.shape != lead + (self.pmax, self.n):
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: Phi %s Htilde %s for a batch of N=%d, n=%d, p=%d"
+                                % (phi.shape, htilde.shape, self.N, self.n, self.pmax))
         k.check(k.lib().kb_prepare(self._h, _ptr(phi), _ptr(htilde), 1 if bcast else phi.shape[0], bcast))
 
     def prepare_pnt(self, gamma):
         gamma = _f64(gamma)
         bcast = 1 if gamma.ndim == 2 else 0
+        if self.kind == k.HYBRID and gamma.shape != (() if bcast else (self.N,)) + (self.n, self.m):
+            raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: Gamma %s for a batch of N=%d, n=%d, q=%d"
+                                % (gamma.shape, self.N, self.n, self.m))
         k.check(k.lib().kb_prepare_pnt(self._h, _ptr(gamma), 1 if bcast else gamma.shape[0], bcast))
 
     def enable_ekf(self):
@@ -212,18 +329,15 @@ class FilterBatch:
     def ekf_enabled(self):
         return bool(k.lib().kb_ekf_enabled(self._h))
 
-    def update_nl(self, real_obs, computed_obs):
-        r, c = _f64(real_obs), _f64(computed_obs)
-        if r.ndim == 1:
-            r = _f64(np.broadcast_to(r, (self.N, r.shape[0])))
-        if c.ndim == 1:
-            c = _f64(np.broadcast_to(c, (self.N, c.shape[0])))
+    def update_nl(self, real_obs, computed_obs, snapshot=None):
+        r = self._per_filter(real_obs, "real observation")
+        c = self._per_filter(computed_obs, "computed observation")
         k.check(k.lib().kb_update_nl(self._h, _ptr(r), r.shape[1], _ptr(c), c.shape[1]))
-        return Estimate(self)
+        return self._estimate(snapshot)
 
-    def predict_nl(self):
+    def predict_nl(self, snapshot=None):
         k.check(k.lib().kb_predict_nl(self._h))
-        return Estimate(self)
+        return self._estimate(snapshot)
 
     # ---- results -----------------------------------------------------------------------
     def _shape(self, field):
@@ -258,8 +372,9 @@ class FilterBatch:
         k.check(k.lib().kb_is_within_nsigma(self._h, float(nsigma), out.ctypes.data_as(C.POINTER(C.c_uint8)), first, count))
         return out.astype(bool)
 
-    def estimate(self):
-        return Estimate(self)
+    def estimate(self, snapshot=None):
+        """The batch's current estimate (what the reference keeps in kf.prevEst)."""
+        return self._estimate(snapshot)
 
     def step(self):
         return int(k.lib().kb_step(self._h))

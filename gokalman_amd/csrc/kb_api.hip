@@ -506,16 +506,16 @@ int kb_update_steps_dev(kb_batch *b, const void *meas, int64_t ld_meas, const vo
 // =====================================================================================
 // results
 // =====================================================================================
-int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
-    if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
-    int rc = use_device(*b);
-    if (rc) return rc;
-    if (first < 0 || count < 0 || first + count > b->N) { set_error("range [%lld,+%lld) outside the batch", (long long)first, (long long)count); return KB_ERR_INVALID; }
-    if (count == 0) return KB_OK;
+// Where an OUTPUT field lives: the AoSoA block, its element count, the element map to the host layout and the number of
+// doubles per filter on the host side.  Lazy getters (SquareRoot / Information / SRIF covariance, Information / SRIF
+// state) enqueue their materialise kernel here, into the handle's scratch block.
+struct OutputSource { const void *block = nullptr; int block_elems = 0, out_elems = 0; int16_t map[KB_MAX_DIM * KB_MAX_DIM]; };
+static int resolve_output(kb_batch *b, int field, OutputSource &o) {
+    int rc = KB_OK;
     const int n = b->n, p = b->p;
     const Layout &L = b->L;
-    int16_t map[KB_MAX_DIM * KB_MAX_DIM];
-    const void *block = nullptr; int block_elems = 0, out_elems = 0;
+    int16_t (&map)[KB_MAX_DIM * KB_MAX_DIM] = o.map;
+    const void *&block = o.block; int &block_elems = o.block_elems, &out_elems = o.out_elems;
     const bool full = (b->flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS);
     auto need_full = [&]() -> int {
@@ -588,6 +588,19 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
         set_error("unknown field %d", field);
         return KB_ERR_INVALID;
     }
+    return KB_OK;
+}
+
+int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count) {
+    if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || first + count > b->N) { set_error("range [%lld,+%lld) outside the batch", (long long)first, (long long)count); return KB_ERR_INVALID; }
+    if (count == 0) return KB_OK;
+    OutputSource o;
+    if ((rc = resolve_output(b, field, o))) return rc;
+    const void *block = o.block; const int block_elems = o.block_elems, out_elems = o.out_elems;
+    const int16_t *map = o.map;
     const size_t bytes = (size_t)count * out_elems * sizeof(double);
     if (bytes <= KB_PIN_OUT_BYTES && !ensure_pin(*b)) {   // small read-back: the kernel writes the pinned host buffer itself
         const size_t off = 3 * KB_PIN_TILE_BYTES;
@@ -629,6 +642,75 @@ int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld) {
     return KB_ERR_UNSUPPORTED;
 }
 
+__global__ void status_fetch_kernel(uint32_t *status, int64_t first, int64_t count, uint32_t *out, int clear) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t v = clear ? atomicExch(status + first + k, 0u) : status[first + k];
+    out[k] = v & ~KB_ST_SKIP_STEP;
+}
+
+// One snapshot of the Estimate of filters [first, first+count): every requested member is unpacked into ONE staging
+// area (the pinned, device-mapped buffer when it fits: no copy at all) and handed over after ONE stream synchronisation.
+int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *v) {
+    if (!b || !v) { set_error("null argument"); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
+    if (first < 0 || count < 0 || first + count > b->N) { set_error("range [%lld,+%lld) outside the batch", (long long)first, (long long)count); return KB_ERR_INVALID; }
+    if (count == 0) return KB_OK;
+    struct Want { int field; double *dst; size_t off, bytes; };
+    Want want[6] = {{KB_STATE, v->state, 0, 0}, {KB_COVAR, v->covariance, 0, 0}, {KB_PRED_COVAR, v->pred_covariance, 0, 0},
+                    {KB_GAIN, v->gain, 0, 0}, {KB_INNOVATION, v->innovation, 0, 0}, {KB_MEASUREMENT, v->measurement, 0, 0}};
+    // sizes first (the staging area must exist before anything is enqueued into it)
+    const int n = b->n, p = b->p;
+    const bool info = b->kind == KB_INFORMATION || b->kind == KB_SRIF;
+    const int elems[6] = {n, n * n, n * n, n * p, info ? n : p, p};
+    size_t total = 0;
+    for (int i = 0; i < 6; i++)
+        if (want[i].dst) { want[i].off = total; want[i].bytes = (size_t)count * elems[i] * sizeof(double); total += want[i].bytes; }
+    const size_t st_off = total;
+    if (v->status) total += (size_t)count * sizeof(uint32_t);
+    if (total == 0) return KB_OK;
+    char *d_area = nullptr; const char *h_area = nullptr;
+    const bool pinned = total <= KB_PIN_OUT_BYTES && !ensure_pin(*b);
+    if (pinned) {
+        d_area = (char *)b->d_pin + 3 * KB_PIN_TILE_BYTES;
+        h_area = (const char *)b->h_pin + 3 * KB_PIN_TILE_BYTES;
+    } else {
+        if ((rc = ensure_stage(*b, total))) return rc;
+        d_area = (char *)b->d_stage;
+    }
+    // pred_covar of the lazy kinds re-uses the scratch block of state / covar: stream order keeps the two apart
+    for (int i = 0; i < 6; i++) {
+        if (!want[i].dst) continue;
+        OutputSource o;
+        if ((rc = resolve_output(b, want[i].field, o))) return rc;
+        if ((rc = launch_unpack(*b, o.block, o.block_elems, o.map, o.out_elems, (double *)(d_area + want[i].off), first, count))) return rc;
+    }
+    if (v->status) {
+        hipLaunchKernelGGL(status_fetch_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, b->stream, b->d_status, first, count,
+                           (uint32_t *)(d_area + st_off), v->clear_status ? 1 : 0);
+        KB_HIP(hipGetLastError());
+    }
+    if (pinned) {
+        KB_HIP(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < 6; i++)
+            if (want[i].dst) memcpy(want[i].dst, h_area + want[i].off, want[i].bytes);
+        if (v->status) memcpy(v->status, h_area + st_off, (size_t)count * sizeof(uint32_t));
+    } else {
+        for (int i = 0; i < 6; i++)
+            if (want[i].dst) KB_HIP(hipMemcpyAsync(want[i].dst, d_area + want[i].off, want[i].bytes, hipMemcpyDeviceToHost, b->stream));
+        if (v->status) KB_HIP(hipMemcpyAsync(v->status, d_area + st_off, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        KB_HIP(hipStreamSynchronize(b->stream));
+    }
+    if (v->status && v->clear_status && b->kind == KB_SRIF) {
+        // the fused SRIF Update finds filters that may hold a dense R through their status words (kb_srif_reg.hip)
+        for (int64_t k = 0; k < count; k++)
+            if (v->status[k]) { b->srif_tri = 0; break; }
+    }
+    return KB_OK;
+}
+
 int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count) {
     if (!b || !host) { set_error("null argument"); return KB_ERR_INVALID; }
     int rc = use_device(*b);
@@ -645,6 +727,9 @@ int kb_clear_status(kb_batch *b) {
     if (rc) return rc;
     KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
     KB_HIP(hipStreamSynchronize(b->stream));
+    // KB_SRIF: the fused Update finds the filters whose R may be dense (they skipped an Update after a Predict()) through
+    // their status words; with those gone the next Update takes the two-kernel path, which tests R itself
+    if (b->kind == KB_SRIF) b->srif_tri = 0;
     return KB_OK;
 }
 

@@ -200,6 +200,11 @@ int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const doub
     if ((rc = upload(measurement, (size_t)nmeas * p, &b->d_bn_meas))) return rc;
     b->bn_nproc = nproc; b->bn_nmeas = nmeas; b->bn_p = p;
     b->noise_kind = KB_NOISE_BATCH;
+    // BatchNoise.ProcessMatrix / MeasurementMatrix return ZERO matrices (noise.go:89-98): the filter propagates with
+    // Q = 0 and R = 0, whatever was given to kb_set before
+    const std::vector<double> zeros((size_t)(n > p ? n * n : p * p), 0.0);
+    if ((rc = kb_set(b, KB_Q, zeros.data(), 1, 1, 0))) return rc;
+    if ((rc = kb_set(b, KB_R, zeros.data(), 1, 1, p))) return rc;
     return KB_OK;
 }
 

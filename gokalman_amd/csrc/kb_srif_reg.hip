@@ -320,7 +320,11 @@ constexpr bool srif_fused_fits() { return sizeof(T) * 4 * (NS * (NS + 1) + 1) * 
 
 // Phase A for one tile: (b, R upper, Phi) -> the LDS panel [RBar | bBar] plus an "ok" slot (0 when Phi / R turned out
 // singular at this step: the filter keeps its estimate for this step; the status word is updated here).
-template <typename T, int NS, bool EXT>
+// TRI = false is the cold variant for a tile in which some filter may hold a dense R although the batch as a whole is in
+// the triangular steady state: a filter that skipped the Update right after a Predict() (singular Phi) still has the full
+// RBar of that Predict().  Such filters carry a non-zero status word, so the kernel picks the variant per tile from the
+// status words (wave-uniform); the dense variant reads all of R and solves State(prev) by pivoted LU.
+template <typename T, int NS, bool EXT, bool TRI>
 __device__ __forceinline__ void srif_time_to_panel(const StepArgs &a, int64_t tile, int lane, T *panel) {
     constexpr int COLS = NS + 1, RG = 2;
     static_assert(NS % RG == 0, "row groups");
@@ -332,7 +336,21 @@ __device__ __forceinline__ void srif_time_to_panel(const StepArgs &a, int64_t ti
     const T *ephi = EXT ? (const T *)a.ext_phi + (inb ? fi : 0) : nullptr;
     unsigned err = 0;
     T xprev[NS], lu[NS * NS];
-    {
+    if constexpr (!TRI) {
+        T Rw[NS * NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) xprev[i] = ldt(st, i);
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) Rw[e] = ldt(st, NS + e);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) panel[(i * COLS + j) * KB_TILE] = Rw[i * NS + j];
+        if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;   // State(prev) = R^-1 b (srif.go:223-234)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) lu[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
+    } else {
         T Ru[tri(NS)];   // upper triangle of R, Ru[symi(i, j)], i <= j
 #pragma unroll
         for (int i = 0; i < NS; i++) xprev[i] = ldt(st, i);
@@ -410,16 +428,16 @@ __device__ __forceinline__ void srif_time_to_panel(const StepArgs &a, int64_t ti
 #pragma unroll
         for (int g = 0; g < RG; g++)
 #pragma unroll
-            for (int c = 0; c < NS; c++) z[g][c] = c >= i0 + g ? panel[((i0 + g) * COLS + c) * KB_TILE] : T(0);
+            for (int c = 0; c < NS; c++) z[g][c] = (!TRI || c >= i0 + g) ? panel[((i0 + g) * COLS + c) * KB_TILE] : T(0);
 #pragma unroll
         for (int j = 0; j < NS; j++) {      // constant trip counts everywhere: the structural-zero tests fold after unrolling
 #pragma unroll
             for (int g = 0; g < RG; g++) {
-                if (j >= i0 + g) {
+                if (!TRI || j >= i0 + g) {
                     T sum = z[g][j];
 #pragma unroll
                     for (int k2 = 0; k2 < NS; k2++)
-                        if (k2 >= i0 + g && k2 < j) sum -= z[g][k2] * lu[k2 * NS + j];
+                        if ((!TRI || k2 >= i0 + g) && k2 < j) sum -= z[g][k2] * lu[k2 * NS + j];
                     z[g][j] = sum * lu[j * NS + j];
                 }
             }
@@ -449,7 +467,7 @@ __device__ __forceinline__ void srif_time_to_panel(const StepArgs &a, int64_t ti
 
 // Phase B for one tile: the LDS panel [RBar | bBar] + (Htilde, chol_L(R), real, computed) -> Householder -> b, R (upper).
 template <typename T, int NS, int NM, bool FULL, bool EXT, typename W, typename F>
-__device__ __forceinline__ void srif_meas_from_panel(const StepArgs &a, int64_t tile, int lane, const T *panel, W &&wait_panel, F &&panel_consumed) {
+__device__ __forceinline__ void srif_meas_from_panel(const StepArgs &a, int64_t tile, int lane, const T *panel, bool dense, W &&wait_panel, F &&panel_consumed) {
     constexpr int COLS = NS + 1;
     const int64_t fi = tile * KB_TILE + lane;
     const bool inb = fi < a.N;
@@ -529,6 +547,12 @@ __device__ __forceinline__ void srif_meas_from_panel(const StepArgs &a, int64_t 
             for (int r = 0; r < NM; r++) stt(es, a.L.es_innov + r, A[(NS + r) * COLS + NS]);
         }
     }
+    if (dense && active) {   // cold: this filter's R may have been the dense RBar of a Predict() (see srif_time_to_panel<..., TRI = false>)
+#pragma unroll
+        for (int i = 1; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < i; j++) stt(st, NS + i * NS + j, T(0));   // srif.go:334-337 zeroes the sub-columns
+    }
     if (active && chk != chk) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
 }
 
@@ -555,12 +579,16 @@ __global__ void __launch_bounds__(128, 1) srif_fused_kernel(const StepArgs a) {
         auto wait_for = [&](int want) {
             while (__hip_atomic_load(&full[bsel], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(8);
         };
+        // a non-zero status word in the tile: some filter may hold a dense R (it skipped the Update after a Predict())
+        const int64_t fi = cur * KB_TILE + lane;
+        const bool dense = __any(fi < a.N && (a.status[fi < a.N ? fi : 0] & ~KB_ST_SKIP_STEP) != 0u);
         if (first_half) {
             wait_for(0);
-            srif_time_to_panel<T, NS, EXT>(a, cur, lane, panel);
+            if (dense) srif_time_to_panel<T, NS, EXT, false>(a, cur, lane, panel);
+            else srif_time_to_panel<T, NS, EXT, true>(a, cur, lane, panel);
             __hip_atomic_store(&full[bsel], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            srif_meas_from_panel<T, NS, NM, FULL, EXT>(a, cur, lane, panel, [&]() { wait_for(1); }, [&]() {
+            srif_meas_from_panel<T, NS, NM, FULL, EXT>(a, cur, lane, panel, dense, [&]() { wait_for(1); }, [&]() {
                 __hip_atomic_store(&full[bsel], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             });
         }

@@ -197,6 +197,25 @@ int kb_smooth_all_dev(kb_batch *b, const void *phis, int64_t ld, int steps, void
  * materialised by a small kernel (S S^T, I^-1, R^-1 R^-T) exactly like the
  * reference's lazy getters (squareroot.go:317, information.go:277, srif.go:253). */
 int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count);
+/* One SNAPSHOT of the Estimate (kalman.go:64-72) of filters [first, first+count): the reference's Update returns a freshly
+ * allocated, immutable estimate and keeps it alive (vanilla.go:216-218; consumed later through a channel in
+ * examples/jerkcar/main.go:71-90, stored per step in montecarlo.go:108-117).  Every non-NULL member of the view receives
+ * its copy (float64, host layout as in kb_get) with one device synchronisation for all of them; NULL members are skipped.
+ * pred_covariance / gain / measurement (and innovation of the Vanilla / SquareRoot / Hybrid kinds) need a batch created
+ * with KB_FLAG_FULL_ESTIMATE.  status receives the per-filter status bits; with clear_status != 0 the words are read AND
+ * cleared in one atomic step, which gives a host shim the reference's per-call error: an Update that fails for a filter
+ * leaves that filter's previous estimate in place and does not poison the next call (vanilla.go:164-167). */
+typedef struct kb_estimate_view {
+    double *state;           /* [count][n]                                                          */
+    double *covariance;      /* [count][n][n]                                                       */
+    double *pred_covariance; /* [count][n][n]                                                       */
+    double *gain;            /* [count][n][p]                                                       */
+    double *innovation;      /* [count][p]   (KB_INFORMATION / KB_SRIF: [count][n], the information vector) */
+    double *measurement;     /* [count][p]                                                          */
+    uint32_t *status;        /* [count]                                                             */
+    int clear_status;
+} kb_estimate_view;
+int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *view);
 /* Planar device-side variant: writes element e of filter i to dst[e*ld + i] in the batch dtype. */
 int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld);
 int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count);
@@ -224,7 +243,7 @@ int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed);
  * are the recorded vectors (host, row-major), shared by every filter of the batch; step k adds
  * process[k] at both Process(k) call sites and measurement[k] to yhat.  An Update at a step with no
  * recorded vector fails with "no process noise defined at step k=%d" (a panic in the reference,
- * noise.go:75-86).  BatchNoise reports zero Q and R (noise.go:89-98): give kb_set zero matrices.
+ * noise.go:75-86).  BatchNoise reports zero Q and R (noise.go:89-98): this call zeroes the batch's Q and R.
  * Selects KB_NOISE_BATCH. */
 int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const double *measurement, int nmeas);
 /* The standard normals z behind the AWGN draw of the filter with global index `filter` at

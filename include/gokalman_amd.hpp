@@ -12,7 +12,9 @@
 // Matrices are row-major std::vector<double> wrapped in gokalman::Matrix {rows, cols, data};
 // for N > 1 `data` holds N matrices back to back (or one, shared by all filters).
 // Errors: the reference returns (nil, error) or panics; here every failure throws
-// gokalman::Error carrying the kb_status code and the reference's message.
+// gokalman::Error carrying the kb_status code and the reference's message (gokalman::StepError for the
+// numerical failure of one Update: the filter keeps its previous estimate and the next call runs normally).
+// Update / Predict return an Estimate VALUE that owns its data (see class Estimate).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -69,38 +71,29 @@ struct Noise {
 inline Noise NewNoiseless(Matrix Q, Matrix R) { return Noise{std::move(Q), std::move(R), KB_NOISE_NOISELESS, 0}; }       // noise.go:29-37
 inline Noise NewAWGN(Matrix Q, Matrix R, uint64_t seed = 0) { return Noise{std::move(Q), std::move(R), KB_NOISE_AWGN, seed}; }  // noise.go:117-121
 
-class Batch;  // owns the kb_batch
-
-// kalman.go:64-72.  Lazy: getters download from HBM (the reference's SquareRoot / Information /
-// SRIF estimates compute their covariance lazily as well).  Valid until the next Update.
-class Estimate {
-   public:
-    explicit Estimate(std::shared_ptr<Batch> b) : b_(std::move(b)) {}
-    Vector State() const;
-    Vector Measurement() const;
-    Vector Innovation() const;
-    Matrix Covariance() const;
-    Matrix PredCovariance() const;
-    Matrix Gain() const;
-    std::vector<uint8_t> IsWithinNσ(double N) const;
-    std::vector<uint8_t> IsWithin2σ() const { return IsWithinNσ(2); }
-
-   private:
-    std::shared_ptr<Batch> b_;
+// The reference's per-call error of an Update that failed NUMERICALLY for a filter (vanilla.go:164-167, :207-215,
+// hybrid.go:150-152, srif.go:112-114): thrown for batches of one filter, exactly where the reference returns
+// (nil, err); the filter keeps its previous estimate and the next Update runs normally.  Larger batches report the
+// per-filter status words through Estimate::Status() instead.
+struct StepError : Error {
+    uint32_t status;
+    StepError(uint32_t st, const std::string &m) : Error(KB_ERR_INVALID, m), status(st) {}
 };
 
-class Batch : public std::enable_shared_from_this<Batch> {
+class Batch {
    public:
     Batch(int kind, int n, int p, int m, int64_t N, unsigned flags = KB_FLAG_FULL_ESTIMATE, int dtype = KB_F64, int device = 0)
-        : n_(n), N_(N) {
+        : kind_(kind), n_(n), N_(N), flags_(flags) {
         check(kb_create(&h_, kind, n, p, m, N, dtype, device, flags));
     }
     ~Batch() { kb_destroy(h_); }
     Batch(const Batch &) = delete;
     Batch &operator=(const Batch &) = delete;
     kb_batch *handle() const { return h_; }
+    int kind() const { return kind_; }
     int n() const { return n_; }
     int64_t N() const { return N_; }
+    unsigned flags() const { return flags_; }
     void set(int field, const Matrix &m, int p_rows = 0) {
         check(kb_set(h_, field, m.data.data(), m.shared() ? 1 : N_, m.shared() ? 1 : 0, p_rows));
     }
@@ -113,20 +106,139 @@ class Batch : public std::enable_shared_from_this<Batch> {
 
    private:
     kb_batch *h_ = nullptr;
-    int n_;
+    int kind_, n_;
     int64_t N_;
+    unsigned flags_;
 };
 
-inline Vector Estimate::State() const { return b_->get(KB_STATE, b_->n(), 1); }
-inline Vector Estimate::Measurement() const { return b_->get(KB_MEASUREMENT, kb_meas_dim(b_->handle()), 1); }
-inline Vector Estimate::Innovation() const { return b_->get(KB_INNOVATION, kb_meas_dim(b_->handle()), 1); }
-inline Matrix Estimate::Covariance() const { return b_->get(KB_COVAR, b_->n(), b_->n()); }
-inline Matrix Estimate::PredCovariance() const { return b_->get(KB_PRED_COVAR, b_->n(), b_->n()); }
-inline Matrix Estimate::Gain() const { return b_->get(KB_GAIN, b_->n(), kb_meas_dim(b_->handle())); }
-inline std::vector<uint8_t> Estimate::IsWithinNσ(double N) const {
-    std::vector<uint8_t> out((size_t)b_->N());
-    check(kb_is_within_nsigma(b_->handle(), N, out.data(), 0, b_->N()));
-    return out;
+// Batches up to this size get an owning Estimate from every Update (the reference's semantics); larger ones get a
+// guarded view (copying a million estimates to the host every step is what the device path exists to avoid).
+constexpr int64_t kSnapshotMaxFilters = 4096;
+
+// kalman.go:64-72.  An Estimate is an immutable VALUE: the reference's Update returns a freshly allocated estimate and
+// the callers keep it (vanilla.go:216-218; consumed later through a channel in examples/jerkcar/main.go:71-90, stored per
+// step in montecarlo.go:108-117).  Here it owns one snapshot taken with a single kb_get_estimate call, shared by its
+// copies like the Go pointer is.  For batches above kSnapshotMaxFilters it is a view instead, and every getter throws
+// once the batch has moved on (never a silent read of a later step); Freeze() turns a live view into a snapshot.
+class Estimate {
+   public:
+    struct Snapshot {
+        int n = 0, p = 0;
+        int64_t N = 0;
+        bool has_full = false, has_innovation = false, has_gain = false;
+        Matrix state, covariance, pred_covariance, gain, innovation, measurement;
+        std::vector<uint32_t> status;
+    };
+    Estimate() = default;
+    // snapshot == true: download now (clear_status: read-and-clear the status words, the per-call error semantics)
+    Estimate(std::shared_ptr<Batch> b, bool snapshot, bool clear_status = false) : b_(std::move(b)), step_(kb_step(b_->handle())) {
+        if (snapshot) snap_ = download(*b_, clear_status);
+    }
+    bool Owning() const { return snap_ != nullptr; }
+    Estimate &Freeze() {
+        if (!snap_) { live(); snap_ = download(*b_, false); }
+        return *this;
+    }
+    Vector State() const { return snap_ ? snap_->state : (live(), b_->get(KB_STATE, b_->n(), 1)); }
+    Matrix Covariance() const { return snap_ ? snap_->covariance : (live(), b_->get(KB_COVAR, b_->n(), b_->n())); }
+    Vector Measurement() const {
+        if (snap_) { need(snap_->has_full, "Measurement"); return snap_->measurement; }
+        live();
+        return b_->get(KB_MEASUREMENT, kb_meas_dim(b_->handle()), 1);
+    }
+    Vector Innovation() const {
+        if (snap_) { need(snap_->has_innovation, "Innovation"); return snap_->innovation; }
+        live();
+        const bool info = b_->kind() == KB_INFORMATION || b_->kind() == KB_SRIF;
+        return b_->get(KB_INNOVATION, info ? b_->n() : kb_meas_dim(b_->handle()), 1);
+    }
+    Matrix PredCovariance() const {
+        if (snap_) { need(snap_->has_full, "PredCovariance"); return snap_->pred_covariance; }
+        live();
+        return b_->get(KB_PRED_COVAR, b_->n(), b_->n());
+    }
+    Matrix Gain() const {
+        if (snap_) { need(snap_->has_gain, "Gain"); return snap_->gain; }
+        live();
+        return b_->get(KB_GAIN, b_->n(), kb_meas_dim(b_->handle()));
+    }
+    // per-filter status bits of the step this estimate belongs to (0 = the reference's err == nil)
+    std::vector<uint32_t> Status() const {
+        if (snap_) return snap_->status;
+        live();
+        std::vector<uint32_t> st((size_t)b_->N());
+        check(kb_get_status(b_->handle(), st.data(), 0, b_->N()));
+        return st;
+    }
+    // vanilla.go:231-239: |x_i| <= N sqrt(P_ii) for every component
+    std::vector<uint8_t> IsWithinNσ(double N) const {
+        std::vector<uint8_t> out;
+        if (snap_) {
+            const int n = snap_->n;
+            out.assign((size_t)snap_->N, 1);
+            for (int64_t f = 0; f < snap_->N; f++)
+                for (int i = 0; i < n; i++) {
+                    const double ns = N * std::sqrt(snap_->covariance.At(i, i, f)), x = snap_->state.At(i, 0, f);
+                    if (x > ns || x < -ns) out[(size_t)f] = 0;
+                }
+            return out;
+        }
+        live();
+        out.assign((size_t)b_->N(), 0);
+        check(kb_is_within_nsigma(b_->handle(), N, out.data(), 0, b_->N()));
+        return out;
+    }
+    std::vector<uint8_t> IsWithin2σ() const { return IsWithinNσ(2); }
+
+   private:
+    static std::shared_ptr<const Snapshot> download(Batch &b, bool clear_status) {
+        auto s = std::make_shared<Snapshot>();
+        const int n = b.n(), p = kb_meas_dim(b.handle());
+        const int64_t N = b.N();
+        const int kind = b.kind();
+        const bool info = kind == KB_INFORMATION || kind == KB_SRIF;
+        const bool full = (b.flags() & KB_FLAG_FULL_ESTIMATE) != 0;
+        const bool lazy = kind == KB_SQUAREROOT || kind == KB_INFORMATION || kind == KB_SRIF || kind == KB_BATCH_LS;
+        s->n = n; s->p = p; s->N = N; s->has_full = full; s->has_innovation = info || full;
+        s->has_gain = full && (!lazy || kind == KB_SQUAREROOT);
+        auto alloc = [&](Matrix &m, int r, int c) { m = Matrix(r, c); m.data.assign((size_t)N * r * c, 0.0); return m.data.data(); };
+        kb_estimate_view v{};
+        v.state = alloc(s->state, n, 1);
+        v.covariance = alloc(s->covariance, n, n);
+        if (full) { v.pred_covariance = alloc(s->pred_covariance, n, n); v.measurement = alloc(s->measurement, p, 1); }
+        if (s->has_gain) v.gain = alloc(s->gain, n, p);
+        if (s->has_innovation) v.innovation = alloc(s->innovation, info ? n : p, 1);
+        s->status.assign((size_t)N, 0u);
+        v.status = s->status.data();
+        v.clear_status = clear_status ? 1 : 0;
+        check(kb_get_estimate(b.handle(), 0, N, &v));
+        return s;
+    }
+    void live() const {
+        if (!b_) throw Error(KB_ERR_INVALID, "empty Estimate");
+        if (kb_step(b_->handle()) != step_)
+            throw Error(KB_ERR_INVALID, "this Estimate is a view of step " + std::to_string(step_) + " but the batch is at step " +
+                                            std::to_string(kb_step(b_->handle())) + ": Freeze() it before the next Update to keep it");
+    }
+    static void need(bool have, const char *what) {
+        if (!have) throw Error(KB_ERR_INVALID, std::string(what) + "() needs a batch created with KB_FLAG_FULL_ESTIMATE");
+    }
+    std::shared_ptr<Batch> b_;
+    std::shared_ptr<const Snapshot> snap_;
+    int64_t step_ = 0;
+};
+
+// The estimate of the step that just ran, with the reference's per-call error behaviour.
+inline Estimate step_estimate(const std::shared_ptr<Batch> &b, const char *what_failed) {
+    if (b->N() > kSnapshotMaxFilters) return Estimate(b, false);
+    Estimate est(b, true, /*clear_status=*/true);
+    if (b->N() == 1) {
+        const uint32_t st = est.Status()[0];
+        if (st & KB_ST_SINGULAR) throw StepError(st, std::string("could not invert ") + what_failed + ": matrix singular or near-singular");
+        if (st & KB_ST_ASYMMETRIC) throw StepError(st, "matrix is not symmetric");                       // helper.go:76
+        if (st & KB_ST_NONFINITE) throw StepError(st, "matrix is not symmetric (non-finite covariance)");  // NaN fails helper.go:75's comparison
+    }
+    return est;
 }
 
 // kalman.go:35-47
@@ -137,7 +249,7 @@ class LDKF {
     Estimate Update(const Vector &measurement, const Vector &control) {
         const std::vector<double> y = expand(measurement), u = expand(control);
         check(kb_update(b_->handle(), y.data(), measurement.rows, control.rows ? u.data() : nullptr, control.rows));
-        return Estimate(b_);
+        return step_estimate(b_, "`H*P_kp1_minus*H' + R`");   // vanilla.go:166
     }
     const Noise &GetNoise() const { return noise_; }
     const Matrix &GetStateTransition() const { return F_; }
@@ -207,31 +319,31 @@ using VanillaPair = std::pair<std::shared_ptr<Vanilla>, Estimate>;
 inline VanillaPair NewVanilla(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &noise,
                               int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
     auto kf = std::make_shared<Vanilla>(x0, P0, F, G, H, noise, false, N, pmax, flags);
-    return {kf, Estimate(kf->batch())};
+    return {kf, Estimate(kf->batch(), true)};
 }
 // NewPurePredictorVanilla   vanilla.go:43-62
 inline VanillaPair NewPurePredictorVanilla(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &noise,
                                            int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
     auto kf = std::make_shared<Vanilla>(x0, P0, F, G, H, noise, true, N, pmax, flags);
-    return {kf, Estimate(kf->batch())};
+    return {kf, Estimate(kf->batch(), true)};
 }
 // NewSquareRoot   squareroot.go:21-50
 inline std::pair<std::shared_ptr<SquareRoot>, Estimate> NewSquareRoot(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H,
                                                                       const Noise &noise, int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
     auto kf = std::make_shared<SquareRoot>(x0, P0, F, G, H, noise, N, pmax, flags);
-    return {kf, Estimate(kf->batch())};
+    return {kf, Estimate(kf->batch(), true)};
 }
 // NewInformation(i0, I0, ...)   information.go:20-53
 inline std::pair<std::shared_ptr<Information>, Estimate> NewInformation(const Vector &i0, const Matrix &I0, const Matrix &F, const Matrix &G, const Matrix &H,
                                                                         const Noise &noise, int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
     auto kf = std::make_shared<Information>(i0, I0, F, G, H, noise, false, N, pmax, flags);
-    return {kf, Estimate(kf->batch())};
+    return {kf, Estimate(kf->batch(), true)};
 }
 // NewInformationFromState(x0, P0, ...)   information.go:65-81
 inline std::pair<std::shared_ptr<Information>, Estimate> NewInformationFromState(const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H,
                                                                                  const Noise &noise, int64_t N = 1, int pmax = 0, unsigned flags = KB_FLAG_FULL_ESTIMATE) {
     auto kf = std::make_shared<Information>(x0, P0, F, G, H, noise, true, N, pmax, flags);
-    return {kf, Estimate(kf->batch())};
+    return {kf, Estimate(kf->batch(), true)};
 }
 
 // kalman.go:51-60
@@ -241,11 +353,11 @@ class NLDKF {
     void Prepare(const Matrix &Phi, const Matrix &Htilde) {
         check(kb_prepare(b_->handle(), Phi.data.data(), Htilde.data.data(), Phi.shared() ? 1 : b_->N(), Phi.shared() ? 1 : 0));
     }
-    Estimate Predict() { check(kb_predict_nl(b_->handle())); return Estimate(b_); }
+    Estimate Predict() { check(kb_predict_nl(b_->handle())); return step_estimate(b_, what_failed()); }
     Estimate Update(const Vector &realObservation, const Vector &computedObservation) {
         const std::vector<double> r = expand(realObservation), c = expand(computedObservation);
         check(kb_update_nl(b_->handle(), r.data(), realObservation.rows, c.data(), computedObservation.rows));
-        return Estimate(b_);
+        return step_estimate(b_, what_failed());
     }
     bool EKFEnabled() const { return kb_ekf_enabled(b_->handle()) != 0; }
     void EnableEKF() { check(kb_set_ekf(b_->handle(), 1)); }
@@ -256,6 +368,8 @@ class NLDKF {
     std::shared_ptr<Batch> batch() const { return b_; }
 
    protected:
+    // srif.go:113 "could not invert `Φ` at k=%d", hybrid.go:151 "could not invert `H*P_kp1_minus*H' + R` at k=%d"
+    const char *what_failed() const { return b_->kind() == KB_SRIF ? "`Φ`" : "`H*P_kp1_minus*H' + R`"; }
     std::vector<double> expand(const Vector &v) const {
         if (!v.shared() || b_->N() == 1) return v.data;
         std::vector<double> out;

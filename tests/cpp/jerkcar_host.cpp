@@ -1,7 +1,14 @@
 // Replays the reference's examples/jerkcar scenario (main.go:94-161) through the C++ host mirror
 // (include/gokalman_amd.hpp) for one filter kind and prints CSVExporter rows (exporter.go:34-45).
-// usage: jerkcar_host <vanilla|sqrt|information> <uvec.csv> <yacchist.csv> <yposhist.csv>
+// usage: jerkcar_host <vanilla|sqrt|information> <uvec.csv> <yacchist.csv> <yposhist.csv> [channel]
+// With "channel" the estimates go through a queue to a consumer thread that writes the rows, as main.go:71-90 does with
+// a Go channel and a goroutine per exporter; the consumer is held back until the filter is 500 steps ahead, so every
+// row it writes comes from an Estimate the filter has long moved past (the Estimate must own its data).
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -29,6 +36,16 @@ static std::vector<double> single_record(const char *path, bool one_per_line) {
     return out;
 }
 
+struct EstChan {   // chan gokalman.Estimate
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Estimate> q;
+    size_t pushed = 0;
+    bool closed = false;
+    void send(Estimate e) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(e)); pushed++; } cv.notify_all(); }
+    void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+};
+
 static void write_row(const Estimate &est) {
     const Vector x = est.State();
     const Matrix P = est.Covariance();
@@ -54,9 +71,29 @@ int main(int argc, char **argv) {
         Matrix P0 = ScaledIdentity(4, 10);
         std::shared_ptr<LDKF> kf;
         const std::string kind = argv[1];
-        if (kind == "vanilla") { auto pr = NewVanilla(x0, P0, F, G, H2, noise2, 1, 2); kf = pr.first; write_row(pr.second); }
-        else if (kind == "sqrt") { auto pr = NewSquareRoot(x0, P0, F, G, H2, noise2, 1, 2); kf = pr.first; write_row(pr.second); }
-        else { auto pr = NewInformation(NewVector(4), Matrix(4, 4), F, G, H2, noise2, 1, 2); kf = pr.first; write_row(pr.second); }
+        const bool channel = argc > 5 && std::string(argv[5]) == "channel";
+        EstChan chan;
+        std::thread consumer;
+        if (channel)
+            consumer = std::thread([&chan]() {   // processEst (main.go:76-87)
+                {   // lag: start draining only when the producer is 500 estimates ahead (or done)
+                    std::unique_lock<std::mutex> l(chan.m);
+                    chan.cv.wait(l, [&] { return chan.pushed >= 500 || chan.closed; });
+                }
+                for (;;) {
+                    std::unique_lock<std::mutex> l(chan.m);
+                    chan.cv.wait(l, [&] { return !chan.q.empty() || chan.closed; });
+                    if (chan.q.empty()) break;
+                    Estimate e = std::move(chan.q.front());
+                    chan.q.pop_front();
+                    l.unlock();
+                    write_row(e);
+                }
+            });
+        auto emit = [&](const Estimate &e) { if (channel) chan.send(e); else write_row(e); };
+        if (kind == "vanilla") { auto pr = NewVanilla(x0, P0, F, G, H2, noise2, 1, 2); kf = pr.first; emit(pr.second); }
+        else if (kind == "sqrt") { auto pr = NewSquareRoot(x0, P0, F, G, H2, noise2, 1, 2); kf = pr.first; emit(pr.second); }
+        else { auto pr = NewInformation(NewVector(4), Matrix(4, 4), F, G, H2, noise2, 1, 2); kf = pr.first; emit(pr.second); }
         for (size_t k = 0; k < yacc.size(); k++) {
             Vector meas;
             if ((k + 1) % 10 == 0) {
@@ -66,12 +103,13 @@ int main(int argc, char **argv) {
             } else {
                 meas = NewVector(1, {yacc[k]});
             }
-            write_row(kf->Update(meas, NewVector(1, {u[k]})));
+            emit(kf->Update(meas, NewVector(1, {u[k]})));
             if ((k + 1) % 10 == 0) {
                 kf->SetMeasurementMatrix(H2);
                 kf->SetNoise(noise2);
             }
         }
+        if (channel) { chan.close(); consumer.join(); }
     } catch (const Error &e) {
         std::fprintf(stderr, "gokalman error %d: %s\n", e.code, e.what());
         return 3;

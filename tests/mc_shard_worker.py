@@ -35,12 +35,9 @@ b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"][flo:fhi], d["P0"][flo:fhi], d["F"
                             d["Q"][flo:fhi], d["R"][flo:fhi], device=dev)
 for t in range(T):
     b.update(d["y"][t, flo:fhi])
-x, P = torch.from_numpy(b.get(k.STATE)), torch.from_numpy(b.get(k.COVAR))
-xs = [torch.zeros(kd.shard_range(NF, r, world)[1] - kd.shard_range(NF, r, world)[0], 6, dtype=torch.float64) for r in range(world)]
-Ps = [torch.zeros(kd.shard_range(NF, r, world)[1] - kd.shard_range(NF, r, world)[0], 6, 6, dtype=torch.float64) for r in range(world)]
-dist.all_gather(xs, x)   # result collection for the test only; uneven shards are fine on gloo
-dist.all_gather(Ps, P)
+parts = [None] * world
+dist.all_gather_object(parts, (b.get(k.STATE), b.get(k.COVAR)))   # result collection for the test only (uneven shards)
 if rank == 0:
-    np.savez(out, sums=mc.sums, x=torch.cat(xs).numpy(), P=torch.cat(Ps).numpy())
+    np.savez(out, sums=mc.sums, x=np.concatenate([q[0] for q in parts]), P=np.concatenate([q[1] for q in parts]))
 dist.barrier()
 dist.destroy_process_group()

@@ -10,24 +10,26 @@ from tests import jerkcar as jc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = "/tmp/gokalman_amd_jerkcar_host"
+EXE_SEM = "/tmp/gokalman_amd_estimate_semantics"
 
 
-def _build():
+def _build(src="jerkcar_host.cpp", exe=EXE):
     lib = os.path.join(ROOT, "gokalman_amd")
-    cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "jerkcar_host.cpp"),
-           "-o", EXE, "-L" + lib, "-lgokalman_amd", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"]
+    cmd = ["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", src),
+           "-o", exe, "-L" + lib, "-lgokalman_amd", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.check_call(cmd)
 
 
-def _run(kind):
+def _run(kind, *extra):
     g = jc.GOLDEN
-    return subprocess.run([EXE, kind, os.path.join(g, "uvec.csv"), os.path.join(g, "yacchist.csv"), os.path.join(g, "yposhist.csv")],
+    return subprocess.run([EXE, kind, os.path.join(g, "uvec.csv"), os.path.join(g, "yacchist.csv"), os.path.join(g, "yposhist.csv")] + list(extra),
                           capture_output=True, text=True)
 
 
 def test_cpp_host_builds_and_fails_loudly_without_gpu():
     import torch
     _build()
+    _build("estimate_semantics.cpp", EXE_SEM)
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by the gpu test")
     res = _run("vanilla")
@@ -44,3 +46,75 @@ def test_cpp_host_replays_jerkcar_fixture(kind, fixture):
     exp = jc.load_expected(fixture)
     assert got.shape == exp.shape
     assert np.max(np.abs(got - exp)) <= 5.1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,fixture", [("vanilla", "vanilla"), ("sqrt", "sqrt"), ("information", "information")])
+def test_cpp_host_estimates_through_a_channel_to_a_consumer_thread(kind, fixture):
+    """examples/jerkcar/main.go:71-90: Update's estimates are sent through a channel and written by another goroutine;
+    here a consumer thread that runs 500 steps behind the filter.  Only an Estimate that owns its data survives that."""
+    _build()
+    res = _run(kind, "channel")
+    assert res.returncode == 0, res.stderr
+    got = np.array([[float(v) for v in line.split(",")] for line in res.stdout.strip().splitlines()])
+    exp = jc.load_expected(fixture)
+    assert got.shape == exp.shape
+    assert np.max(np.abs(got - exp)) <= 5.1e-7
+
+
+@pytest.mark.gpu
+def test_cpp_estimate_is_a_value_and_errors_are_per_call():
+    """vanilla.go:216-218 (a fresh estimate per Update), vanilla.go:164-167 / srif.go:112-114 (an Update that fails
+    returns an error, keeps prevEst, and the next Update runs normally) through include/gokalman_amd.hpp."""
+    from oracle import oracle as orc
+    _build("estimate_semantics.cpp", EXE_SEM)
+    res = subprocess.run([EXE_SEM], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    out = {}
+    for line in res.stdout.strip().splitlines():
+        name, _, rest = line.partition(" ")
+        out[name] = rest
+    vec = lambda name: np.array([float(v) for v in out[name].split()])
+    assert out["held_estimate_unchanged"] == "1"
+    assert out["singular_step_threw"] == "1" and "could not invert `H*P_kp1_minus*H' + R`" in out["step_error"]
+    assert out["status3"] == "0"          # the failed call did not poison the next one
+    F, H = np.array([[1, 0.1], [0, 1.0]]), np.array([[1.0, 0]])
+    Q, R = np.diag([1e-3, 1e-3]), np.array([[0.05]])
+    f = orc.Filter.ldkf(orc.VANILLA, [0.5, -0.2], 4.0 * np.eye(2), F, np.zeros((2, 1)), H, Q, R)
+    assert f.update([0.7]) == orc.OK
+    np.testing.assert_allclose(vec("x1"), f.state(), rtol=1e-12)
+    np.testing.assert_allclose(vec("P1").reshape(2, 2), f.covariance(), rtol=1e-12)
+    assert f.update([0.9]) == orc.OK
+    np.testing.assert_allclose(vec("x2"), f.state(), rtol=1e-12)
+    np.testing.assert_allclose(vec("P2").reshape(2, 2), f.covariance(), rtol=1e-12)
+    np.testing.assert_allclose(vec("K2"), f.gain().ravel(), rtol=1e-12)
+    np.testing.assert_allclose(vec("innov2"), f.innovation(), rtol=1e-10)
+    np.testing.assert_allclose(vec("Ppred2").reshape(2, 2), f.pred_covariance(), rtol=1e-12)
+    f.set_measurement_matrix(np.zeros((1, 2))); f.set_noise(Q, np.zeros((1, 1)))
+    assert f.update([1.1]) == orc.ERR_SINGULAR
+    f.set_measurement_matrix(H); f.set_noise(Q, R)
+    assert f.update([1.3]) == orc.OK
+    np.testing.assert_allclose(vec("x3"), f.state(), rtol=1e-12)
+    np.testing.assert_allclose(vec("P3").reshape(2, 2), f.covariance(), rtol=1e-12)
+    # SRIF: singular Phi at the second step
+    assert out["srif_singular_step_threw"] == "1" and "could not invert `Φ`" in out["srif_step_error"]
+    n, p = 6, 2
+
+    def phi(eps):
+        m = np.eye(n)
+        for i in range(3):
+            m[i, i + 3] = 0.1
+        m[4, 1] = eps
+        return m
+    Ht = np.array([[1, 0, 0, 0.5, 0, 0], [0, 1, 0, 0, 0.5, 0.0]])
+    s = orc.Filter.srif([0.3, -0.1, 0.2, 0.05, -0.02, 0.01], np.diag([10.0, 10, 10, 1, 1, 1]), np.diag([1e-2, 1e-3]), p)
+    s.prepare(phi(0.01), Ht)
+    assert s.update_nl([0.4, -0.3], [0.35, -0.25]) == orc.OK
+    np.testing.assert_allclose(vec("srif_x1"), s.state(), rtol=1e-9)
+    bad = phi(0.02); bad[2, :] = 0.0
+    s.prepare(bad, Ht)
+    assert s.update_nl([0.5, -0.2], [0.45, -0.15]) == orc.ERR_SINGULAR
+    s.prepare(phi(0.03), Ht)
+    assert s.update_nl([0.6, -0.1], [0.55, -0.05]) == orc.OK
+    np.testing.assert_allclose(vec("srif_x3"), s.state(), rtol=1e-9)
+    np.testing.assert_allclose(vec("srif_P3").reshape(n, n), s.covariance(), rtol=1e-8, atol=1e-14)

@@ -1,0 +1,134 @@
+"""Estimate value semantics of the Python mirror (kalman.go:64-72, vanilla.go:216-218), the one-synchronisation snapshot
+entry point kb_get_estimate, the argument-shape checks in front of the count-less C ABI, and BatchNoise's zero Q / R."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from gokalman_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_steps(kind, d, i, steps):
+    f = orc.Filter.ldkf(kind, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i])
+    out = []
+    for t in range(steps):
+        assert f.update(d["y"][t, i]) == orc.OK
+        out.append((f.state(), f.covariance(), f.pred_covariance(), f.gain(), f.innovation(), f.measurement()))
+    return out
+
+
+@pytest.mark.parametrize("kind,okind", [(k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)])
+def test_update_returns_an_owning_estimate_per_step(kind, okind):
+    N, steps = 70, 5
+    d = synth.linear_batch(N, 6, 3, steps)
+    b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    ests = [b.update(d["y"][t]) for t in range(steps)]     # kept, read only after the last Update (montecarlo.go:108-117)
+    assert all(e.owning for e in ests)
+    ref = [_oracle_steps(okind, d, i, steps) for i in range(N)]
+    for t, e in enumerate(ests):
+        for j, getter in enumerate((e.state, e.covariance, e.pred_covariance, e.gain, e.innovation, e.measurement)):
+            want = np.array([ref[i][t][j] for i in range(N)])
+            assert synth.rel_frobenius(getter().reshape(N, -1), want.reshape(N, -1)) <= 1e-9, (t, j)
+        assert not e.status().any()
+    # IsWithinNsigma on the snapshot = the device's answer for the current step
+    assert np.array_equal(ests[-1].is_within_nsigma(2.0), b.is_within_nsigma(2.0))
+
+
+def test_view_estimate_refuses_to_read_a_later_step():
+    N = 5000   # > SNAPSHOT_MAX_FILTERS: update() hands out a guarded view
+    d = synth.linear_batch(N, 6, 3, 3)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    e0 = b.update(d["y"][0])
+    assert not e0.owning
+    x0 = e0.state().copy()
+    frozen = b.estimate().freeze()
+    e1 = b.update(d["y"][1])
+    with pytest.raises(ga.StaleEstimateError):
+        e0.state()
+    with pytest.raises(ga.StaleEstimateError):
+        e0.freeze()
+    assert np.array_equal(frozen.state(), x0) and not np.array_equal(e1.state(), x0)
+    e2 = b.update(d["y"][2], snapshot=True)
+    assert e2.owning
+    b.reset()
+    with pytest.raises(ga.StaleEstimateError):
+        e1.covariance()
+    assert e2.state().shape == (N, 6)
+
+
+def test_get_estimate_subrange_and_read_and_clear_status():
+    N = 200
+    d = synth.linear_batch(N, 6, 3, 2)
+    d["R"][17] = 0.0; d["H"][17] = 0.0      # S = 0 for filter 17: singular every step
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    b.update(d["y"][0], snapshot=False)
+    first, cnt = 10, 20
+    x, P, st = np.zeros((cnt, 6)), np.zeros((cnt, 6, 6)), np.zeros(cnt, dtype=np.uint32)
+    v = k.EstimateView()
+    dp = C.POINTER(C.c_double)
+    v.state, v.covariance = x.ctypes.data_as(dp), P.ctypes.data_as(dp)
+    v.status, v.clear_status = st.ctypes.data_as(C.POINTER(C.c_uint32)), 1
+    k.check(k.lib().kb_get_estimate(b._h, first, cnt, C.byref(v)))
+    assert np.array_equal(x, b.get(k.STATE, first, cnt)) and np.array_equal(P, b.get(k.COVAR, first, cnt))
+    assert st[7] == k.ST_SINGULAR and np.count_nonzero(st) == 1
+    assert np.array_equal(x[7], d["x0"][17])           # the failed filter kept its estimate
+    assert not b.status().any()                        # read AND cleared
+    b.update(d["y"][1], snapshot=False)
+    assert b.status()[17] == k.ST_SINGULAR             # fails again at the next step: a per-call report
+    with pytest.raises(ga.KalmanError):
+        k.check(k.lib().kb_get_estimate(b._h, 190, 20, C.byref(v)))
+
+
+def test_argument_shapes_are_checked_before_the_c_abi_reads_them():
+    N = 8
+    d = synth.linear_batch(N, 4, 2, 1)
+    G = np.array([[0.0], [1e-4], [1e-2], [0.0]])
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], G, d["H"], d["Q"], d["R"])
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        b.update(np.zeros((1, 2)), np.zeros((N, 1)))        # leading dimension 1 on an 8-filter batch
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        b.update(np.zeros((N, 2)), np.zeros((3, 1)))
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        b.set(k.F, np.zeros((N, 3, 3)), 2)
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        b.set(k.F, np.zeros((5, 4, 4)), 2)
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        b.set_measurement_matrix(np.zeros((2, 5)))
+    assert b.step() == 0
+    b.update(np.zeros(2), np.zeros(1))                      # one vector for every filter is fine
+    s = ga.FilterBatch(k.SRIF, 6, 2, 0, N)
+    s.set(k.X, np.zeros(6), 1); s.set(k.P, np.eye(6), 2); s.set(k.R, np.eye(2) * 1e-2, 2, p_rows=2); s.init()
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        s.prepare(np.zeros((1, 6, 6)), np.zeros((1, 2, 6)))
+    s.prepare(np.eye(6), np.ones((2, 6)))
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        s.update_nl(np.zeros((2, 2)), np.zeros((N, 2)))
+
+
+def test_batch_noise_zeroes_q_and_r():
+    """BatchNoise.ProcessMatrix / MeasurementMatrix are zero matrices (noise.go:89-98) whatever Q, R the filter had."""
+    N, n, p, steps = 40, 4, 2, 4
+    d = synth.linear_batch(N, n, p, steps)
+    rng = np.random.default_rng(3)
+    proc, meas = 1e-2 * rng.standard_normal((steps, n)), 1e-2 * rng.standard_normal((steps, p))
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])   # non-zero Q, R
+    b.set_batch_noise(proc, meas)
+    assert not b.get(k.Q).any() and not b.get(k.R).any()
+    for t in range(steps):
+        est = b.update(d["y"][t])
+    xs, Ps = [], []
+    Z_Q, Z_R = np.zeros((n, n)), np.zeros((p, p))
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], Z_Q, Z_R)
+        for t in range(steps):
+            assert f.update(d["y"][t, i], None, proc[t], meas[t], proc[t]) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-9
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= 1e-9
+    with pytest.raises(ga.KalmanError, match="dimensions must agree"):
+        b.set_batch_noise(np.zeros((4, 3)), meas)
