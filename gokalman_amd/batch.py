@@ -278,8 +278,8 @@ class FilterBatch:
         return _f64(v)
 
     def _estimate(self, snapshot):
-        if snapshot is None:
-            snapshot = self.N <= SNAPSHOT_MAX_FILTERS
+        if snapshot is None:   # BatchKF has no per-step estimate: Solve() (kb_get) is an explicit call there (batch.go:64-79)
+            snapshot = self.N <= SNAPSHOT_MAX_FILTERS and self.kind != k.BATCH_LS
         return Estimate(self, snapshot=snapshot)
 
     def update(self, measurement, control=None, snapshot=None):

@@ -75,11 +75,11 @@ def test_get_estimate_subrange_and_read_and_clear_status():
     v.status, v.clear_status = st.ctypes.data_as(C.POINTER(C.c_uint32)), 1
     k.check(k.lib().kb_get_estimate(b._h, first, cnt, C.byref(v)))
     assert np.array_equal(x, b.get(k.STATE, first, cnt)) and np.array_equal(P, b.get(k.COVAR, first, cnt))
-    assert st[7] == k.ST_SINGULAR and np.count_nonzero(st) == 1
+    assert (st[7] & k.ST_SINGULAR) and np.count_nonzero(st) == 1
     assert np.array_equal(x[7], d["x0"][17])           # the failed filter kept its estimate
     assert not b.status().any()                        # read AND cleared
     b.update(d["y"][1], snapshot=False)
-    assert b.status()[17] == k.ST_SINGULAR             # fails again at the next step: a per-call report
+    assert b.status()[17] & k.ST_SINGULAR              # fails again at the next step: a per-call report
     with pytest.raises(ga.KalmanError):
         k.check(k.lib().kb_get_estimate(b._h, 190, 20, C.byref(v)))
 
@@ -129,6 +129,7 @@ def test_batch_noise_zeroes_q_and_r():
             assert f.update(d["y"][t, i], None, proc[t], meas[t], proc[t]) == orc.OK
         xs.append(f.state()); Ps.append(f.covariance())
     assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-9
-    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= 1e-9
+    # Q = R = 0 and 8 measurements of 4 states: the posterior covariance collapses to rounding level, so absolute here
+    assert np.max(np.abs(est.covariance() - np.array(Ps))) <= 1e-9
     with pytest.raises(ga.KalmanError, match="dimensions must agree"):
         b.set_batch_noise(np.zeros((4, 3)), meas)
