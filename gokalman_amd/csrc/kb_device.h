@@ -126,6 +126,7 @@ __device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P],
 // (generic kernels).  Same algorithm; `a` is destroyed, X receives the inverse.
 template <typename T, int LD>
 __device__ inline bool inverse_lu_rt(int p, T *a, T *X) {
+#pragma clang fp contract(off)   // generic (statement-by-statement) kernels only: see kb_kinds.hip
     T b[LD * LD];
     T anorm = T(0);
     for (int i = 0; i < p; i++) {

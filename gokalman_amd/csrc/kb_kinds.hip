@@ -4,6 +4,10 @@
 // benchmark shapes live in kb_squareroot_reg.hip / kb_srif_reg.hip.
 //
 //   squareroot.go:129-274   information.go:153-227   srif.go:101-160,298-340   hybrid.go:104-204
+// The generic kernels are the statement-by-statement path (every shape, strict AsSymDense test, AWGN): no FMA contraction,
+// so that sums round exactly as gonum's (and the oracle's) separate multiply and add do.  The strict symmetry test decides
+// on rounding-level differences between M_ij and M_ji (helper.go:75); with fused products it would decide differently.
+#pragma clang fp contract(off)
 #include "kb_dense.h"
 #include "kb_internal.h"
 

@@ -26,6 +26,7 @@ namespace kb {
 // ---------------------------------------------------------------------------------
 template <typename T, int LD>
 __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
+#pragma clang fp contract(off)   // statement-by-statement path: products and sums round separately, as in gonum / the oracle (see kb_kinds.hip)
     const int lane = threadIdx.x & 63;
     const int64_t tile = blockIdx.x;
     if (tile >= a.ntiles) return;
