@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libgokalman_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast", "-fno-fast-math"]
+         "-ffp-contract=fast-honor-pragmas", "-fno-fast-math"]
 
 
 def _hipcc():

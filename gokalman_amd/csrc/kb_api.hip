@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "kb_internal.h"
@@ -84,6 +85,43 @@ int ensure_xp(Batch &b) {
     if (b.d_xp) return KB_OK;
     KB_HIP(hipMalloc(&b.d_xp, b.block_bytes(b.n + tri(b.n))));
     return KB_OK;
+}
+
+// ---- HeavyScope (kb_internal.h) -------------------------------------------------------------------
+static hipStream_t heavy_stream(int device) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {nullptr};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[device]) {
+        if (hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) streams[device] = nullptr;
+    }
+    return streams[device];
+}
+
+HeavyScope::HeavyScope(int device, hipStream_t user, bool heavy, hipEvent_t *cached) : stream(user), user_(user) {
+    if (!heavy) return;
+    hipStream_t hs = heavy_stream(device);
+    if (!hs) return;   // could not create it: stay on the caller's stream
+    for (int i = 0; i < 2; i++) {
+        if (cached && cached[i]) { ev_[i] = cached[i]; continue; }
+        if (hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) != hipSuccess) { ev_[i] = nullptr; return; }
+        if (cached) cached[i] = ev_[i];
+    }
+    owned_ = cached == nullptr;
+    if (hipEventRecord(ev_[0], user_) != hipSuccess || hipStreamWaitEvent(hs, ev_[0], 0) != hipSuccess) return;
+    heavy_ = true;
+    stream = hs;
+}
+
+HeavyScope::~HeavyScope() {
+    if (heavy_) {
+        (void)hipEventRecord(ev_[1], stream);
+        (void)hipStreamWaitEvent(user_, ev_[1], 0);
+    }
+    if (owned_)
+        for (int i = 0; i < 2; i++)
+            if (ev_[i]) (void)hipEventDestroy(ev_[i]);   // released by the runtime once the recorded work has completed
 }
 
 int use_device(const Batch &b) {
@@ -295,6 +333,8 @@ void kb_destroy(kb_batch *b) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_pin) (void)hipHostFree(b->h_pin);
+    for (hipEvent_t e : b->ev_heavy)
+        if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }

@@ -126,9 +126,12 @@ static int run_derive(Batch &b, int op, int rp, int *fails) {
     KB_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), b.stream));
     const dim3 grid((unsigned)b.ntiles), block(64);
     const int d = b.n > b.pmax ? b.n : b.pmax;
-#define KB_D(TT, LDD) hipLaunchKernelGGL((derive_kernel<TT, LDD>), grid, block, 0, b.stream, b.d_state, b.d_model, b.N, b.L, op, rp, d_cnt)
-    if (b.dtype == KB_F64) { if (d <= 4) KB_D(double, 4); else if (d <= 8) KB_D(double, 8); else KB_D(double, 16); }
-    else                   { if (d <= 4) KB_D(float, 4);  else if (d <= 8) KB_D(float, 8);  else KB_D(float, 16); }
+#define KB_D(TT, LDD) hipLaunchKernelGGL((derive_kernel<TT, LDD>), grid, block, 0, hs.stream, b.d_state, b.d_model, b.N, b.L, op, rp, d_cnt)
+    {
+        const HeavyScope hs(b, d > 8);   // LD = 16: scratch-heavy, see kb_internal.h
+        if (b.dtype == KB_F64) { if (d <= 4) KB_D(double, 4); else if (d <= 8) KB_D(double, 8); else KB_D(double, 16); }
+        else                   { if (d <= 4) KB_D(float, 4);  else if (d <= 8) KB_D(float, 8);  else KB_D(float, 16); }
+    }
 #undef KB_D
     int cnt = 0;
     hipError_t e = hipGetLastError();
@@ -286,10 +289,13 @@ int launch_materialise(const Batch &b, const void *src_block, bool pred, void *o
     const int src_elems = pred ? b.L.es_elems : b.L.st_elems;
     const int mat_off = pred ? b.L.es_ppred : b.L.st_mat;
     const dim3 grid((unsigned)b.ntiles), block(64);
-#define KB_M(TT, LDD) hipLaunchKernelGGL((materialise_kernel<TT, LDD>), grid, block, 0, b.stream, src_block, src_elems, \
+#define KB_M(TT, LDD) hipLaunchKernelGGL((materialise_kernel<TT, LDD>), grid, block, 0, hs.stream, src_block, src_elems, \
                                          b.L.st_vec, mat_off, (const void *)b.d_state, b.L.st_elems, b.L.st_vec, out_block, b.d_status, b.N, n, b.kind, pred ? 1 : 0)
-    if (b.dtype == KB_F64) { if (n <= 4) KB_M(double, 4); else if (n <= 8) KB_M(double, 8); else KB_M(double, 16); }
-    else                   { if (n <= 4) KB_M(float, 4);  else if (n <= 8) KB_M(float, 8);  else KB_M(float, 16); }
+    {
+        const HeavyScope hs(b, n > 8);   // LD = 16: scratch-heavy, see kb_internal.h
+        if (b.dtype == KB_F64) { if (n <= 4) KB_M(double, 4); else if (n <= 8) KB_M(double, 8); else KB_M(double, 16); }
+        else                   { if (n <= 4) KB_M(float, 4);  else if (n <= 8) KB_M(float, 8);  else KB_M(float, 16); }
+    }
 #undef KB_M
     KB_HIP(hipGetLastError());
     return KB_OK;
@@ -339,10 +345,13 @@ int launch_smooth(const Batch &b, const void *xp_block, int xp_elems, int vec_of
                   void *x_out, void *P_out) {
     const dim3 grid((unsigned)b.ntiles), block(64);
     const int n = b.n;
-#define KB_SM(TT, LDD) hipLaunchKernelGGL((smooth_kernel<TT, LDD>), grid, block, 0, b.stream, (const TT *)xp_block, xp_elems, vec_off, mat_off, \
+#define KB_SM(TT, LDD) hipLaunchKernelGGL((smooth_kernel<TT, LDD>), grid, block, 0, hs.stream, (const TT *)xp_block, xp_elems, vec_off, mat_off, \
                                           (const TT *)phis, ld, steps, (TT *)x_out, (TT *)P_out, b.d_status, b.N, n)
-    if (b.dtype == KB_F64) { if (n <= 4) KB_SM(double, 4); else if (n <= 8) KB_SM(double, 8); else KB_SM(double, 16); }
-    else                   { if (n <= 4) KB_SM(float, 4);  else if (n <= 8) KB_SM(float, 8);  else KB_SM(float, 16); }
+    {
+        const HeavyScope hs(b, n > 8);   // LD = 16: scratch-heavy, see kb_internal.h
+        if (b.dtype == KB_F64) { if (n <= 4) KB_SM(double, 4); else if (n <= 8) KB_SM(double, 8); else KB_SM(double, 16); }
+        else                   { if (n <= 4) KB_SM(float, 4);  else if (n <= 8) KB_SM(float, 8);  else KB_SM(float, 16); }
+    }
 #undef KB_SM
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -73,6 +73,7 @@ struct Batch {
     uint64_t seed = 0;
     int64_t epoch = 0;
     void *d_bn_proc = nullptr, *d_bn_meas = nullptr; int bn_nproc = 0, bn_nmeas = 0, bn_p = 0;  // BatchNoise sequences (batch dtype)
+    mutable hipEvent_t ev_heavy[2] = {nullptr, nullptr};   // HeavyScope: hand-over events between this handle's stream and the heavy stream
     size_t esize() const { return dtype == KB_F64 ? 8 : 4; }
     size_t block_bytes(int elems) const { return (size_t)ntiles * KB_TILE * (size_t)elems * esize(); }
 };
@@ -148,6 +149,27 @@ constexpr size_t KB_PIN_TILE_BYTES = (size_t)KB_MAX_DIM * KB_TILE * sizeof(doubl
 constexpr size_t KB_PIN_OUT_BYTES = (size_t)KB_TILE * KB_MAX_DIM * KB_MAX_DIM * sizeof(double);
 void fill_step_args(const Batch &b, StepArgs &a);
 int upload_field(Batch &b, int field, const double *host, int64_t count, int broadcast, int p_rows);
+
+// The run-time-dimension kernels with a leading dimension of 16 keep 10-31 KB of private arrays per lane.  The runtime
+// sizes a queue's scratch for the whole device (bytes per lane x 64 x 8192 wave slots = up to 15 GiB) the first time such
+// a kernel runs on it and keeps it for the life of the queue, and a process may hold about 64 GiB of scratch in total:
+// with one stream per handle, a handful of handles that each ran one big-shape generic step exhaust it and the runtime
+// aborts the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  So every scratch-heavy launch goes to ONE stream per device,
+// ordered after the handle's stream and before its later work by a pair of events.  The register kernels (no scratch) and
+// the small-shape generic kernels (<= 8 KB per lane) stay on the handle's own stream.
+struct HeavyScope {
+    hipStream_t stream;            // launch on this
+    HeavyScope(const Batch &b, bool heavy) : HeavyScope(b.device, b.stream, heavy, b.ev_heavy) {}
+    HeavyScope(int device, hipStream_t user, bool heavy, hipEvent_t *cached = nullptr);
+    ~HeavyScope();
+    HeavyScope(const HeavyScope &) = delete;
+    HeavyScope &operator=(const HeavyScope &) = delete;
+   private:
+    hipStream_t user_ = nullptr;
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    bool heavy_ = false, owned_ = false;
+};
+constexpr int KB_HEAVY_LD = 16;   // leading dimension from which a generic kernel counts as scratch-heavy
 
 inline dim3 tile_grid(int64_t ntiles) { return dim3((unsigned)((ntiles + 3) / 4)); }
 

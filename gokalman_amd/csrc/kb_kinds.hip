@@ -558,14 +558,15 @@ __global__ void __launch_bounds__(64) batch_ls_gen_kernel(const StepArgs a) {
     do {                                                                                                     \
         const int dm = a.n > a.p ? (a.n > a.m ? a.n : a.m) : (a.p > a.m ? a.p : a.m);                        \
         const dim3 grid((unsigned)a.ntiles), block(64);                                                      \
+        const HeavyScope hs(b, dm > 8);   /* LD = 16: scratch-heavy, see kb_internal.h */                     \
         if (b.dtype == KB_F64) {                                                                             \
-            if (dm <= 4) hipLaunchKernelGGL((KERNEL<double, 4>), grid, block, 0, b.stream, a);               \
-            else if (dm <= 8) hipLaunchKernelGGL((KERNEL<double, 8>), grid, block, 0, b.stream, a);          \
-            else hipLaunchKernelGGL((KERNEL<double, 16>), grid, block, 0, b.stream, a);                      \
+            if (dm <= 4) hipLaunchKernelGGL((KERNEL<double, 4>), grid, block, 0, hs.stream, a);              \
+            else if (dm <= 8) hipLaunchKernelGGL((KERNEL<double, 8>), grid, block, 0, hs.stream, a);         \
+            else hipLaunchKernelGGL((KERNEL<double, 16>), grid, block, 0, hs.stream, a);                     \
         } else {                                                                                             \
-            if (dm <= 4) hipLaunchKernelGGL((KERNEL<float, 4>), grid, block, 0, b.stream, a);                \
-            else if (dm <= 8) hipLaunchKernelGGL((KERNEL<float, 8>), grid, block, 0, b.stream, a);           \
-            else hipLaunchKernelGGL((KERNEL<float, 16>), grid, block, 0, b.stream, a);                       \
+            if (dm <= 4) hipLaunchKernelGGL((KERNEL<float, 4>), grid, block, 0, hs.stream, a);               \
+            else if (dm <= 8) hipLaunchKernelGGL((KERNEL<float, 8>), grid, block, 0, hs.stream, a);          \
+            else hipLaunchKernelGGL((KERNEL<float, 16>), grid, block, 0, hs.stream, a);                      \
         }                                                                                                    \
         KB_HIP(hipGetLastError());                                                                           \
     } while (0)

@@ -270,6 +270,10 @@ template <typename T, typename IO>
 static int vl_launch(int n, int q, int64_t N, const VlSrc &sA, const VlSrc &sG, const VlSrc &sW, const VlSrc &sdt, void *F, void *Q,
                      int64_t o_es, int64_t o_fs, uint32_t *status, hipStream_t stream) {
     const dim3 grid((unsigned)((N + 63) / 64)), block(64);
+    int device = 0;
+    KB_HIP(hipGetDevice(&device));
+    const HeavyScope hs(device, stream, n > 4);   // LD = 12 / 16: 9-16 KB of private arrays per lane, see kb_internal.h
+    stream = hs.stream;
     if (n <= 2) hipLaunchKernelGGL((vanloan_kernel<T, IO, 4>), grid, block, 0, stream, n, q, N, sA, sG, sW, sdt, (IO *)F, (IO *)Q, o_es, o_fs, status);
     else if (n <= 4) hipLaunchKernelGGL((vanloan_kernel<T, IO, 8>), grid, block, 0, stream, n, q, N, sA, sG, sW, sdt, (IO *)F, (IO *)Q, o_es, o_fs, status);
     else if (n <= 6) hipLaunchKernelGGL((vanloan_kernel<T, IO, 12>), grid, block, 0, stream, n, q, N, sA, sG, sW, sdt, (IO *)F, (IO *)Q, o_es, o_fs, status);

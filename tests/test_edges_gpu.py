@@ -243,3 +243,29 @@ def test_two_handles_driven_from_two_threads_concurrently():
     for i in range(2):
         assert together[i][2] == 0
         assert np.array_equal(alone[i][0], together[i][0]) and np.array_equal(alone[i][1], together[i][1])
+
+
+def test_many_handles_with_big_shape_generic_steps_do_not_exhaust_scratch():
+    """The run-time-dimension kernels for n > 8 keep up to 31 KB of private arrays per lane; the runtime sizes a queue's
+    scratch for the whole device (15 GiB) and keeps it, and a process that spread such launches over its handles' own
+    streams ran out of scratch (the runtime aborts).  They all go through one stream per device now (kb_internal.h
+    HeavyScope): the retained scratch stays at one queue's worth however many handles there are."""
+    import torch
+    n, p, N = 12, 4, 64
+    rng = np.random.default_rng(12)
+    free0 = torch.cuda.mem_get_info()[0]
+    keep = []
+    for kind in (k.VANILLA, k.SQUAREROOT, k.INFORMATION, k.VANILLA, k.SQUAREROOT, k.INFORMATION, k.VANILLA, k.VANILLA):
+        F = np.eye(n) + 1e-2 * rng.standard_normal((N, n, n))
+        H = rng.standard_normal((N, p, n))
+        b = ga.FilterBatch.new_ldkf(kind, rng.standard_normal((N, n)), np.eye(n), F, None, H, 1e-3 * np.eye(n), 0.1 * np.eye(p),
+                                    flags=k.FLAG_STRICT_SYMCHECK | (k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0))
+        est = b.update(rng.standard_normal((N, p)))
+        assert np.isfinite(est.state()).all() and not b.status().any()
+        keep.append(b)
+    A = -np.eye(8) + 0.1 * rng.standard_normal((8, 8))
+    Fd, Qd, st = ga.van_loan(A, np.eye(8), 1e-2 * np.eye(8), 0.01)
+    assert np.isfinite(Fd).all() and np.isfinite(Qd).all()
+    torch.cuda.synchronize()
+    held = (free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30
+    assert held < 24.0, "scratch retained by the process: %.1f GiB" % held    # one queue's worth (<= 15.3 GiB) + the batches
