@@ -33,7 +33,7 @@ def _deps_mtime():
 
 # per-file extra flags: the SLP vectoriser packs fp32 pairs in the fully unrolled SRIF panels and
 # lengthens live ranges (more AGPR / scratch spills); it buys nothing there
-EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src, force):

@@ -30,6 +30,19 @@ __device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontempo
 template <typename T>
 __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
+// A read-once global load at (wave-uniform pointer) + (32-bit per-lane BYTE offset), in the scalar-base form of global_load
+// (`global_load_dword v, v_off, s[base:base+1]`): no 64-bit vector address arithmetic and no address register pair per
+// access.  The pointer goes through readfirstlane so that the compiler keeps it in SGPRs instead of folding the lane
+// offset into it, and keeps its global address space (a flat load has no such form).
+template <typename T>
+__device__ __forceinline__ T ld_uniform_nt(const T *uniform_ptr, unsigned lane_bytes) {
+    typedef const __attribute__((address_space(1))) T *gptr;
+    typedef const __attribute__((address_space(1))) char *gbytes;
+    const unsigned long long v = (unsigned long long)uniform_ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_nontemporal_load((gptr)((gbytes)(((unsigned long long)hi << 32) | lo) + lane_bytes));
+}
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct Eps<float>  { static constexpr float  tiny = 1.17549435e-38f; };

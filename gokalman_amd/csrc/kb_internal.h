@@ -137,6 +137,8 @@ int launch_hybrid(const Batch &b, const StepArgs &a);
 int launch_batch_ls(const Batch &b, const StepArgs &a);
 bool hybrid_reg_ok(const Batch &b, const StepArgs &a);
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
+bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
+bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums);
 int mc_repl();
 // shared host helpers (kb_api.hip)

@@ -1,0 +1,458 @@
+// kb_srif_pair.h -- SRIF Update (srif.go:101-160, :298-340, helper.go:142-172) with TWO LANES PER FILTER.
+//
+// Why: with one filter per lane the 18 x 13 Householder panel alone is 234 values per lane, so the one-filter-per-lane
+// kernels (kb_srif_reg.hip) run at one wave per SIMD out of the 512-register budget: a lone wave issues one vector
+// instruction every 4 cycles instead of 2, cannot overlap its own loads with its own arithmetic, and values beyond the
+// 256 architectural VGPRs cost a copy per use.  Here a wave owns 32 filters: lane f (0..31) and lane 32 + f share filter
+// f, the lower half of the wave holding the EVEN rows of every row-distributed matrix and the upper half the ODD rows.
+// Per lane that is 9 x 13 = 117 panel values: the kernel fits 256 registers, two waves share a SIMD (one loads while the
+// other computes), and nothing spills.
+//
+//   lane mapping   lane = 32 * l + f.  With the AoSoA-64 layout element e of 32 consecutive filters is one contiguous
+//                  128-byte segment, so every wave-level load is two fully used segments (one per half) -- measured at the
+//                  same 6.6 TB/s as the one-filter-per-lane stream, where the interleaved mapping lane = 2 f + l reads at
+//                  5.2 TB/s on the same layout (scripts/diag_lanepair.hip).  The halves exchange values with
+//                  v_permlane32_swap_b32 (gfx950): swap(x, x) leaves [x.lo | x.lo] and [x.hi | x.hi].
+//   time update    x = R^-1 b by back substitution, one exchange per component (row i lives in half i % 2);
+//                  Phi's COLUMNS are split the same way (72 registers per lane): xBar = Phi x is a partial sum per half + one
+//                  exchange per row; in P Phi = L U the half that owns column j finds the pivot and forms the multipliers,
+//                  the other half receives them (one exchange each), both update their own columns.  The factors go to LDS
+//                  once per filter ([element][32 filters], 18 KB per wave in fp32, conflict-free, broadcast to both
+//                  halves), and each half solves z Phi = R[i,:] for ITS six rows i, all six at once (one LDS read per
+//                  factor element).
+//                  RBar = R Phi^-1 therefore appears directly in the lanes that own those rows of the panel.
+//   measurement    rows of [L Htilde | L y] are formed where they live; Householder with rows distributed over the halves:
+//                  per column one partial dot product per half + one exchange.  Row k is final after step k and is stored
+//                  from the half that owns it.
+// Arithmetic follows kb_srif_reg.hip (LU solves instead of inverse-then-multiply; exact singularity / non-finite flags);
+// dot products that span both halves are summed as (even rows) + (odd rows), a rounding-level reordering.
+// Failure semantics as everywhere (kb_srif_reg.hip header): a singular Phi / R skips this step for that filter only.
+#pragma once
+#include "kb_internal.h"
+#include "kb_static.h"
+
+namespace kb {
+
+// ---- exchange between lane f and lane 32 + f -------------------------------------------------------
+__device__ __forceinline__ void halves(unsigned x, unsigned &lo, unsigned &hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // [x.lo | x.lo], [x.hi | x.hi]
+    lo = r[0];
+    hi = r[1];
+}
+__device__ __forceinline__ void halves(float x, float &lo, float &hi) {
+    unsigned a, b;
+    halves(__float_as_uint(x), a, b);
+    lo = __uint_as_float(a);
+    hi = __uint_as_float(b);
+}
+__device__ __forceinline__ void halves(double x, double &lo, double &hi) {
+    unsigned al, bl, ah, bh;
+    halves((unsigned)__double2loint(x), al, bl);
+    halves((unsigned)__double2hiint(x), ah, bh);
+    lo = __hiloint2double((int)ah, (int)al);
+    hi = __hiloint2double((int)bh, (int)bl);
+}
+// y <- [y.lo | x.lo], x <- [y.hi | x.hi]: each half hands one value to the other and keeps one, in ONE instruction
+__device__ __forceinline__ void cross(float &y, float &x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(x), false, false);
+    y = __uint_as_float(r[0]);
+    x = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void cross(double &y, double &x) {
+    const auto rl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(y), (unsigned)__double2loint(x), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(y), (unsigned)__double2hiint(x), false, false);
+    y = __hiloint2double((int)rh[0], (int)rl[0]);
+    x = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+// sum over the two halves, identical in both (even-row part + odd-row part)
+template <typename T>
+__device__ __forceinline__ T allsum(T x) {
+    T lo, hi;
+    halves(x, lo, hi);
+    return lo + hi;
+}
+// the value held by half `h` (compile-time), in both halves
+template <typename T>
+__device__ __forceinline__ T from_half(T x, int h) {
+    T lo, hi;
+    halves(x, lo, hi);
+    return h ? hi : lo;
+}
+
+__device__ __forceinline__ int pnib(uint64_t perm, int r) { return (int)((perm >> (4 * r)) & 15u); }
+
+// One half-tile (32 filters) of the SRIF Update.  DENSE: R may be a full matrix for some filter of this half-tile (the
+// Update right after a Predict(), or a filter that skipped such an Update): all of R is read, State(prev) is a pivoted LU
+// solve, and the finished factor's lower triangle is zeroed in memory.  DENSE = false is the steady state (R upper
+// triangular, structural zeros skipped at compile time).
+template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE>
+__device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, int half, int lane, T *lds_lu) {
+    static_assert(NS % 2 == 0 && NM % 2 == 0, "rows are split by parity");
+    constexpr int COLS = NS + 1, HS = NS / 2, HM = NM / 2, SL = HS + HM, ROWE = NS * KB_TILE;
+    // Addressing: every base below is wave-uniform (tile / half come from readfirstlane in the kernel), the per-lane part
+    // is ONE 32-bit element offset (vf, or vrow for the own rows), so the loads and stores use the scalar-base +
+    // 32-bit-vector-offset form: no 64-bit address pair per access (there are ~350 accesses per lane).
+    const unsigned vf = (unsigned)lane & 31u;
+    const bool is_hi = lane >= 32;
+    const int l = is_hi ? 1 : 0;
+    const unsigned vrow = vf + (is_hi ? (unsigned)ROWE : 0u);   // own rows: element NS + 2 s NS + j from here is R[2 s + l][j]
+    const unsigned vl = vf + (is_hi ? (unsigned)KB_TILE : 0u);  // own element of an (even, odd) pair of consecutive elements
+    const int64_t first = tile * KB_TILE + half * 32;
+    const int64_t fi = first + vf;
+    const bool inb = fi < a.N;
+    const unsigned vx = inb ? vf : 0u;   // caller's arrays end at N: lanes past it re-read the half-tile's first filter
+    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + half * 32;
+    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + half * 32;
+    const T *ephi = EXT ? (const T *)a.ext_phi + first : nullptr;
+    const T *eh = EXT ? (const T *)a.ext_h + first : nullptr;
+    const T *yr = (const T *)a.y + tile * a.y_ts + half * 32;
+    const T *yc = (const T *)a.y2 + tile * a.y2_ts + half * 32;
+    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + half * 32 : nullptr;
+    auto ld_st = [&](int e) { return st[(unsigned)(e * KB_TILE) + vf]; };            // state element e of this lane's filter
+    auto ld_row = [&](int e) { return st[(unsigned)(e * KB_TILE) + vrow]; };         // ... of the own row
+    auto ld_mo = [&](int e) { return __builtin_nontemporal_load(mo + ((unsigned)(e * KB_TILE) + vf)); };
+    // element e of Phi for the lower half, element e + 1 for the upper half (its column is the next one); the caller's planar
+    // arrays have a run-time element stride, so their addresses are formed as (scalar pointer) + (32-bit lane byte offset)
+    const unsigned vphi = EXT ? vx + (is_hi ? (unsigned)a.ext_ld : 0u) : vl;
+    const unsigned bx = vx * (unsigned)sizeof(T), bphi = vphi * (unsigned)sizeof(T);
+    auto ld_phic = [&](int e) {
+        return EXT ? ld_uniform_nt(ephi + (int64_t)e * a.ext_ld, bphi)
+                   : __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_F + e) * KB_TILE) + vphi));
+    };
+    auto ld_h = [&](int e) { return EXT ? ld_uniform_nt(eh + (int64_t)e * a.ext_ld, bx) : ld_mo(a.L.mo_H + e); };
+
+    unsigned err = 0;
+    T A[SL * COLS];   // own rows of the panel [[RBar bBar], [L Htilde, L y]]; the top part first holds the own rows of R
+    T xprev[NS];
+    T pc[NS * HS];    // Phi, this half's columns: pc[r * HS + cs] = Phi[r][2 cs + l]; factorised in place
+    // ---- every operand is requested up front: ONE exposed memory latency per wave (the partner wave on the SIMD computes
+    // meanwhile).  ~230 values in flight; the measurement operands (99) stay in registers until the factors of Phi have gone
+    // to LDS, which is what the 256-register budget allows (whitening first would need 39 more accumulators on top).
+    T Hc[NM * HS], Lw[tri(NM)], yv[NM];   // Htilde, this half's columns: Hc[m * HS + cs] = Htilde[m][2 cs + l]
+    [[maybe_unused]] T yreal[NM], yown[HM];
+#pragma unroll
+    for (int m = 0; m < NM; m++)
+#pragma unroll
+        for (int cs = 0; cs < HS; cs++)
+            Hc[m * HS + cs] = EXT ? ld_uniform_nt(eh + (int64_t)(m * NS + 2 * cs) * a.ext_ld, bphi)
+                                  : __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
+#pragma unroll
+    for (int e = 0; e < tri(NM); e++) Lw[e] = ld_mo(a.L.mo_LR + e);   // QUIRK srif.go:48: chol_L(R), not its inverse
+#pragma unroll
+    for (int r = 0; r < NM; r++) {
+        const T re = ld_uniform_nt(yr + (int64_t)r * a.y_es, bx);
+        const T co = ld_uniform_nt(yc + (int64_t)r * a.y2_es, bx);
+        yv[r] = re - co;   // srif.go:143-144
+        if constexpr (FULL) yreal[r] = re;
+    }
+    [[maybe_unused]] T bown[HS];   // b of the own rows
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) xprev[i] = ld_st(i);   // b, in both halves
+    } else {
+#pragma unroll
+        for (int s = 0; s < HS; s++) bown[s] = st[(unsigned)(2 * s * KB_TILE) + vl];
+    }
+    [[maybe_unused]] T Rw[DENSE ? NS * NS : 1];
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) Rw[e] = ld_st(NS + e);
+    } else {
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) A[s * COLS + j] = j >= 2 * s ? ld_row(NS + 2 * s * NS + j) : T(0);   // (2 s + 1, 2 s) is a stored zero
+#pragma unroll
+        for (int r = 0; r < NS; r++)
+#pragma unroll
+            for (int cs = 0; cs < HS; cs++) pc[r * HS + cs] = ld_phic(r * NS + 2 * cs);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- State(prev) = R^-1 b (srif.go:223-234) -------------------------------------------------------------------
+    if constexpr (DENSE) {
+        if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;   // both halves, redundantly
+        asm volatile("" ::: "memory");   // (cold path) the own rows are read after the 144 registers of Rw are free
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) A[s * COLS + j] = ld_row(NS + 2 * s * NS + j);
+#pragma unroll
+        for (int r = 0; r < NS; r++)
+#pragma unroll
+            for (int cs = 0; cs < HS; cs++) pc[r * HS + cs] = ld_phic(r * NS + 2 * cs);
+    } else {
+        // back substitution: row i is in half i % 2; each component is handed to the other half as soon as it exists
+#pragma unroll
+        for (int i = NS - 1; i >= 0; i--) {
+            const int s = i / 2, own = i % 2;
+            T sum = bown[s];
+#pragma unroll
+            for (int k2 = i + 1; k2 < NS; k2++) sum -= A[s * COLS + k2] * xprev[k2];
+            const T d = A[s * COLS + i];
+            if (is_hi == (own == 1) && d == T(0)) err |= KB_ST_SINGULAR;
+            xprev[i] = from_half(sum * (T(1) / d), own);   // the other half computed the same expression on ITS row: discarded
+        }
+    }
+    // ---- xBar = Phi State(prev) (srif.go:118): each half sums over its columns ------------------------------------------
+    T xbar[NS];
+    {
+        T xs[HS];
+#pragma unroll
+        for (int cs = 0; cs < HS; cs++) xs[cs] = is_hi ? xprev[2 * cs + 1] : xprev[2 * cs];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T part = T(0);
+#pragma unroll
+            for (int cs = 0; cs < HS; cs++) part += pc[i * HS + cs] * xs[cs];
+            xbar[i] = allsum(part);
+        }
+    }
+    // ---- P Phi = L U (srif.go:111-114's Inverse = Dgetrf + ...), the columns split over the halves: the half that owns
+    // column j searches the pivot and forms the multipliers, the other half receives them (one exchange each) and both
+    // update their own columns.  nibble k of perm = original index of the row now in position k.
+    uint64_t perm = 0xBA9876543210ull;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const int cj = j / 2, oj = j % 2;
+        const bool owner = is_hi == (oj == 1);
+#pragma unroll
+        for (int r = j + 1; r < NS; r++) {
+            const bool sw = owner && fabs(pc[r * HS + cj]) > fabs(pc[j * HS + cj]);
+            if (__any(sw)) {   // wave-uniform and rare: the exchange code only runs when some lane pivots
+                const bool s2 = from_half(sw ? 1u : 0u, oj) != 0u;
+#pragma unroll
+                for (int cs = 0; cs < HS; cs++) {   // whole rows: the L part moves with its row (LAPACK dlaswp)
+                    const T t0 = pc[j * HS + cs], t1 = pc[r * HS + cs];
+                    pc[j * HS + cs] = s2 ? t1 : t0;
+                    pc[r * HS + cs] = s2 ? t0 : t1;
+                }
+                const uint64_t x = s2 ? (((perm >> (4 * j)) ^ (perm >> (4 * r))) & 15u) : 0u;
+                perm ^= (x << (4 * j)) | (x << (4 * r));
+            }
+        }
+        const T piv = pc[j * HS + cj];
+        if (owner && piv == T(0)) err |= KB_ST_SINGULAR;
+        const T rp = T(1) / piv;
+        const T ujc = pc[j * HS + cj];          // upper half, j even: U[j][j + 1], still needed below
+        if (owner) pc[j * HS + cj] = rp;        // the solves multiply by the reciprocal
+#pragma unroll
+        for (int r = j + 1; r < NS; r++) {
+            const T lf = from_half(pc[r * HS + cj] * rp, oj);   // the multiplier, in both halves
+            // slot cj: the owner keeps the multiplier (L); for an even j the upper half's column j + 1 is still active
+            if (oj == 0) pc[r * HS + cj] = is_hi ? pc[r * HS + cj] - lf * ujc : lf;
+            else pc[r * HS + cj] = is_hi ? lf : pc[r * HS + cj];
+#pragma unroll
+            for (int cs = cj + 1; cs < HS; cs++) pc[r * HS + cs] -= lf * pc[j * HS + cs];
+        }
+    }
+    const bool anyswap = __any(perm != 0xBA9876543210ull);
+    // the factors go to LDS, [element][32 filters]: element (r, 2 cs + l) from this lane; the solves below read every
+    // element from both halves (lanes f and 32 + f read the same word: a broadcast, no bank conflict)
+#pragma unroll
+    for (int r = 0; r < NS; r++)
+#pragma unroll
+        for (int cs = 0; cs < HS; cs++) lds_lu[(r * NS + 2 * cs) * 32 + lane] = pc[r * HS + cs];
+    {   // a failure in either half fails the filter
+        unsigned elo, ehi;
+        halves(err, elo, ehi);
+        err = elo | ehi;
+    }
+    const bool ok = inb && err == 0;   // failed: (b, R) stay as they are, srif.go:111-114 returns before any assignment
+    if (err && inb && !is_hi) atomicOr(a.status + fi, err);
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- whitened measurement rows (srif.go:146-148): [L Htilde | L y].  Each half forms ALL rows of L Htilde for ITS
+    // columns (Htilde is held column-split like Phi: half the registers, half the loads), then one exchange per pair of
+    // values turns columns-of-all-rows into all-columns-of-the-own-rows.
+#pragma unroll
+    for (int t = 0; t < HM; t++) {
+#pragma unroll
+        for (int cs = 0; cs < HS; cs++) {
+            T w0 = T(0), w1 = T(0);   // rows 2 t and 2 t + 1, column 2 cs + l
+#pragma unroll
+            for (int m = 0; m <= 2 * t; m++) w0 += Lw[symi(m, 2 * t)] * Hc[m * HS + cs];
+#pragma unroll
+            for (int m = 0; m <= 2 * t + 1; m++) w1 += Lw[symi(m, 2 * t + 1)] * Hc[m * HS + cs];
+            cross(w0, w1);   // lower half: row 2 t, columns 2 cs and 2 cs + 1; upper half: row 2 t + 1, the same columns
+            A[(HS + t) * COLS + 2 * cs] = w0;
+            A[(HS + t) * COLS + 2 * cs + 1] = w1;
+        }
+        T s0 = T(0), s1 = T(0);
+#pragma unroll
+        for (int m = 0; m <= 2 * t; m++) s0 += Lw[symi(m, 2 * t)] * yv[m];
+#pragma unroll
+        for (int m = 0; m <= 2 * t + 1; m++) s1 += Lw[symi(m, 2 * t + 1)] * yv[m];
+        A[(HS + t) * COLS + NS] = is_hi ? s1 : s0;
+        if constexpr (FULL) yown[t] = is_hi ? yreal[2 * t + 1] : yreal[2 * t];
+    }
+
+    __builtin_amdgcn_sched_barrier(0);   // the measurement operands are dead from here on
+    // ---- RBar = R Phi^-1 (srif.go:115) for the own rows: z Phi = R[i,:], i.e. w U = r, v L = w, z[perm_k] = v_k --------
+    // A[s][0..NS) is z for row 2 s + l; columns < 2 s are structural zeros (skipped) unless DENSE
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+#pragma unroll
+        for (int k2 = 0; k2 < j; k2++) {
+            const T ukj = lds_lu[(k2 * NS + j) * 32 + vf];
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+                if (DENSE || 2 * s <= k2) A[s * COLS + j] -= A[s * COLS + k2] * ukj;
+        }
+        const T rjj = lds_lu[(j * NS + j) * 32 + vf];
+#pragma unroll
+        for (int s = 0; s < HS; s++)
+            if (DENSE || 2 * s <= j) A[s * COLS + j] *= rjj;
+    }
+#pragma unroll
+    for (int j = NS - 2; j >= 0; j--) {
+#pragma unroll
+        for (int k2 = j + 1; k2 < NS; k2++) {
+            const T lkj = lds_lu[(k2 * NS + j) * 32 + vf];
+#pragma unroll
+            for (int s = 0; s < HS; s++) A[s * COLS + j] -= A[s * COLS + k2] * lkj;
+        }
+    }
+    // bBar = RBar xBar (srif.go:119), same products in pivoted order; then the row permutation is undone
+    if (anyswap) {   // cold: some lane pivoted.  Register arrays cannot be indexed per lane: select chains
+        T xp[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            const int pr = pnib(perm, r);
+            T v = T(0);
+#pragma unroll
+            for (int c = 0; c < NS; c++) v = pr == c ? xbar[c] : v;
+            xp[r] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < HS; s++) {
+            T bb = T(0);
+#pragma unroll
+            for (int r = 0; r < NS; r++) bb += A[s * COLS + r] * xp[r];
+            T row[NS];
+#pragma unroll
+            for (int c = 0; c < NS; c++) {
+                T v = T(0);
+#pragma unroll
+                for (int r = 0; r < NS; r++) v = pnib(perm, r) == c ? A[s * COLS + r] : v;
+                row[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < NS; c++) A[s * COLS + c] = row[c];
+            A[s * COLS + NS] = bb;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < HS; s++) {
+            T bb = T(0);
+#pragma unroll
+            for (int r = 0; r < NS; r++) bb += A[s * COLS + r] * xbar[r];
+            A[s * COLS + NS] = bb;
+        }
+    }
+    if constexpr (FULL) {
+        if (ok) {
+#pragma unroll
+            for (int s = 0; s < HS; s++)
+#pragma unroll
+                for (int j = 0; j < NS; j++) es[(unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow] = A[s * COLS + j];
+#pragma unroll
+            for (int t = 0; t < HM; t++) {
+                es[(unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl] = yown[t];
+                es[(unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl] = A[(HS + t) * COLS + NS];
+            }
+        }
+    }
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- HouseholderTransf (helper.go:142-172) with the rows split over the halves ----------------------------------
+    T chk = T(0);
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        const int sk = k / 2, lk = k % 2;
+        // u_i = A[i][k] for the rows i >= k; in slot sk that is both halves when k is even, only the upper half when odd
+        const T ask = A[sk * COLS + k];
+        T part = lk == 0 ? ask * ask : (is_hi ? ask * ask : T(0));
+#pragma unroll
+        for (int s = sk + 1; s < SL; s++) part += A[s * COLS + k] * A[s * COLS + k];
+        T sigma = allsum(part);
+        const T akk = from_half(ask, lk);
+        const T sgn = (akk == T(0) || fabs(akk) <= T(1e-12)) ? T(1) : copysign(T(1), akk);   // helper.go:133-138 Sign
+        sigma = sqrt(sigma) * sgn;
+        const T uk = akk + sigma;
+        const T beta = T(1) / (sigma * uk);
+        const T usk = lk == 0 ? (is_hi ? ask : uk) : (is_hi ? uk : T(0));   // u of this lane's row in slot sk
+#pragma unroll
+        for (int j = k + 1; j < COLS; j++) {
+            T pj = usk * A[sk * COLS + j];
+#pragma unroll
+            for (int s = sk + 1; s < SL; s++) pj += A[s * COLS + k] * A[s * COLS + j];
+            const T gamma = allsum(pj) * beta;
+            A[sk * COLS + j] -= gamma * usk;
+#pragma unroll
+            for (int s = sk + 1; s < SL; s++) A[s * COLS + j] -= gamma * A[s * COLS + k];
+        }
+        A[sk * COLS + k] = lk == 0 ? (is_hi ? T(0) : -sigma) : (is_hi ? -sigma : ask);
+        // row k is final: it leaves the register file from the half that owns it
+#pragma unroll
+        for (int j = k; j < COLS; j++) chk += A[sk * COLS + j] * T(0);
+        if (ok && is_hi == (lk == 1)) {
+            st[(unsigned)(k * KB_TILE) + vf] = A[sk * COLS + NS];
+#pragma unroll
+            for (int j = k; j < NS; j++) st[(unsigned)((NS + 2 * sk * NS + j) * KB_TILE) + vrow] = A[sk * COLS + j];
+        }
+    }
+    if constexpr (FULL) {
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < HM; t++) es[(unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl] = A[(HS + t) * COLS + NS];
+        }
+    }
+    if constexpr (DENSE) {
+        if (ok) {   // srif.go:334-337 zeroes the sub-columns; R was dense in memory
+#pragma unroll
+            for (int s = 0; s < HS; s++) {
+#pragma unroll
+                for (int j = 0; j < 2 * s; j++) st[(unsigned)((NS + 2 * s * NS + j) * KB_TILE) + vrow] = T(0);
+                if (is_hi) st[(unsigned)((NS + 2 * s * NS + 2 * s) * KB_TILE) + vrow] = T(0);
+            }
+        }
+    }
+    // a non-finite result is stored as it is (helper.go:142-172 has no guard) and flagged
+    if (ok && chk != chk) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
+}
+
+template <typename T, int NS>
+constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 * 2 <= 160 * 1024 ? 2 : 1; }
+
+template <typename T, int NS, int NM, bool FULL, bool EXT>
+__global__ void __launch_bounds__(256, (srif_pair_waves_per_simd<T, NS>())) srif_pair_kernel(const StepArgs a) {
+    __shared__ T lds[4 * NS * NS * 32];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: all bases become scalar
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t tile = gw >> 1;
+    const int half = (int)(gw & 1);
+    const int64_t first = tile * KB_TILE + half * 32;
+    if (first >= a.N) return;
+    const int64_t fi = first + (lane & 31);
+    // a non-zero status word: that filter may hold a dense R (it skipped the Update after a Predict()), see kb_srif_reg.hip
+    const bool flagged = fi < a.N && (a.status[fi] & ~KB_ST_SKIP_STEP) != 0u;
+    T *lds_lu = lds + wv * (NS * NS * 32);
+    if (!a.srif_tri || __any(flagged)) srif_pair_tile<T, NS, NM, FULL, EXT, true>(a, tile, half, lane, lds_lu);
+    else srif_pair_tile<T, NS, NM, FULL, EXT, false>(a, tile, half, lane, lds_lu);
+}
+
+template <typename T, int NS, int NM>
+static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
+    if (a.n != NS || a.p != NM || a.predict) return false;
+    if (a.ext_phi && a.ext_ld >= (int64_t(1) << 28)) return false;   // the upper half's Phi offset (+ ld elements) is a 32-bit byte offset
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
+    const dim3 grid((unsigned)((2 * a.ntiles + 3) / 4)), block(256);
+#define KB_P(F_, E_) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
+    if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
+    else      { if (ext) KB_P(false, true); else KB_P(false, false); }
+#undef KB_P
+    return true;
+}
+
+}  // namespace kb

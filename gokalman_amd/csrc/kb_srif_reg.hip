@@ -18,6 +18,8 @@
 // flagged KB_ST_NONFINITE.
 // Algorithmic bytes per filter-step: b 12 + R 144 + Phi 144 + Htilde 72 +
 // L 36 + real 6 + computed 6 read, b 12 + R 144 written = 576 elements = 2304 B in fp32.
+#include <cstdlib>
+
 #include "kb_internal.h"
 #include "kb_static.h"
 
@@ -643,6 +645,13 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
 
 int launch_srif(const Batch &b, const StepArgs &a) {
     bool done = false;
+    // Update(): the two-lanes-per-filter kernel (kb_srif_pair.h); Predict() and KB_SRIF_ONE_LANE=1 (comparison runs): the
+    // one-filter-per-lane kernels of this file
+    static const bool one_lane = getenv("KB_SRIF_ONE_LANE") != nullptr;
+    if (!a.predict && !one_lane) {
+        done = b.dtype == KB_F32 ? launch_srif_pair_f32(b, a) : launch_srif_pair_f64(b, a);
+        if (done) { KB_HIP(hipGetLastError()); return KB_OK; }
+    }
     if (b.dtype == KB_F32) done = srif_try<float, 12, 6>(b, a) || srif_try<float, 6, 2>(b, a);
     else done = srif_try<double, 6, 2>(b, a) || srif_try<double, 12, 6>(b, a);
     if (!done) return launch_srif_gen(b, a);
