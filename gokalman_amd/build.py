@@ -33,7 +33,10 @@ def _deps_mtime():
 
 # per-file extra flags: the SLP vectoriser packs fp32 pairs in the fully unrolled SRIF panels and
 # lengthens live ranges (more AGPR / scratch spills); it buys nothing there
-EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": ["-fno-slp-vectorize"]}
+# the two-lanes-per-filter SRIF kernel is ~10k instructions of straight-line code per variant: past LLVM's default budget for
+# `#pragma unroll` (16k cost units) a loop silently stays rolled, its register arrays become scratch arrays
+_PAIR = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]
+EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR}
 
 
 def _compile(src, force):

@@ -30,18 +30,28 @@ __device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontempo
 template <typename T>
 __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
-// A read-once global load at (wave-uniform pointer) + (32-bit per-lane BYTE offset), in the scalar-base form of global_load
+// Read-once global loads at (wave-uniform pointer) + (32-bit per-lane BYTE offset), in the scalar-base form of global_load
 // (`global_load_dword v, v_off, s[base:base+1]`): no 64-bit vector address arithmetic and no address register pair per
-// access.  The pointer goes through readfirstlane so that the compiler keeps it in SGPRs instead of folding the lane
-// offset into it, and keeps its global address space (a flat load has no such form).
+// access.  UniformCursor keeps the pointer in SGPRs (it goes through readfirstlane, so the compiler neither folds the lane
+// offset into it nor re-derives every address with a 64-bit multiply: advancing costs two scalar adds) and in the global
+// address space (a flat load has no scalar-base form).
 template <typename T>
-__device__ __forceinline__ T ld_uniform_nt(const T *uniform_ptr, unsigned lane_bytes) {
-    typedef const __attribute__((address_space(1))) T *gptr;
-    typedef const __attribute__((address_space(1))) char *gbytes;
-    const unsigned long long v = (unsigned long long)uniform_ptr;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_nontemporal_load((gptr)((gbytes)(((unsigned long long)hi << 32) | lo) + lane_bytes));
-}
+struct UniformCursor {
+    unsigned lo, hi;
+    __device__ __forceinline__ explicit UniformCursor(const T *uniform_ptr) { set((unsigned long long)uniform_ptr); }
+    __device__ __forceinline__ void set(unsigned long long v) {
+        lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    }
+    __device__ __forceinline__ void advance(long long elements) { set((((unsigned long long)hi << 32) | lo) + (unsigned long long)(elements * (long long)sizeof(T))); }
+    __device__ __forceinline__ T load_nt(unsigned lane_bytes) const {
+        typedef const __attribute__((address_space(1))) T *gptr;
+        typedef const __attribute__((address_space(1))) char *gbytes;
+        return __builtin_nontemporal_load((gptr)((gbytes)(((unsigned long long)hi << 32) | lo) + lane_bytes));
+    }
+};
+template <typename T>
+__device__ __forceinline__ T ld_uniform_nt(const T *uniform_ptr, unsigned lane_bytes) { return UniformCursor<T>(uniform_ptr).load_nt(lane_bytes); }
 
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };

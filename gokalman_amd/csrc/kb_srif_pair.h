@@ -115,35 +115,47 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     // arrays have a run-time element stride, so their addresses are formed as (scalar pointer) + (32-bit lane byte offset)
     const unsigned vphi = EXT ? vx + (is_hi ? (unsigned)a.ext_ld : 0u) : vl;
     const unsigned bx = vx * (unsigned)sizeof(T), bphi = vphi * (unsigned)sizeof(T);
-    auto ld_phic = [&](int e) {
-        return EXT ? ld_uniform_nt(ephi + (int64_t)e * a.ext_ld, bphi)
-                   : __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_F + e) * KB_TILE) + vphi));
-    };
-    auto ld_h = [&](int e) { return EXT ? ld_uniform_nt(eh + (int64_t)e * a.ext_ld, bx) : ld_mo(a.L.mo_H + e); };
 
     unsigned err = 0;
     T A[SL * COLS];   // own rows of the panel [[RBar bBar], [L Htilde, L y]]; the top part first holds the own rows of R
     T xprev[NS];
     T pc[NS * HS];    // Phi, this half's columns: pc[r * HS + cs] = Phi[r][2 cs + l]; factorised in place
+    auto load_phi = [&]() {
+        UniformCursor<T> cur(EXT ? ephi : mo);   // walks Phi two elements at a time
+#pragma unroll
+        for (int r = 0; r < NS; r++)
+#pragma unroll
+            for (int cs = 0; cs < HS; cs++) {
+                if constexpr (EXT) { pc[r * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
+                else pc[r * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_F + r * NS + 2 * cs) * KB_TILE) + vphi));
+            }
+    };
     // ---- every operand is requested up front: ONE exposed memory latency per wave (the partner wave on the SIMD computes
     // meanwhile).  ~230 values in flight; the measurement operands (99) stay in registers until the factors of Phi have gone
     // to LDS, which is what the 256-register budget allows (whitening first would need 39 more accumulators on top).
     T Hc[NM * HS], Lw[tri(NM)], yv[NM];   // Htilde, this half's columns: Hc[m * HS + cs] = Htilde[m][2 cs + l]
     [[maybe_unused]] T yreal[NM], yown[HM];
+    {
+        UniformCursor<T> cur(EXT ? eh : mo);   // walks Htilde two elements at a time
 #pragma unroll
-    for (int m = 0; m < NM; m++)
+        for (int m = 0; m < NM; m++)
 #pragma unroll
-        for (int cs = 0; cs < HS; cs++)
-            Hc[m * HS + cs] = EXT ? ld_uniform_nt(eh + (int64_t)(m * NS + 2 * cs) * a.ext_ld, bphi)
-                                  : __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
+            for (int cs = 0; cs < HS; cs++) {
+                if constexpr (EXT) { Hc[m * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
+                else Hc[m * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
+            }
+    }
 #pragma unroll
     for (int e = 0; e < tri(NM); e++) Lw[e] = ld_mo(a.L.mo_LR + e);   // QUIRK srif.go:48: chol_L(R), not its inverse
+    {
+        UniformCursor<T> cr(yr), cc(yc);
 #pragma unroll
-    for (int r = 0; r < NM; r++) {
-        const T re = ld_uniform_nt(yr + (int64_t)r * a.y_es, bx);
-        const T co = ld_uniform_nt(yc + (int64_t)r * a.y2_es, bx);
-        yv[r] = re - co;   // srif.go:143-144
-        if constexpr (FULL) yreal[r] = re;
+        for (int r = 0; r < NM; r++) {
+            const T re = cr.load_nt(bx), co = cc.load_nt(bx);
+            cr.advance(a.y_es); cc.advance(a.y2_es);
+            yv[r] = re - co;   // srif.go:143-144
+            if constexpr (FULL) yreal[r] = re;
+        }
     }
     [[maybe_unused]] T bown[HS];   // b of the own rows
     if constexpr (DENSE) {
@@ -162,10 +174,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         for (int s = 0; s < HS; s++)
 #pragma unroll
             for (int j = 0; j < NS; j++) A[s * COLS + j] = j >= 2 * s ? ld_row(NS + 2 * s * NS + j) : T(0);   // (2 s + 1, 2 s) is a stored zero
-#pragma unroll
-        for (int r = 0; r < NS; r++)
-#pragma unroll
-            for (int cs = 0; cs < HS; cs++) pc[r * HS + cs] = ld_phic(r * NS + 2 * cs);
+        load_phi();
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- State(prev) = R^-1 b (srif.go:223-234) -------------------------------------------------------------------
@@ -176,10 +185,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         for (int s = 0; s < HS; s++)
 #pragma unroll
             for (int j = 0; j < NS; j++) A[s * COLS + j] = ld_row(NS + 2 * s * NS + j);
-#pragma unroll
-        for (int r = 0; r < NS; r++)
-#pragma unroll
-            for (int cs = 0; cs < HS; cs++) pc[r * HS + cs] = ld_phic(r * NS + 2 * cs);
+        load_phi();
     } else {
         // back substitution: row i is in half i % 2; each component is handed to the other half as soon as it exists
 #pragma unroll
@@ -215,10 +221,13 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     for (int j = 0; j < NS; j++) {
         const int cj = j / 2, oj = j % 2;
         const bool owner = is_hi == (oj == 1);
+        bool need = false;   // some row below has a larger entry in column j: the bubble below would exchange at least once
 #pragma unroll
-        for (int r = j + 1; r < NS; r++) {
-            const bool sw = owner && fabs(pc[r * HS + cj]) > fabs(pc[j * HS + cj]);
-            if (__any(sw)) {   // wave-uniform and rare: the exchange code only runs when some lane pivots
+        for (int r = j + 1; r < NS; r++) need = need || fabs(pc[r * HS + cj]) > fabs(pc[j * HS + cj]);
+        if (__any(owner && need)) {   // wave-uniform and rare (one test per column): the exchange code only runs when some lane pivots
+#pragma unroll
+            for (int r = j + 1; r < NS; r++) {
+                const bool sw = owner && fabs(pc[r * HS + cj]) > fabs(pc[j * HS + cj]);
                 const bool s2 = from_half(sw ? 1u : 0u, oj) != 0u;
 #pragma unroll
                 for (int cs = 0; cs < HS; cs++) {   // whole rows: the L part moves with its row (LAPACK dlaswp)
@@ -381,15 +390,39 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         const T uk = akk + sigma;
         const T beta = T(1) / (sigma * uk);
         const T usk = lk == 0 ? (is_hi ? ask : uk) : (is_hi ? uk : T(0));   // u of this lane's row in slot sk
+        // two columns per exchange: cross() leaves (column j total | column j + 1 total) in the (lower | upper) half after
+        // one add, a second swap hands both totals to both halves -- 4 instructions for 2 columns; same sums as allsum()
 #pragma unroll
-        for (int j = k + 1; j < COLS; j++) {
-            T pj = usk * A[sk * COLS + j];
+        for (int j = 1; j < COLS; j++) {   // constant trip count (the compiler unrolls inner loops first): j = k + 1, k + 3, ... do the work
+            if (j <= k || ((j - k - 1) & 1) != 0) continue;
+            if (j + 1 < COLS) {
+                T p0 = usk * A[sk * COLS + j], p1 = usk * A[sk * COLS + j + 1];
 #pragma unroll
-            for (int s = sk + 1; s < SL; s++) pj += A[s * COLS + k] * A[s * COLS + j];
-            const T gamma = allsum(pj) * beta;
-            A[sk * COLS + j] -= gamma * usk;
+                for (int s = sk + 1; s < SL; s++) {
+                    p0 += A[s * COLS + k] * A[s * COLS + j];
+                    p1 += A[s * COLS + k] * A[s * COLS + j + 1];
+                }
+                T g0, g1;
+                cross(p0, p1);
+                halves(p0 + p1, g0, g1);
+                g0 *= beta;
+                g1 *= beta;
+                A[sk * COLS + j] -= g0 * usk;
+                A[sk * COLS + j + 1] -= g1 * usk;
 #pragma unroll
-            for (int s = sk + 1; s < SL; s++) A[s * COLS + j] -= gamma * A[s * COLS + k];
+                for (int s = sk + 1; s < SL; s++) {
+                    A[s * COLS + j] -= g0 * A[s * COLS + k];
+                    A[s * COLS + j + 1] -= g1 * A[s * COLS + k];
+                }
+            } else {
+                T pj = usk * A[sk * COLS + j];
+#pragma unroll
+                for (int s = sk + 1; s < SL; s++) pj += A[s * COLS + k] * A[s * COLS + j];
+                const T gamma = allsum(pj) * beta;
+                A[sk * COLS + j] -= gamma * usk;
+#pragma unroll
+                for (int s = sk + 1; s < SL; s++) A[s * COLS + j] -= gamma * A[s * COLS + k];
+            }
         }
         A[sk * COLS + k] = lk == 0 ? (is_hi ? T(0) : -sigma) : (is_hi ? -sigma : ask);
         // row k is final: it leaves the register file from the half that owns it
