@@ -28,6 +28,8 @@
 // dot products that span both halves are summed as (even rows) + (odd rows), a rounding-level reordering.
 // Failure semantics as everywhere (kb_srif_reg.hip header): a singular Phi / R skips this step for that filter only.
 #pragma once
+#include <cstdlib>
+
 #include "kb_internal.h"
 #include "kb_static.h"
 
@@ -200,16 +202,23 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             for (int j = 0; j < NS; j++) A[s * COLS + j] = ld_row(NS + 2 * s * NS + j);
         load_phi();
     } else {
-        // back substitution: row i is in half i % 2; each component is handed to the other half as soon as it exists
+        // back substitution, column-oriented: as soon as x_i exists (in the half that owns row i) it is handed to the other
+        // half and every remaining own row subtracts its R[r][i] x_i -- the critical path per component is one multiply, one
+        // exchange and one FMA; the reciprocals of the diagonal are formed up front, off that path
+        T rinv[HS], acc[HS];
+#pragma unroll
+        for (int s = 0; s < HS; s++) {
+            const T d = is_hi ? A[s * COLS + 2 * s + 1] : A[s * COLS + 2 * s];   // R[2 s + l][2 s + l]
+            if (d == T(0)) err |= KB_ST_SINGULAR;
+            rinv[s] = recip(d);
+            acc[s] = bown[s];
+        }
 #pragma unroll
         for (int i = NS - 1; i >= 0; i--) {
-            const int s = i / 2, own = i % 2;
-            T sum = bown[s];
+            const int si = i / 2, own = i % 2;
+            xprev[i] = from_half(acc[si] * rinv[si], own);   // the other half's product (its row 2 si + 1 - own) is discarded
 #pragma unroll
-            for (int k2 = i + 1; k2 < NS; k2++) sum -= A[s * COLS + k2] * xprev[k2];
-            const T d = A[s * COLS + i];
-            if (is_hi == (own == 1) && d == T(0)) err |= KB_ST_SINGULAR;
-            xprev[i] = from_half(sum * recip(d), own);   // the other half computed the same expression on ITS row: discarded
+            for (int s = 0; s <= si; s++) acc[s] -= A[s * COLS + i] * xprev[i];   // rows 2 s + l < i; the structural zeros contribute 0
         }
     }
     // ---- xBar = Phi State(prev) (srif.go:118): each half sums over its columns ------------------------------------------
@@ -393,10 +402,13 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         const int sk = k / 2, lk = k % 2;
         // u_i = A[i][k] for the rows i >= k; in slot sk that is both halves when k is even, only the upper half when odd
         const T ask = A[sk * COLS + k];
-        T part = lk == 0 ? ask * ask : (is_hi ? ask * ask : T(0));
+        T part = lk == 0 ? ask * ask : (is_hi ? ask * ask : T(0)), part2 = T(0);   // two chains: the sum is on the critical path of the step
 #pragma unroll
-        for (int s = sk + 1; s < SL; s++) part += A[s * COLS + k] * A[s * COLS + k];
-        T sigma = allsum(part);
+        for (int s = sk + 1; s < SL; s++) {
+            if ((s - sk) & 1) part2 += A[s * COLS + k] * A[s * COLS + k];
+            else part += A[s * COLS + k] * A[s * COLS + k];
+        }
+        T sigma = allsum(part + part2);
         const T akk = from_half(ask, lk);
         const T sgn = (akk == T(0) || fabs(akk) <= T(1e-12)) ? T(1) : copysign(T(1), akk);   // helper.go:133-138 Sign
         sigma = sqrt(sigma) * sgn;
@@ -409,12 +421,14 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         for (int j = 1; j < COLS; j++) {   // constant trip count (the compiler unrolls inner loops first): j = k + 1, k + 3, ... do the work
             if (j <= k || ((j - k - 1) & 1) != 0) continue;
             if (j + 1 < COLS) {
-                T p0 = usk * A[sk * COLS + j], p1 = usk * A[sk * COLS + j + 1];
+                T p0 = T(0), p1 = T(0);   // the rows below first: they do not wait for sigma
 #pragma unroll
                 for (int s = sk + 1; s < SL; s++) {
                     p0 += A[s * COLS + k] * A[s * COLS + j];
                     p1 += A[s * COLS + k] * A[s * COLS + j + 1];
                 }
+                p0 += usk * A[sk * COLS + j];
+                p1 += usk * A[sk * COLS + j + 1];
                 T g0, g1;
                 cross(p0, p1);
                 halves(p0 + p1, g0, g1);
@@ -428,9 +442,10 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
                     A[s * COLS + j + 1] -= g1 * A[s * COLS + k];
                 }
             } else {
-                T pj = usk * A[sk * COLS + j];
+                T pj = T(0);
 #pragma unroll
                 for (int s = sk + 1; s < SL; s++) pj += A[s * COLS + k] * A[s * COLS + j];
+                pj += usk * A[sk * COLS + j];
                 const T gamma = allsum(pj) * beta;
                 A[sk * COLS + j] -= gamma * usk;
 #pragma unroll
@@ -494,7 +509,8 @@ static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
     if (a.ext_phi && a.ext_ld >= (int64_t(1) << 28)) return false;   // the upper half's Phi offset (+ ld elements) is a 32-bit byte offset
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
     const dim3 grid((unsigned)((2 * a.ntiles + 3) / 4)), block(256);
-#define KB_P(F_, E_) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
+    static const unsigned pad = getenv("KB_SRIF_PAIR_LDS_PAD") ? (unsigned)atoi(getenv("KB_SRIF_PAIR_LDS_PAD")) : 0u;   // occupancy experiments only
+#define KB_P(F_, E_) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, pad, b.stream, a)
     if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
     else      { if (ext) KB_P(false, true); else KB_P(false, false); }
 #undef KB_P
