@@ -56,6 +56,8 @@ def moved_bytes(kind, n, p, w=8):
         return w * (n + t + n * n + p * n + tp + 2 * p + n + t)
     if kind == "srif":          # b, R upper, Phi, Htilde, chol R, real, computed -> b, R upper (fused Update)
         return w * (n + t + n * n + p * n + tp + 2 * p + n + t)
+    if kind == "srif_pair":     # two-lanes-per-filter Update: as "srif" plus the n / 2 stored zeros R[2 s + 1][2 s] the upper half reads with its rows
+        return w * (n + t + n // 2 + n * n + p * n + tp + 2 * p + n + t)
     if kind == "srif_split":    # time kernel: b, R, Phi -> b, Rbar (full); meas kernel: b, Rbar, Htilde, L, y -> b, R upper... written full
         return w * ((n + n * n + n * n + n + n * n) + (n + n * n + p * n + tp + 2 * p + n + n * n))
     raise KeyError(kind)

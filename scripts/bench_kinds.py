@@ -11,6 +11,7 @@ import torch
 sys.path.insert(0, ".")
 import gokalman_amd as ga
 from gokalman_amd import _capi as k, synth
+from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 which = args or ["vfull", "sqrt", "info", "srif", "hybrid", "mc"]
@@ -34,16 +35,14 @@ def timed(b, fn, K=20, warm=3):
     return e0.elapsed_time(e1) / K
 
 
-def report(name, N, ms, bytes_per, extra=None, dtype="f64"):
+def report(name, N, ms, bytes_per, extra=None, dtype="f64", moved=None):
     """One JSON line per config, with the keys of bench.py's contract line (value = filter-update steps/s with the inputs
-    resident in HBM; roofline.achieved = BASELINE.md section 4's algorithmic bytes x filters / kernel time)."""
-    gbps = N * bytes_per / (ms * 1e-3) / 1e9
+    resident in HBM).  roofline.frac is PHYSICAL: bytes the kernel moves (packed working set, gokalman_amd/roofline.py) /
+    kernel time / 8 TB/s; the SURVEY 8d full-matrix figure is roofline.frac_algorithmic."""
     out = {"config": name, "filters": N, "ms_per_step": ms, "steps_per_s": N / (ms * 1e-3),
-           "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0,
            "metric": "filter-update steps/s", "value": N / (ms * 1e-3), "unit": "filter-update steps/s", "n_gpus": 1,
            "higher_is_better": True, "dtype": dtype, "data": "synthetic",
-           "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
-                        "algorithmic_bytes_per_launch": N * bytes_per}}
+           "roofline": rl.hbm_roofline(ms, N, bytes_per, moved if moved is not None else bytes_per)}
     if extra:
         out.update(extra)
     print(json.dumps(out), flush=True)
@@ -55,18 +54,19 @@ if "vfull" in which:
     y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
     b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
     ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
-    report("B': Vanilla 6/3 f64, FULL_ESTIMATE (also writes P-, K, innovation, yhat: +480 B)", N, ms, 1488 + 480, {"errors": int(np.count_nonzero(b.status()))})
+    report("B': Vanilla 6/3 f64, FULL_ESTIMATE (also writes P-, K, innovation, yhat: +480 B)", N, ms, 1488 + 480, {"errors": int(np.count_nonzero(b.status()))},
+           moved=rl.moved_bytes("vanilla_full", 6, 3))
     del b
 
 if "sqrt" in which or "info" in which:
     N = Nopt or (1 << 20)
     d = synth.linear_batch(N, 6, 3, 1)
     y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
-    for name, kind, fl in (("C: SquareRoot 6/3 f64", k.SQUAREROOT, 0), ("Information 6/3 f64 (from state)", k.INFORMATION, k.FLAG_INFO_FROM_STATE)):
+    for name, kind, fl, mv in (("C: SquareRoot 6/3 f64", k.SQUAREROOT, 0, "squareroot"), ("Information 6/3 f64 (from state)", k.INFORMATION, k.FLAG_INFO_FROM_STATE, "information")):
         if ("sqrt" in which and kind == k.SQUAREROOT) or ("info" in which and kind == k.INFORMATION):
             b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=fl)
             ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
-            report(name, N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))})
+            report(name, N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes(mv, 6, 3))
             del b
 
 if "srif" in which:
@@ -88,7 +88,8 @@ if "srif" in which:
             k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
         ms = timed(b, step, K=10)
         # update only (model already resident): re-arm the lock without re-uploading
-        report(nm + " (prepare_dev + update_nl_dev)", N, ms, 576 * w, {"errors": int(np.count_nonzero(b.status()))}, dtype="f32" if dt == k.F32 else "f64")
+        report(nm + " (prepare_dev + update_nl_dev)", N, ms, 576 * w, {"errors": int(np.count_nonzero(b.status()))}, dtype="f32" if dt == k.F32 else "f64",
+               moved=rl.moved_bytes("srif_pair", n, p, w))
         del b
 
 if "hybrid" in which:
@@ -105,7 +106,7 @@ if "hybrid" in which:
         k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
         k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
     ms = timed(b, step, K=10)
-    report("D(ii): Hybrid EKF 6/2 f64 (prepare_dev + update_nl_dev)", N, ms, 1120, {"errors": int(np.count_nonzero(b.status()))})
+    report("D(ii): Hybrid EKF 6/2 f64 (prepare_dev + update_nl_dev)", N, ms, 1120, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("hybrid", 6, 2))
     del b
 
 if "mc" in which:
