@@ -95,7 +95,8 @@ def main():
                             "fetch_bytes_raw": e["mean"]["FETCH_SIZE"] * 1024.0, "write_bytes": w})
     # ---- SQ counters
     md.append("\n## SQ counters per launch (means; SQ_WAVE_CYCLES / WAIT / ACTIVE count quad-cycles summed over waves)\n")
-    md.append("| kernel | waves | VALU / wave | SALU / wave | wave quad-cycles / wave | active | issue-stalled | waiting | VGPR(+AGPR) | LDS B |\n|---|---|---|---|---|---|---|---|---|---|")
+    md.append("(register / LDS / scratch allocation per kernel: resource_usage.md, from the code objects' metadata)\n")
+    md.append("| kernel | waves | VALU / wave | SALU / wave | wave quad-cycles / wave | active | issue-stalled | waiting | LDS B / workgroup |\n|---|---|---|---|---|---|---|---|---|")
     valu = {}
     for key in ("bench_sq", "kinds_sq", "chisq_sq"):
         for kn, e in c["pmc"].get(key, {}).items():
@@ -104,9 +105,11 @@ def main():
                 continue
             wv = m["SQ_WAVES"]
             wc = m["SQ_WAVE_CYCLES"]
-            md.append("| `%s` | %.0f | %.0f | %.0f | %.0f | %.0f%% | %.0f%% | %.0f%% | %s(+%s) | %s |" % (
+            if "rocclr" in kn or "at::native" in kn:
+                continue
+            md.append("| `%s` | %.0f | %.0f | %.0f | %.0f | %.0f%% | %.0f%% | %.0f%% | %s |" % (
                 short(kn)[:90], wv, m["SQ_INSTS_VALU"] / wv, m["SQ_INSTS_SALU"] / wv, wc / wv, 100 * m["SQ_ACTIVE_INST_ANY"] / wc,
-                100 * m["SQ_WAIT_INST_ANY"] / wc, 100 * m["SQ_WAIT_ANY"] / wc, e["regs"].get("VGPR_Count"), e["regs"].get("Accum_VGPR_Count"), e["regs"].get("LDS_Block_Size")))
+                100 * m["SQ_WAIT_INST_ANY"] / wc, 100 * m["SQ_WAIT_ANY"] / wc, e["regs"].get("LDS_Block_Size")))
             valu[kn] = {"waves": wv, "valu_insts_per_wave": m["SQ_INSTS_VALU"] / wv}
     named = {}
     for kn, v in valu.items():
