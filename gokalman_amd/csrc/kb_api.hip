@@ -682,13 +682,6 @@ int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld) {
     return KB_ERR_UNSUPPORTED;
 }
 
-__global__ void status_fetch_kernel(uint32_t *status, int64_t first, int64_t count, uint32_t *out, int clear) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    const uint32_t v = clear ? atomicExch(status + first + k, 0u) : status[first + k];
-    out[k] = v & ~KB_ST_SKIP_STEP;
-}
-
 // One snapshot of the Estimate of filters [first, first+count): every requested member is unpacked into ONE staging
 // area (the pinned, device-mapped buffer when it fits: no copy at all) and handed over after ONE stream synchronisation.
 int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *v) {
@@ -720,17 +713,27 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
         if ((rc = ensure_stage(*b, total))) return rc;
         d_area = (char *)b->d_stage;
     }
-    // pred_covar of the lazy kinds re-uses the scratch block of state / covar: stream order keeps the two apart
-    for (int i = 0; i < 6; i++) {
-        if (!want[i].dst) continue;
-        OutputSource o;
-        if ((rc = resolve_output(b, want[i].field, o))) return rc;
-        if ((rc = launch_unpack(*b, o.block, o.block_elems, o.map, o.out_elems, (double *)(d_area + want[i].off), first, count))) return rc;
-    }
-    if (v->status) {
-        hipLaunchKernelGGL(status_fetch_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, b->stream, b->d_status, first, count,
-                           (uint32_t *)(d_area + st_off), v->clear_status ? 1 : 0);
-        KB_HIP(hipGetLastError());
+    // One launch for every member that can be read in place; a lazy getter's member (SquareRoot / Information / SRIF covariance,
+    // Information / SRIF state) first gets its materialise kernel, and pred_covar of those kinds -- which re-uses the scratch
+    // block of state / covar -- goes into a second snapshot launch, stream-ordered behind the first.
+    const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS);
+    for (int pass = 0; pass < 2; pass++) {
+        SnapArgs sa;
+        sa.nmembers = 0;
+        for (int i = 0; i < 6; i++) {
+            if (!want[i].dst) continue;
+            const bool second = lazy && want[i].field == KB_PRED_COVAR;
+            if (second != (pass == 1)) continue;
+            OutputSource o;
+            if ((rc = resolve_output(b, want[i].field, o))) return rc;
+            if (o.out_elems != elems[i]) { set_error("internal: member %d has %d elements, expected %d", want[i].field, o.out_elems, elems[i]); return KB_ERR_INVALID; }
+            const int m = sa.nmembers++;
+            sa.block[m] = o.block; sa.block_elems[m] = o.block_elems; sa.out_elems[m] = o.out_elems; sa.off[m] = (int64_t)want[i].off;
+            memcpy(sa.map[m], o.map, sizeof(sa.map[m]));
+        }
+        const bool with_status = v->status && pass == 0;
+        if (sa.nmembers == 0 && !with_status) continue;
+        if ((rc = launch_snapshot(*b, sa, first, count, d_area, with_status ? b->d_status : nullptr, (int64_t)st_off, v->clear_status ? 1 : 0))) return rc;
     }
     if (pinned) {
         KB_HIP(hipStreamSynchronize(b->stream));

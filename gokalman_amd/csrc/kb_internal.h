@@ -108,6 +108,14 @@ struct StepArgs {
 };
 
 // kb_pack.hip
+struct SnapArgs {   // kernel argument of the one-launch Estimate snapshot (kb_get_estimate): at most 6 members
+    const void *block[6];
+    int block_elems[6], out_elems[6];
+    int64_t off[6];
+    int16_t map[6][KB_MAX_DIM * KB_MAX_DIM];
+    int nmembers;
+};
+int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t count, void *area, uint32_t *status, int64_t status_off, int clear);
 int launch_pack(const Batch &b, const void *src_aos, int src_elems, int64_t count, bool broadcast,
                 void *dst_block, int dst_elems, const int16_t *map /* [src_elems] -> dst elem or -1 */);
 int launch_unpack(const Batch &b, const void *src_block, int src_elems, const int16_t *map /* [dst_elems] -> src elem or -1 (0.0) */,

@@ -47,6 +47,40 @@ __global__ void unpack_planar_kernel(const T *__restrict__ src, int src_elems, i
     }
 }
 
+// Estimate snapshot (kb_get_estimate): up to six members and the status words of filters [first, first + count) in ONE launch.
+// dst members are AoS double [count][out_elems] at byte offsets of `area`; status is read (and cleared) atomically.
+// One workgroup (one wave) per filter, the lanes share the elements: for the one-filter batches of the drop-in path the
+// destination is pinned HOST memory written across PCIe, where 64 lanes storing neighbouring doubles make a few large
+// transactions instead of a hundred 8-byte ones.
+template <typename T>
+__global__ void __launch_bounds__(64) snapshot_kernel(SnapArgs sa, int64_t first, int64_t count, char *area, uint32_t *status, int64_t status_off, int clear) {
+    const int64_t k = blockIdx.x;
+    if (k >= count) return;
+    const int64_t i = first + k;
+    for (int m = 0; m < sa.nmembers; m++) {
+        const T *s = (const T *)sa.block[m] + (i / KB_TILE) * ((int64_t)KB_TILE * sa.block_elems[m]) + (i % KB_TILE);
+        double *d = (double *)(area + sa.off[m]) + k * sa.out_elems[m];
+        for (int e = threadIdx.x; e < sa.out_elems[m]; e += 64) {
+            const int se = sa.map[m][e];
+            d[e] = se >= 0 ? (double)s[(int64_t)se * KB_TILE] : 0.0;
+        }
+    }
+    if (status && threadIdx.x == 0) {
+        const uint32_t v = clear ? atomicExch(status + i, 0u) : status[i];
+        ((uint32_t *)(area + status_off))[k] = v & ~KB_ST_SKIP_STEP;
+    }
+}
+
+int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t count, void *area, uint32_t *status, int64_t status_off, int clear) {
+    if (count <= 0) return KB_OK;
+    if (b.dtype == KB_F64)
+        hipLaunchKernelGGL(snapshot_kernel<double>, dim3((unsigned)count), dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear);
+    else
+        hipLaunchKernelGGL(snapshot_kernel<float>, dim3((unsigned)count), dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
 static MapArg make_map(const int16_t *map, int n) {
     MapArg m;
     for (int i = 0; i < KB_MAX_DIM * KB_MAX_DIM; i++) m.m[i] = i < n ? map[i] : (int16_t)-1;

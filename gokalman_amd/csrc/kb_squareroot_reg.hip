@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
             }
             D[r * DD + c] = val;
         }
+    // H x- for the innovation (:255-262) is formed here, so that H (18 doubles) is dead before the 9 x 9 factorisation
+    T Hxm[NM];
+    smv<T, NM, NS>(H, xm, Hxm);
     [[maybe_unused]] T yhat[NM];
     if constexpr (FULL) {
         smv<T, NM, NS>(H, x, yhat);  // :237-239 yhat = H x_prev
@@ -155,10 +158,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
 #pragma unroll
     for (int r = 0; r < NM; r++) {
         const T yv = (active && r < rp) ? __builtin_nontemporal_load(yp + (int64_t)r * a.y_es) : T(0);
-        T s = T(0);
-#pragma unroll
-        for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
-        innov[r] = yv - s;
+        innov[r] = yv - Hxm[r];
     }
     T chk = T(0);
 #pragma unroll
