@@ -94,6 +94,11 @@ __device__ __forceinline__ double recip(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
+// sqrt: fp32 takes the hardware instruction (1 ulp) in place of the correctly rounded sequence the compiler expands sqrtf()
+// into (15 instructions, once per Householder column); fp64 keeps the library expansion
+__device__ __forceinline__ float root(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double root(double x) { return sqrt(x); }
+
 __device__ __forceinline__ int pnib(uint64_t perm, int r) { return (int)((perm >> (4 * r)) & 15u); }
 
 // One half-tile (32 filters) of the SRIF Update.  DENSE: R may be a full matrix for some filter of this half-tile (the
@@ -411,7 +416,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         T sigma = allsum(part + part2);
         const T akk = from_half(ask, lk);
         const T sgn = (akk == T(0) || fabs(akk) <= T(1e-12)) ? T(1) : copysign(T(1), akk);   // helper.go:133-138 Sign
-        sigma = sqrt(sigma) * sgn;
+        sigma = root(sigma) * sgn;
         const T uk = akk + sigma;
         const T beta = recip(sigma * uk);
         const T usk = lk == 0 ? (is_hi ? ask : uk) : (is_hi ? uk : T(0));   // u of this lane's row in slot sk
