@@ -2,9 +2,10 @@
 
 * config E at size: 262 144 filters x 12/6 (fp32 and fp64), inputs from a seeded device generator, handed over zero-copy
   (kb_prepare_dev / kb_update_nl_dev).  Sampled filters (first tile, last tile, random tiles) are checked against the
-  oracle, and the WHOLE batch must be bit-equal to the same data run in 4096-filter chunks -- the fused kernel is a
-  persistent grid whose workgroups take >= 8 tiles each at this size (LDS double buffer + flag hand-over), a 4096-filter
-  batch gives every workgroup exactly one tile.
+  oracle, and the WHOLE batch must be bit-equal to the same data run in 4096-filter chunks: the result of a filter may not
+  depend on where in the grid (which workgroup, which wave, which LDS region, which round of waves) it was computed.  (The
+  round-1 one-filter-per-lane kernels, still reachable with KB_SRIF_ONE_LANE=1, are a persistent grid with an LDS double
+  buffer and a flag hand-over that only wraps around at this size.)
 * per-step failure semantics (srif.go:111-114 returns before anything is assigned): a filter whose Phi is singular at
   step k keeps its estimate for that step only, on every SRIF kernel path."""
 import numpy as np
@@ -34,8 +35,8 @@ def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
     x0 = rng.standard_normal((N, n))
     P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
     R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
-    # sequence: Update (fused kernel where it exists), Predict (time kernel, R no longer triangular), Update (time + meas
-    # kernels), Update (fused again)
+    # sequence: Update (two-lane kernel, triangular R), Predict (time kernel: R becomes the dense RBar), Update (the DENSE
+    # variant of the two-lane kernel), Update (steady state again)
     SEQ = ["update", "predict", "update", "update"]
     eye = torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1)
     Phi = [(eye + 1e-2 * torch.randn(n * n, N, dtype=tdt, device="cuda", generator=g)).contiguous() for _ in SEQ]
@@ -87,7 +88,7 @@ def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
     assert synth.rel_frobenius(bvec[idx], np.array(bs)) <= tol
 
 
-@pytest.mark.parametrize("fail_step", [1, 3])   # 1: steady state (fused kernel where the shape has one); 3: right after a Predict() (time + meas kernels)
+@pytest.mark.parametrize("fail_step", [1, 3])   # 1: steady state (triangular R); 3: right after a Predict() (dense R: the skipped filters keep it)
 @pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F32, 2e-3), (12, 6, k.F64, 1e-9), (6, 2, k.F64, 1e-9), (6, 2, k.F32, 2e-3), (5, 2, k.F64, 1e-9)])
 def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
     """(5, 2) has no register kernel: the generic one must behave the same."""
@@ -124,3 +125,44 @@ def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
         if t >= fail_step:   # the failing step itself (estimate untouched), then k+1, k+2 ... run normally
             assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in filters])) <= tol, t
             assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in filters])) <= tol, t
+
+
+@pytest.mark.parametrize("N", [1, 31, 33, 65])
+@pytest.mark.parametrize("dtype,tol", [(k.F32, 2e-3), (k.F64, 1e-9)])
+def test_srif_partial_half_tiles_zero_copy_and_full_estimate(N, dtype, tol):
+    """The two-lanes-per-filter kernel owns 32 filters per wave: batches that end inside a half-tile, models read in place from
+    planar arrays whose leading dimension exceeds N (kb_prepare_dev), every Estimate member written (FULL_ESTIMATE)."""
+    import torch
+    n, p, ld, steps = 12, 6, 200, 3
+    rng = np.random.default_rng(1000 + N)
+    tdt = torch.float32 if dtype == k.F32 else torch.float64
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    b = _srif_batch(N, n, p, dtype, x0, P0, R, flags=k.FLAG_FULL_ESTIMATE)
+    filters = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+    for t in range(steps):
+        Phi = np.eye(n) + 1e-2 * rng.standard_normal((N, n, n))
+        Ht = rng.standard_normal((N, p, n))
+        real = rng.standard_normal((N, p)); comp = real + 1e-2 * rng.standard_normal((N, p))
+        dPhi = torch.full((n * n, ld), float("nan"), dtype=tdt, device="cuda"); dPhi[:, :N] = torch.from_numpy(Phi.reshape(N, -1).T.copy()).to(tdt)
+        dH = torch.full((p * n, ld), float("nan"), dtype=tdt, device="cuda"); dH[:, :N] = torch.from_numpy(Ht.reshape(N, -1).T.copy()).to(tdt)
+        dre = torch.full((p, ld), float("nan"), dtype=tdt, device="cuda"); dre[:, :N] = torch.from_numpy(real.T.copy()).to(tdt)
+        dco = torch.full((p, ld), float("nan"), dtype=tdt, device="cuda"); dco[:, :N] = torch.from_numpy(comp.T.copy()).to(tdt)
+        k.check(k.lib().kb_prepare_dev(b._h, dPhi.data_ptr(), dH.data_ptr(), ld))
+        k.check(k.lib().kb_update_nl_dev(b._h, dre.data_ptr(), dco.data_ptr(), ld))
+        b.synchronize()
+        # the oracle sees what the device saw (fp32 inputs are rounded on the way in)
+        Phi_d = dPhi[:, :N].T.double().cpu().numpy().reshape(N, n, n); Ht_d = dH[:, :N].T.double().cpu().numpy().reshape(N, p, n)
+        re_d = dre[:, :N].T.double().cpu().numpy(); co_d = dco[:, :N].T.double().cpu().numpy()
+        for i, f in enumerate(filters):
+            f.prepare(Phi_d[i], Ht_d[i])
+            assert f.update_nl(re_d[i], co_d[i]) == orc.OK
+    est = b.estimate(snapshot=True)
+    assert not est.status().any()
+    assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in filters])) <= tol
+    assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in filters])) <= tol
+    assert synth.rel_frobenius(est.state(), np.array([f.state() for f in filters])) <= tol * 10
+    assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in filters])) <= tol * 10
+    assert synth.rel_frobenius(est.measurement(), np.array([f.measurement() for f in filters])) <= tol
+    assert np.isfinite(est.covariance()).all()
