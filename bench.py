@@ -42,9 +42,6 @@ sys.path.insert(0, ROOT)
 
 N_STATE, N_MEAS = 6, 3
 HEADLINE_KERNEL = "vanilla_reg_kernel<double, 6, 3, 0"
-# fp64 FMA-class VALU instructions per filter tile and step of vanilla_reg_kernel<..., FUSED> (static count of the
-# fully unrolled step body; scripts/resource_usage.py prints it, profiles/r02*/valu_counters.md confirms it with SQ_INSTS_VALU)
-FUSED_VALU_PER_STEP = None  # filled from profiles/valu_latest.json when present
 
 
 def parse_args(argv=None):
@@ -60,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")
     ap.add_argument("--mc-steps", type=int, default=1086)
     ap.add_argument("--hybrid-filters", type=int, default=1 << 20, help="Hybrid EKF filters per GPU for extra.hybrid_ekf (0 = skip)")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="initialise torch.distributed and run every collective even for ONE rank (exercises the RCCL code path on a single GPU)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, one GPU per rank) or gloo (testing the N>1 path with several ranks on one GPU)")
     return ap.parse_args(argv)
@@ -151,8 +150,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or args.init_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -165,12 +168,12 @@ def main():
     from gokalman_amd import synth
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(seconds):
-        if world == 1:
+        if not use_dist:
             return seconds, [seconds]
         t = torch.tensor([seconds], dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -212,7 +215,7 @@ def main():
 
     # ---- epilogue collective: what every rank did, summed over RCCL (the update path itself has no exchange) --------
     counts = torch.tensor([float(N) * args.steps, float(nbad), 1.0], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     total_filter_steps, total_bad, ranks_seen = float(counts[0].item()), int(counts[1].item()), int(counts[2].item())
 
@@ -287,15 +290,15 @@ def main():
         barrier()
         t0 = time.perf_counter()
         mc = ga.new_monte_carlo_runs(args.mc_runs * world, args.mc_steps, 2, np.zeros((1, 2)), kf, first_run=first,
-                                     reduce=kd.allreduce_sum if world > 1 else None)
+                                     reduce=kd.allreduce_sum if use_dist else None)
         torch.cuda.synchronize()
         mc_s, _ = max_over_ranks(time.perf_counter() - t0)
         extra["mc"] = {"config": "configs[3] D(i): montecarlo.go pure-predictor statOD5044 (n=4, AWGN), runs sharded by global index",
                        "runs_total": world * args.mc_runs, "steps": args.mc_steps, "seconds": mc_s,
                        "value": world * args.mc_runs * args.mc_steps / mc_s, "unit": "run-steps/s (whole job)",
                        "collective": "all_reduce(SUM) of %d doubles over %s" % (args.mc_steps * 2 * 4,
-                                                                                  "RCCL" if args.dist_backend == "nccl" and world > 1 else
-                                                                                  (args.dist_backend if world > 1 else "one rank (identity)")),
+                                                                                  "RCCL" if args.dist_backend == "nccl" and use_dist else
+                                                                                  (args.dist_backend if use_dist else "one rank (identity)")),
                        "stddev_last": mc.stddev(args.mc_steps - 1).tolist()}
         del kf
     # ---- extra: config D(ii), Hybrid EKF ensemble sharded the same way ---------------------------------------------
@@ -334,7 +337,7 @@ def main():
         h_s, _ = max_over_ranks(time.perf_counter() - t0)
         hms = e0.elapsed_time(e1) / K3
         hbad = torch.tensor([float(np.count_nonzero(hb.status()))], dtype=torch.float64, device=coll_dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(hbad, op=dist.ReduceOp.SUM)
         extra["hybrid_ekf"] = {"config": "configs[3] D(ii): HybridKF EKF 6/2 fp64 ensemble, per-step Phi/Htilde read in place, filters sharded",
                                "filters_total": world * M, "steps": K3, "value": world * M * K3 / h_s,
@@ -358,7 +361,7 @@ def main():
                        "sharding": "independent filter shards, no collective in the update path; epilogue all-reduce of counts"},
             "roofline": roof,
             "filters_with_error_status": total_bad,
-            "ranks": {"launched": world, "rccl_ranks_seen": ranks_seen, "backend": args.dist_backend if world > 1 else "none",
+            "ranks": {"launched": world, "rccl_ranks_seen": ranks_seen, "backend": args.dist_backend if use_dist else "none",
                       "per_rank_ms_per_step": [s_ / args.steps * 1e3 for s_ in per_rank_s],
                       "filter_steps_counted": total_filter_steps},
         }
@@ -373,7 +376,7 @@ def main():
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,7 +16,7 @@ def allreduce_sum(arr):
     """Sum a float64 numpy array over all ranks (identity when not distributed)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return arr
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
     if dist.get_backend() == "nccl":

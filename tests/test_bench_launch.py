@@ -81,3 +81,15 @@ def test_bench_line_roofline_is_physical():
     assert roof["bytes_convention"]["algorithmic_bytes_per_filter_step"] == 1488
     assert roof["bytes_convention"]["moved_bytes_per_filter_step"] == 1104
     assert "traffic_source" in roof
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_run_on_one_rank():
+    """No multi-GPU box in the test loop: at least the RCCL code path itself (communicator set-up with device_id, device
+    tensors in all_gather / all_reduce / barrier, the Monte-Carlo statistics reduction) runs, with one rank."""
+    r = _run(["--gpus", "1", "--init-dist", "--dist-backend", "nccl"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["ranks"]["backend"] == "nccl" and out["ranks"]["rccl_ranks_seen"] == 1
+    assert "RCCL" in out["extra"]["mc"]["collective"]
+    assert out["ranks"]["filter_steps_counted"] == 65536 * 30
