@@ -30,6 +30,12 @@ __device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontempo
 template <typename T>
 __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
 
+// pin(v): an empty asm that "modifies" v.  The value must exist in a VGPR at this point of the program, so LLVM can neither
+// sink the computation that produces it into a later basic block (machine sinking does that across the data-dependent
+// branches of the factorisations, and drags the producers' operands along as live registers) nor rematerialise it later.
+template <typename T>
+__device__ __forceinline__ void pin(T &v) { asm volatile("" : "+v"(v)); }
+
 // Read-once global loads at (wave-uniform pointer) + (32-bit per-lane BYTE offset), in the scalar-base form of global_load
 // (`global_load_dword v, v_off, s[base:base+1]`): no 64-bit vector address arithmetic and no address register pair per
 // access.  UniformCursor keeps the pointer in SGPRs (it goes through readfirstlane, so the compiler neither folds the lane

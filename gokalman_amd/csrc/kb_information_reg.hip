@@ -12,8 +12,13 @@ namespace kb {
 #define INFO_WPB 1   // waves per workgroup
 #endif
 #ifndef INFO_WAVES
-#define INFO_WAVES 1
+#define INFO_WAVES 2
 #endif
+#ifndef INFO_STASH
+#define INFO_STASH 1
+#endif
+template <typename T, int NS>
+constexpr bool info_stash() { return INFO_STASH && sizeof(T) == 8 && NS > 4; }
 
 
 // PAD: run-time dimensions a.n <= NS, a.p <= NM, a.m <= NC on operands padded with zeros and an identity block in
@@ -22,6 +27,7 @@ namespace kb {
 template <typename T, int NS, int NM, int NC, bool SCALAR_RINV, bool PAD = false>
 __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
+    constexpr bool STASH = info_stash<T, NS>();
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * INFO_WPB + (threadIdx.x >> 6);
@@ -41,26 +47,29 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_Finv + i * rn + j) : T(0);
-    // :163-165 zk = Finv^T (I Finv)
-    T t1[NS * NS], zk[NS * NS];
+    // :163-165 zk = Finv^T (I Finv), one column at a time: column j of I Finv lives only until column j of zk is formed
+    // (the whole intermediate product would put 3 n^2 + n(n+1)/2 doubles in registers at once)
+    T zk[NS * NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++)
+    for (int j = 0; j < NS; j++) {
+        T t1[NS];
 #pragma unroll
-        for (int j = 0; j < NS; j++) {
+        for (int i = 0; i < NS; i++) {
             T s = T(0);
 #pragma unroll
             for (int l = 0; l < NS; l++) s += I[symi(i, l)] * Fi[l * NS + j];
-            t1[i * NS + j] = s;
+            t1[i] = s;
         }
 #pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
+        for (int i = 0; i < NS; i++) {
             T s = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += Fi[l * NS + i] * t1[l * NS + j];
+            for (int l = 0; l < NS; l++) s += Fi[l * NS + i] * t1[l];
             zk[i * NS + j] = s;
         }
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(zk[i * NS + j]);
+    }
     // iKp1Minus (first half, :176-177): Finv^T i
     T im[NS];
 #pragma unroll
@@ -70,6 +79,13 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         for (int i = 0; i < NS; i++) s += Fi[i * NS + j] * iv[i];
         im[j] = s;
     }
+    // pin (kb_device.h): without it the products above are sunk into the basic blocks of the pivoted solve below and
+    // I, Finv, t1 stay alive beside its two work arrays
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) pin(zk[i]);
+#pragma unroll
+    for (int i = 0; i < NS; i++) pin(im[i]);
+    __builtin_amdgcn_sched_barrier(0);
     // :169-174 Z = -zk (zk + Qinv)^-1 (inverse error ignored by the reference).  Obtained as an in-place
     // pivoted LU solve of (zk + Qinv)^T X = zk^T (X = (zk (zk + Qinv)^-1)^T) instead of inverse-then-multiply:
     // two 6x6 work arrays instead of four (the explicit inverse kept the kernel at 1 wave/SIMD).
@@ -81,7 +97,27 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
             zqT[j * NS + i] = zk[i * NS + j] + ((i < rn && j < rn) ? ldnt(mo, a.L.mo_Qinv + i * rn + j) : (i == j ? T(1) : T(0)));
             X[j * NS + i] = zk[i * NS + j];
         }
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) pin(zqT[i]);
+    // zk is needed again for I- (:188-190) but not by the solve: with the solve's two work arrays it would make 3 n^2
+    // live doubles (228 registers at n = 6).  It waits in LDS instead (n^2 x 512 B per wave, 8 waves per CU = 147 KB).
+    __shared__ T lds[STASH ? NS * NS * 64 * INFO_WPB : 1];
+    [[maybe_unused]] const int so = (threadIdx.x >> 6) * (NS * NS * 64) + lane;
+    if constexpr (STASH) {
+#pragma unroll
+        for (int i = 0; i < NS * NS; i++) lds[so + i * 64] = zk[i];
+        asm volatile("" ::: "memory");  // no store-to-load forwarding: the point is to free the registers
+    }
+    __builtin_amdgcn_sched_barrier(0);
     lu_solve_inplace<T, NS, NS>(zqT, X);
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) pin(X[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STASH) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NS * NS; i++) zk[i] = lds[so + i * 64];
+    }
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -125,6 +161,12 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
             for (int l = 0; l < NS; l++) s += Z[i * NS + l] * zk[j * NS + l];
             Im[symi(i, j)] = zk[i * NS + j] + s;
         }
+    // H and R^-1 are only requested once zk and Z are dead (the other wave of the SIMD covers the latency)
+#pragma unroll
+    for (int i = 0; i < TR; i++) pin(Im[i]);
+#pragma unroll
+    for (int i = 0; i < NS; i++) pin(imn[i]);
+    __builtin_amdgcn_sched_barrier(0);
     // :197-212 HTR = H^T Rinv; i+ = HTR y + i-; I+ = I- + HTR H
     T H[NM * NS], HTR[NS * NM];
 #pragma unroll

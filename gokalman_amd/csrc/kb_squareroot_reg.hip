@@ -15,9 +15,10 @@ namespace kb {
 #ifndef SQRT_WPB
 #define SQRT_WPB 1   // waves per workgroup
 #endif
-#ifndef SQRT_WAVES
-#define SQRT_WAVES 1
-#endif
+// Waves per SIMD the register allocation is held to: the exact 6/3 fp64 step fits 256 registers (242, no scratch) once the
+// panel builds are pinned below; the padded 6/4 shapes (10 x 10 second panel) do not.
+template <typename T, int NS, int NM, bool FULL, bool PAD>
+constexpr int sqrt_waves() { return (sizeof(T) == 8 && NS > 4 && PAD) ? 1 : 2; }
 
 
 template <int NS>
@@ -33,7 +34,7 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 // chol(R)): zero rows / columns of a QR panel produce no reflection (sqr_r's `refl` test) and leave the real entries
 // untouched, so only loads and stores see the real sizes (cf. kb_vanilla_reg.h).
 template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false>
-__global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PAD>())) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
     const int lane = threadIdx.x & 63;
@@ -85,6 +86,13 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
             for (int l = i; l < NS; l++) s += S[symi(i, l)] * F[j * NS + l];  // S[l][i], l >= i
             C[i * NS + j] = s;
         }
+    // The reflector's `refl` test splits the factorisation into basic blocks, and LLVM's machine sinking then moves the
+    // products above INTO the factorisation (each column of C formed where it is first used), which keeps S and F alive
+    // next to the panel: +100 registers.  An empty asm that "modifies" each value pins it before the barrier.
+#pragma unroll
+    for (int i = 0; i < NS * NS; i++) pin(C[i]);
+#pragma unroll
+    for (int i = 0; i < NS; i++) pin(xm[i]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NS; i++)
@@ -124,9 +132,14 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
     // H x- for the innovation (:255-262) is formed here, so that H (18 doubles) is dead before the 9 x 9 factorisation
     T Hxm[NM];
     smv<T, NM, NS>(H, xm, Hxm);
-    [[maybe_unused]] T yhat[NM];
     if constexpr (FULL) {
-        smv<T, NM, NS>(H, x, yhat);  // :237-239 yhat = H x_prev
+        // :237-239 yhat = H x_prev.  x_prev is read a second time here (an L2 hit) instead of being kept in registers
+        // through the first factorisation; yhat and Uc leave at once.
+        asm volatile("" ::: "memory");
+        T xp[NS], yhat[NM];
+#pragma unroll
+        for (int i = 0; i < NS; i++) xp[i] = (i < rn) ? ldt(st, i) : T(0);
+        smv<T, NM, NS>(H, xp, yhat);
         T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
         if (active) {
 #pragma unroll
@@ -134,8 +147,18 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
 #pragma unroll
                 for (int j = i; j < NS; j++)
                     if (j < rn) stt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
+#pragma unroll
+            for (int r = 0; r < NM; r++)
+                if (r < rp) stt(es, a.L.es_yhat + r, yhat[r]);
         }
     }
+#pragma unroll
+    for (int r = NM; r < DD; r++)
+#pragma unroll
+        for (int c = 0; c < NM; c++) pin(D[r * DD + c]);
+#pragma unroll
+    for (int r = 0; r < NM; r++) pin(Hxm[r]);
+    __builtin_amdgcn_sched_barrier(0);
     sqr_r<T, DD, DD, ActD<NM>>(D);
     // :225-252 Syy = UD[:p,:p]^T, W = UD[:p,p:]^T, K = W Syy^-1 (general inverse, error ignored)
     T Syy[NM * NM], SyyI[NM * NM], K[NS * NM];
@@ -192,7 +215,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, SQRT_WAVES) squareroot_reg_kern
                     if (i < rn && c < rp) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
             for (int r = 0; r < NM; r++)
-                if (r < rp) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, yhat[r]); }
+                if (r < rp) stt(es, a.L.es_innov + r, innov[r]);
         }
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
