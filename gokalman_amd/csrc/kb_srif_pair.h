@@ -29,6 +29,7 @@
 // Failure semantics as everywhere (kb_srif_reg.hip header): a singular Phi / R skips this step for that filter only.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "kb_internal.h"
 #include "kb_static.h"
@@ -101,6 +102,32 @@ __device__ __forceinline__ double root(double x) { return sqrt(x); }
 
 __device__ __forceinline__ int pnib(uint64_t perm, int r) { return (int)((perm >> (4 * r)) & 15u); }
 
+// compile-time loop: f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
+template <int B, int E, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sfor<B + 1, E>(f);
+    }
+}
+
+// SL rows x (2 HS + 1) columns in registers: HS column pairs per row and the last column apart.  All indices are compile-time
+// constants once the loops are unrolled.
+template <typename T, int SL, int HS>
+struct Panel {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 p[SL * HS];
+    T b[SL];
+    __device__ __forceinline__ T get(int s, int j) const { return j == 2 * HS ? b[s] : p[s * HS + j / 2][j & 1]; }
+    __device__ __forceinline__ void set(int s, int j, T v) {
+        if (j == 2 * HS) b[s] = v;
+        else p[s * HS + j / 2][j & 1] = v;
+    }
+    __device__ __forceinline__ V2 &pair(int s, int c) { return p[s * HS + c]; }
+    static __device__ __forceinline__ V2 splat(T u) { return (V2){u, u}; }
+    static __device__ __forceinline__ V2 fma2(V2 a, V2 b, V2 c) { return __builtin_elementwise_fma(a, b, c); }
+};
+
 // One half-tile (32 filters) of the SRIF Update.  DENSE: R may be a full matrix for some filter of this half-tile (the
 // Update right after a Predict(), or a filter that skipped such an Update): all of R is read, State(prev) is a pivoted LU
 // solve, and the finished factor's lower triangle is zeroed in memory.  DENSE = false is the steady state (R upper
@@ -109,12 +136,13 @@ template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE>
 __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, int half, int lane, T *lds_lu) {
     static_assert(NS % 2 == 0 && NM % 2 == 0, "rows are split by parity");
     constexpr int COLS = NS + 1, HS = NS / 2, HM = NM / 2, SL = HS + HM, ROWE = NS * KB_TILE;
+    typedef Panel<T, SL, HS> PN;
+    typedef typename PN::V2 V2;
     // Addressing: every base below is wave-uniform (tile / half come from readfirstlane in the kernel), the per-lane part
     // is ONE 32-bit element offset (vf, or vrow for the own rows), so the loads and stores use the scalar-base +
     // 32-bit-vector-offset form: no 64-bit address pair per access (there are ~350 accesses per lane).
     const unsigned vf = (unsigned)lane & 31u;
     const bool is_hi = lane >= 32;
-    const int l = is_hi ? 1 : 0;
     const unsigned vrow = vf + (is_hi ? (unsigned)ROWE : 0u);   // own rows: element NS + 2 s NS + j from here is R[2 s + l][j]
     const unsigned vl = vf + (is_hi ? (unsigned)KB_TILE : 0u);  // own element of an (even, odd) pair of consecutive elements
     const int64_t first = tile * KB_TILE + half * 32;
@@ -137,7 +165,10 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     const unsigned bx = vx * (unsigned)sizeof(T), bphi = vphi * (unsigned)sizeof(T);
 
     unsigned err = 0;
-    T A[SL * COLS];   // own rows of the panel [[RBar bBar], [L Htilde, L y]]; the top part first holds the own rows of R
+    // own rows of the panel [[RBar bBar], [L Htilde, L y]] (the top part first holds the own rows of R), kept as COLUMN PAIRS
+    // (2 c, 2 c + 1) plus the right-hand-side column: the Householder updates run on pairs (v_pk_fma_f32 in fp32: two
+    // columns per instruction; in fp64 the same source compiles to two scalar FMAs)
+    Panel<T, SL, HS> A;
     T xprev[NS];
     T pc[NS * HS];    // Phi, this half's columns: pc[r * HS + cs] = Phi[r][2 cs + l]; factorised in place
     auto load_phi = [&]() {
@@ -193,7 +224,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
 #pragma unroll
         for (int s = 0; s < HS; s++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) A[s * COLS + j] = j >= 2 * s ? ld_row(NS + 2 * s * NS + j) : T(0);   // (2 s + 1, 2 s) is a stored zero
+            for (int j = 0; j < NS; j++) A.set(s, j, j >= 2 * s ? ld_row(NS + 2 * s * NS + j) : T(0));   // (2 s + 1, 2 s) is a stored zero
         load_phi();
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -204,7 +235,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
 #pragma unroll
         for (int s = 0; s < HS; s++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) A[s * COLS + j] = ld_row(NS + 2 * s * NS + j);
+            for (int j = 0; j < NS; j++) A.set(s, j, ld_row(NS + 2 * s * NS + j));
         load_phi();
     } else {
         // back substitution, column-oriented: as soon as x_i exists (in the half that owns row i) it is handed to the other
@@ -213,7 +244,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         T rinv[HS], acc[HS];
 #pragma unroll
         for (int s = 0; s < HS; s++) {
-            const T d = is_hi ? A[s * COLS + 2 * s + 1] : A[s * COLS + 2 * s];   // R[2 s + l][2 s + l]
+            const T d = is_hi ? A.get(s, 2 * s + 1) : A.get(s, 2 * s);   // R[2 s + l][2 s + l]
             if (d == T(0)) err |= KB_ST_SINGULAR;
             rinv[s] = recip(d);
             acc[s] = bown[s];
@@ -223,7 +254,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             const int si = i / 2, own = i % 2;
             xprev[i] = from_half(acc[si] * rinv[si], own);   // the other half's product (its row 2 si + 1 - own) is discarded
 #pragma unroll
-            for (int s = 0; s <= si; s++) acc[s] -= A[s * COLS + i] * xprev[i];   // rows 2 s + l < i; the structural zeros contribute 0
+            for (int s = 0; s <= si; s++) acc[s] -= A.get(s, i) * xprev[i];   // rows 2 s + l < i; the structural zeros contribute 0
         }
     }
     // ---- xBar = Phi State(prev) (srif.go:118): each half sums over its columns ------------------------------------------
@@ -310,42 +341,87 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
 #pragma unroll
             for (int m = 0; m <= 2 * t + 1; m++) w1 += Lw[symi(m, 2 * t + 1)] * Hc[m * HS + cs];
             cross(w0, w1);   // lower half: row 2 t, columns 2 cs and 2 cs + 1; upper half: row 2 t + 1, the same columns
-            A[(HS + t) * COLS + 2 * cs] = w0;
-            A[(HS + t) * COLS + 2 * cs + 1] = w1;
+            A.set(HS + t, 2 * cs, w0);
+            A.set(HS + t, 2 * cs + 1, w1);
         }
         T s0 = T(0), s1 = T(0);
 #pragma unroll
         for (int m = 0; m <= 2 * t; m++) s0 += Lw[symi(m, 2 * t)] * yv[m];
 #pragma unroll
         for (int m = 0; m <= 2 * t + 1; m++) s1 += Lw[symi(m, 2 * t + 1)] * yv[m];
-        A[(HS + t) * COLS + NS] = is_hi ? s1 : s0;
+        A.set(HS + t, NS, is_hi ? s1 : s0);
         if constexpr (FULL) yown[t] = is_hi ? yreal[2 * t + 1] : yreal[2 * t];
     }
 
     __builtin_amdgcn_sched_barrier(0);   // the measurement operands are dead from here on
     // ---- RBar = R Phi^-1 (srif.go:115) for the own rows: z Phi = R[i,:], i.e. w U = r, v L = w, z[perm_k] = v_k --------
     // A[s][0..NS) is z for row 2 s + l; columns < 2 s are structural zeros (skipped) unless DENSE
+    // two columns (2 c, 2 c + 1) at a time: the pair subtracts A[s][k2] (U[k2][2 c], U[k2][2 c + 1]) in one packed FMA
+    auto lu2 = [&](int r, int c) { return V2{lds_lu[(r * NS + 2 * c) * 32 + vf], lds_lu[(r * NS + 2 * c + 1) * 32 + vf]}; };
+    if constexpr (sizeof(T) == 8) {
+    // (sfor: compile-time indices, no loop for the optimiser to unroll late -- the panel must be promoted to registers)
+    sfor<0, HS>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = C;
+        sfor<0, 2 * c>([&](auto K2) __attribute__((always_inline)) {
+            constexpr int k2 = K2;
+            const V2 u = lu2(k2, c);
+            sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
+                constexpr int s = S;
+                if constexpr (DENSE || 2 * s <= k2) A.pair(s, c) = PN::fma2(-PN::splat(A.get(s, k2)), u, A.pair(s, c));
+            });
+        });
+        const V2 d = lu2(2 * c, c);   // (1 / U[2c][2c], U[2c][2c + 1])
+        const T r1 = lds_lu[((2 * c + 1) * NS + 2 * c + 1) * 32 + vf];
+        sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = S;
+            if constexpr (DENSE || s <= c) {
+                const T z0 = A.get(s, 2 * c) * d[0];
+                A.set(s, 2 * c, z0);
+                A.set(s, 2 * c + 1, (A.get(s, 2 * c + 1) - z0 * d[1]) * r1);
+            }
+        });
+    });
+    // v L = w from the last column back; within a pair the (2 c + 1) -> 2 c term comes last
+    sfor<0, HS>([&](auto CR) __attribute__((always_inline)) {
+        constexpr int c = HS - 1 - CR;
+        sfor<2 * c + 2, NS>([&](auto K2) __attribute__((always_inline)) {
+            constexpr int k2 = K2;
+            const V2 lk = lu2(k2, c);
+            sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
+                constexpr int s = S;
+                A.pair(s, c) = PN::fma2(-PN::splat(A.get(s, k2)), lk, A.pair(s, c));
+            });
+        });
+        const T l10 = lds_lu[((2 * c + 1) * NS + 2 * c) * 32 + vf];
+        sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = S;
+            A.set(s, 2 * c, A.get(s, 2 * c) - A.get(s, 2 * c + 1) * l10);
+        });
+    });
+    } else {
+        // fp32: column by column -- the pair form costs the allocator its slack at the 256-register cap (spills on the hot path)
 #pragma unroll
-    for (int j = 0; j < NS; j++) {
+        for (int j = 0; j < NS; j++) {
 #pragma unroll
-        for (int k2 = 0; k2 < j; k2++) {
-            const T ukj = lds_lu[(k2 * NS + j) * 32 + vf];
+            for (int k2 = 0; k2 < j; k2++) {
+                const T ukj = lds_lu[(k2 * NS + j) * 32 + vf];
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+                    if (DENSE || 2 * s <= k2) A.set(s, j, A.get(s, j) - A.get(s, k2) * ukj);
+            }
+            const T rjj = lds_lu[(j * NS + j) * 32 + vf];
 #pragma unroll
             for (int s = 0; s < HS; s++)
-                if (DENSE || 2 * s <= k2) A[s * COLS + j] -= A[s * COLS + k2] * ukj;
+                if (DENSE || 2 * s <= j) A.set(s, j, A.get(s, j) * rjj);
         }
-        const T rjj = lds_lu[(j * NS + j) * 32 + vf];
 #pragma unroll
-        for (int s = 0; s < HS; s++)
-            if (DENSE || 2 * s <= j) A[s * COLS + j] *= rjj;
-    }
+        for (int j = NS - 2; j >= 0; j--) {
 #pragma unroll
-    for (int j = NS - 2; j >= 0; j--) {
+            for (int k2 = j + 1; k2 < NS; k2++) {
+                const T lkj = lds_lu[(k2 * NS + j) * 32 + vf];
 #pragma unroll
-        for (int k2 = j + 1; k2 < NS; k2++) {
-            const T lkj = lds_lu[(k2 * NS + j) * 32 + vf];
-#pragma unroll
-            for (int s = 0; s < HS; s++) A[s * COLS + j] -= A[s * COLS + k2] * lkj;
+                for (int s = 0; s < HS; s++) A.set(s, j, A.get(s, j) - A.get(s, k2) * lkj);
+            }
         }
     }
     // bBar = RBar xBar (srif.go:119), same products in pivoted order; then the row permutation is undone
@@ -363,26 +439,26 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         for (int s = 0; s < HS; s++) {
             T bb = T(0);
 #pragma unroll
-            for (int r = 0; r < NS; r++) bb += A[s * COLS + r] * xp[r];
+            for (int r = 0; r < NS; r++) bb += A.get(s, r) * xp[r];
             T row[NS];
 #pragma unroll
             for (int c = 0; c < NS; c++) {
                 T v = T(0);
 #pragma unroll
-                for (int r = 0; r < NS; r++) v = pnib(perm, r) == c ? A[s * COLS + r] : v;
+                for (int r = 0; r < NS; r++) v = pnib(perm, r) == c ? A.get(s, r) : v;
                 row[c] = v;
             }
 #pragma unroll
-            for (int c = 0; c < NS; c++) A[s * COLS + c] = row[c];
-            A[s * COLS + NS] = bb;
+            for (int c = 0; c < NS; c++) A.set(s, c, row[c]);
+            A.set(s, NS, bb);
         }
     } else {
 #pragma unroll
         for (int s = 0; s < HS; s++) {
             T bb = T(0);
 #pragma unroll
-            for (int r = 0; r < NS; r++) bb += A[s * COLS + r] * xbar[r];
-            A[s * COLS + NS] = bb;
+            for (int r = 0; r < NS; r++) bb += A.get(s, r) * xbar[r];
+            A.set(s, NS, bb);
         }
     }
     if constexpr (FULL) {
@@ -390,11 +466,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
 #pragma unroll
             for (int s = 0; s < HS; s++)
 #pragma unroll
-                for (int j = 0; j < NS; j++) es[(unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow] = A[s * COLS + j];
+                for (int j = 0; j < NS; j++) es[(unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow] = A.get(s, j);
 #pragma unroll
             for (int t = 0; t < HM; t++) {
                 es[(unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl] = yown[t];
-                es[(unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl] = A[(HS + t) * COLS + NS];
+                es[(unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl] = A.get(HS + t, NS);
             }
         }
     }
@@ -406,12 +482,16 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     for (int k = 0; k < NS; k++) {
         const int sk = k / 2, lk = k % 2;
         // u_i = A[i][k] for the rows i >= k; in slot sk that is both halves when k is even, only the upper half when odd
-        const T ask = A[sk * COLS + k];
+        const int ck = k / 2;
+        T colk[SL];   // column k of the own rows (register renaming)
+#pragma unroll
+        for (int s = sk; s < SL; s++) colk[s] = A.get(s, k);
+        const T ask = colk[sk];
         T part = lk == 0 ? ask * ask : (is_hi ? ask * ask : T(0)), part2 = T(0);   // two chains: the sum is on the critical path of the step
 #pragma unroll
         for (int s = sk + 1; s < SL; s++) {
-            if ((s - sk) & 1) part2 += A[s * COLS + k] * A[s * COLS + k];
-            else part += A[s * COLS + k] * A[s * COLS + k];
+            if ((s - sk) & 1) part2 += colk[s] * colk[s];
+            else part += colk[s] * colk[s];
         }
         T sigma = allsum(part + part2);
         const T akk = from_half(ask, lk);
@@ -420,57 +500,71 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         const T uk = akk + sigma;
         const T beta = recip(sigma * uk);
         const T usk = lk == 0 ? (is_hi ? ask : uk) : (is_hi ? uk : T(0));   // u of this lane's row in slot sk
-        // two columns per exchange: cross() leaves (column j total | column j + 1 total) in the (lower | upper) half after
-        // one add, a second swap hands both totals to both halves -- 4 instructions for 2 columns; same sums as allsum()
+        // The column pairs to the right of column k: both dot products in one accumulator pair, then ONE exchange for the
+        // two columns: cross() leaves (first column's total | second column's total) in the (lower | upper) half after one
+        // add, a second swap hands both totals to both halves -- 4 instructions for 2 columns; same sums as allsum()
 #pragma unroll
-        for (int j = 1; j < COLS; j++) {   // constant trip count (the compiler unrolls inner loops first): j = k + 1, k + 3, ... do the work
-            if (j <= k || ((j - k - 1) & 1) != 0) continue;
-            if (j + 1 < COLS) {
-                T p0 = T(0), p1 = T(0);   // the rows below first: they do not wait for sigma
+        for (int c = 0; c < HS; c++) {
+            if (c <= ck) continue;
+            V2 pp = V2{T(0), T(0)};   // the rows below first: they do not wait for sigma
 #pragma unroll
-                for (int s = sk + 1; s < SL; s++) {
-                    p0 += A[s * COLS + k] * A[s * COLS + j];
-                    p1 += A[s * COLS + k] * A[s * COLS + j + 1];
-                }
-                p0 += usk * A[sk * COLS + j];
-                p1 += usk * A[sk * COLS + j + 1];
-                T g0, g1;
-                cross(p0, p1);
-                halves(p0 + p1, g0, g1);
-                g0 *= beta;
-                g1 *= beta;
-                A[sk * COLS + j] -= g0 * usk;
-                A[sk * COLS + j + 1] -= g1 * usk;
+            for (int s = sk + 1; s < SL; s++) pp = PN::fma2(PN::splat(colk[s]), A.pair(s, c), pp);
+            pp = PN::fma2(PN::splat(usk), A.pair(sk, c), pp);
+            T p0 = pp[0], p1 = pp[1], g0, g1;
+            cross(p0, p1);
+            halves(p0 + p1, g0, g1);
+            const V2 g = V2{g0 * beta, g1 * beta};
+            A.pair(sk, c) = PN::fma2(-g, PN::splat(usk), A.pair(sk, c));
 #pragma unroll
-                for (int s = sk + 1; s < SL; s++) {
-                    A[s * COLS + j] -= g0 * A[s * COLS + k];
-                    A[s * COLS + j + 1] -= g1 * A[s * COLS + k];
-                }
-            } else {
-                T pj = T(0);
-#pragma unroll
-                for (int s = sk + 1; s < SL; s++) pj += A[s * COLS + k] * A[s * COLS + j];
-                pj += usk * A[sk * COLS + j];
-                const T gamma = allsum(pj) * beta;
-                A[sk * COLS + j] -= gamma * usk;
-#pragma unroll
-                for (int s = sk + 1; s < SL; s++) A[s * COLS + j] -= gamma * A[s * COLS + k];
-            }
+            for (int s = sk + 1; s < SL; s++) A.pair(s, c) = PN::fma2(-g, PN::splat(colk[s]), A.pair(s, c));
         }
-        A[sk * COLS + k] = lk == 0 ? (is_hi ? T(0) : -sigma) : (is_hi ? -sigma : ask);
+        // the odd columns out: the right-hand side always, and column k + 1 (the other half of k's pair) when k is even
+        if (lk == 0) {
+            const int j = k + 1;
+            T p0 = T(0), p1 = T(0);
+#pragma unroll
+            for (int s = sk + 1; s < SL; s++) {
+                p0 += colk[s] * A.get(s, j);
+                p1 += colk[s] * A.b[s];
+            }
+            p0 += usk * A.get(sk, j);
+            p1 += usk * A.b[sk];
+            T g0, g1;
+            cross(p0, p1);
+            halves(p0 + p1, g0, g1);
+            g0 *= beta;
+            g1 *= beta;
+            A.set(sk, j, A.get(sk, j) - g0 * usk);
+            A.b[sk] -= g1 * usk;
+#pragma unroll
+            for (int s = sk + 1; s < SL; s++) {
+                A.set(s, j, A.get(s, j) - g0 * colk[s]);
+                A.b[s] -= g1 * colk[s];
+            }
+        } else {
+            T pj = T(0);
+#pragma unroll
+            for (int s = sk + 1; s < SL; s++) pj += colk[s] * A.b[s];
+            pj += usk * A.b[sk];
+            const T gamma = allsum(pj) * beta;
+            A.b[sk] -= gamma * usk;
+#pragma unroll
+            for (int s = sk + 1; s < SL; s++) A.b[s] -= gamma * colk[s];
+        }
+        A.set(sk, k, lk == 0 ? (is_hi ? T(0) : -sigma) : (is_hi ? -sigma : ask));
         // row k is final: it leaves the register file from the half that owns it
 #pragma unroll
-        for (int j = k; j < COLS; j++) chk += A[sk * COLS + j] * T(0);
+        for (int j = k; j < COLS; j++) chk += A.get(sk, j) * T(0);
         if (ok && is_hi == (lk == 1)) {
-            st[(unsigned)(k * KB_TILE) + vf] = A[sk * COLS + NS];
+            st[(unsigned)(k * KB_TILE) + vf] = A.b[sk];
 #pragma unroll
-            for (int j = k; j < NS; j++) st[(unsigned)((NS + 2 * sk * NS + j) * KB_TILE) + vrow] = A[sk * COLS + j];
+            for (int j = k; j < NS; j++) st[(unsigned)((NS + 2 * sk * NS + j) * KB_TILE) + vrow] = A.get(sk, j);
         }
     }
     if constexpr (FULL) {
         if (ok) {
 #pragma unroll
-            for (int t = 0; t < HM; t++) es[(unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl] = A[(HS + t) * COLS + NS];
+            for (int t = 0; t < HM; t++) es[(unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl] = A.get(HS + t, NS);
         }
     }
     if constexpr (DENSE) {
