@@ -9,13 +9,16 @@
 namespace kb {
 
 
+#ifndef HYB_WPB
+#define HYB_WPB 1   // waves per workgroup: a finished wave frees its slot at once (4 per workgroup: 137.7 us, 1: 128.5 us at 1M filters)
+#endif
 // SNCP: the instantiation that also handles SNC (PreparePNT) and Predict(); the plain update stays free of their
 // branches and registers (it is the D(ii) benchmark path).
 template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT, bool SNCP = false>
-__global__ void __launch_bounds__(256, (SNCP && FULL) ? 1 : 2) hybrid_reg_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS);
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * HYB_WPB + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
@@ -244,7 +247,7 @@ static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {
 template <typename T, int NS, int NM>
 static bool hybrid_try(const Batch &b, const StepArgs &a) {
     if (!hybrid_shape_ok(a, NS, NM)) return false;
-    const dim3 grid = tile_grid(a.ntiles), block(256);
+    const dim3 grid((unsigned)((a.ntiles + HYB_WPB - 1) / HYB_WPB)), block(64 * HYB_WPB);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const bool sncp = a.snc || a.predict;
 #define KB_H(E_, F_) do { if (sncp) { if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true, true>), grid, block, 0, b.stream, a); \
