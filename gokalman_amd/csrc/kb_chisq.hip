@@ -22,6 +22,7 @@ namespace kb {
 constexpr int CHI_REPL = 32;
 
 
+
 struct ChiArgs {
     const void *t_state, *t_model;  // truth batch (pure predictor, AWGN factors in its model block)
     const void *k_state, *k_model;  // filter batch (initial estimate + model)
@@ -34,7 +35,7 @@ struct ChiArgs {
 };
 
 template <typename T, int NS, int NM, int NC>
-__global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
+__global__ void __launch_bounds__(256, (NS <= 4 ? 2 : 1)) chisq_kernel(const ChiArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM);
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,18 +47,25 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
     const T *ks = (const T *)a.k_state + tile * ((int64_t)KB_TILE * a.kL.st_elems) + lane;
     const T *km = (const T *)a.k_model + tile * ((int64_t)KB_TILE * a.kL.mo_elems) + lane;
     // truth model
-    T xt[NS], Ft[NS * NS], Ht[NM * NS], LQ[TR], LR[TM];
+    T xt[NS], Ft[NS * NS];
+    // the truth model's H, chol(Q), chol(R) are read once per step: they wait in LDS ((NM NS + TR + TM) x 2 KB per workgroup)
+    constexpr int NPARK = NM * NS + TR + TM;
+    __shared__ T park[NPARK * 256];
+    T *pk = park + threadIdx.x;
+#define Ht(e) pk[(e) * 256]
+#define LQ(e) pk[(NM * NS + (e)) * 256]
+#define LR(e) pk[(NM * NS + TR + (e)) * 256]
     [[maybe_unused]] T Gt[NC > 0 ? NS * NC : 1], Gk[NC > 0 ? NS * NC : 1];
 #pragma unroll
     for (int i = 0; i < NS; i++) xt[i] = ldt(ts, a.tL.st_vec + i);
 #pragma unroll
     for (int e = 0; e < NS * NS; e++) Ft[e] = ldt(tm, a.tL.mo_F + e);
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) Ht[e] = ldt(tm, a.tL.mo_H + e);
+    for (int e = 0; e < NM * NS; e++) Ht(e) = ldt(tm, a.tL.mo_H + e);
 #pragma unroll
-    for (int e = 0; e < TR; e++) LQ[e] = ldt(tm, a.tL.mo_LQ + e);
+    for (int e = 0; e < TR; e++) LQ(e) = ldt(tm, a.tL.mo_LQ + e);
 #pragma unroll
-    for (int e = 0; e < TM; e++) LR[e] = ldt(tm, a.tL.mo_LR + e);
+    for (int e = 0; e < TM; e++) LR(e) = ldt(tm, a.tL.mo_LR + e);
     // filter
     T x[NS], P[TR], F[NS * NS], H[NM * NS], Q[TR], R[TM];
 #pragma unroll
@@ -79,6 +87,7 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
     const uint64_t gfi = (uint64_t)(a.first_run + fi);
     double *my = a.sums + (size_t)(tile % CHI_REPL) * a.nsteps * 2;
     for (int t = 0; t < a.nsteps; t++) {
+        asm volatile("" ::: "memory");   // the parked operands are re-read each step, not hoisted back into registers
         [[maybe_unused]] T u[NC > 0 ? NC : 1];
         if constexpr (NC > 0) {
             const T *up = (const T *)a.controls + (a.ncontrols == 1 ? 0 : (int64_t)t * NC);
@@ -110,9 +119,9 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
         for (int r2 = 0; r2 < NM; r2++) {
             T s = T(0), v = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += Ht[r2 * NS + l] * xt[l];
+            for (int l = 0; l < NS; l++) s += Ht(r2 * NS + l) * xt[l];
 #pragma unroll
-            for (int k2 = 0; k2 <= r2; k2++) v += LR[symi(k2, r2)] * zr[k2];
+            for (int k2 = 0; k2 <= r2; k2++) v += LR(symi(k2, r2)) * zr[k2];
             y[r2] = s + v;
         }
 #pragma unroll
@@ -127,11 +136,16 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
                 s = s + g;
             }
 #pragma unroll
-            for (int k2 = 0; k2 <= i; k2++) w += LQ[symi(k2, i)] * zq[k2];
+            for (int k2 = 0; k2 <= i; k2++) w += LQ(symi(k2, i)) * zq[k2];
             xtn[i] = s + w;
         }
 #pragma unroll
         for (int i = 0; i < NS; i++) xt[i] = xtn[i];
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(xt[i]);
+#pragma unroll
+        for (int i = 0; i < NM; i++) pin(y[i]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- filter: Vanilla.Update(y, u), Noiseless (vanilla.go:128-220)
         T xm[NS], Pm[TR];
 #pragma unroll
@@ -165,6 +179,11 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
                 Pm[symi(i, j)] = s + Q[symi(i, j)];
             }
         }
+#pragma unroll
+        for (int i = 0; i < TR; i++) pin(Pm[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(xm[i]);
+        __builtin_amdgcn_sched_barrier(0);
         T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
 #pragma unroll
         for (int i = 0; i < NS; i++)
@@ -184,8 +203,18 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
                 for (int i = 0; i < NS; i++) s += H[r2 * NS + i] * PHt[i * NM + c];
                 S[r2 * NM + c] = s + R[symi(r2, c)];
             }
+#pragma unroll
+        for (int i = 0; i < NS * NM; i++) pin(PHt[i]);
+#pragma unroll
+        for (int i = 0; i < NM * NM; i++) pin(S[i]);
+        __builtin_amdgcn_sched_barrier(0);
         inverse_lu<T, NM>(S, Si);
         smm_nn<T, NS, NM, NM>(PHt, Si, K);
+#pragma unroll
+        for (int i = 0; i < NS * NM; i++) pin(K[i]);
+#pragma unroll
+        for (int i = 0; i < NM * NM; i++) pin(Si[i]);
+        __builtin_amdgcn_sched_barrier(0);
         T innov[NM];
 #pragma unroll
         for (int r2 = 0; r2 < NM; r2++) {
@@ -238,6 +267,11 @@ __global__ void __launch_bounds__(256) chisq_kernel(const ChiArgs a) {
                 P[symi(i, j)] = s + s2;
             }
         }
+#pragma unroll
+        for (int i = 0; i < TR; i++) pin(P[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(x[i]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- statistics (chisquare.go:46-77)
         double nis = 0.0, nees = 0.0;
         if (a.with_nis) {
