@@ -90,6 +90,7 @@ func (b *batch) get(field C.int, rows, cols int) []float64 {
 // once, by ONE kb_get_estimate call, when the estimate is created.
 type Estimate struct {
 	n, p                        int
+	kind                        C.int
 	state, meas, innov          []float64
 	covar, predCovar, gain      []float64
 	status                      uint32
@@ -105,7 +106,7 @@ func snapshot(b *batch, kind C.int) (*Estimate, error) {
 	if info {
 		ni = n // Innovation() returns the information vector (information.go:272, srif.go:237)
 	}
-	e := &Estimate{n: n, p: p, state: make([]float64, n), covar: make([]float64, n*n), predCovar: make([]float64, n*n),
+	e := &Estimate{n: n, p: p, kind: kind, state: make([]float64, n), covar: make([]float64, n*n), predCovar: make([]float64, n*n),
 		meas: make([]float64, p), innov: make([]float64, ni)}
 	var v C.kb_estimate_view
 	v.state, v.covariance, v.pred_covariance = ptr(e.state), ptr(e.covar), ptr(e.predCovar)
@@ -141,8 +142,23 @@ func (e *Estimate) IsWithinNσ(N float64) bool {
 	return true
 }
 func (e *Estimate) IsWithin2σ() bool { return e.IsWithinNσ(2) }
+// String prints what the reference's estimate of the same kind prints (vanilla.go:276-284, squareroot.go:347-355,
+// hybrid.go:300-308; information.go:318-325 without the gain; srif.go:283-289 without gain and innovation).
 func (e *Estimate) String() string {
-	return fmt.Sprintf("{\ns=%v\ny=%v\nP=%v\n}", e.state, e.meas, e.covar)
+	state := mat64.Formatted(e.State(), mat64.Prefix("  "))
+	meas := mat64.Formatted(e.Measurement(), mat64.Prefix("  "))
+	covar := mat64.Formatted(e.Covariance(), mat64.Prefix("  "))
+	predp := mat64.Formatted(e.PredCovariance(), mat64.Prefix("   "))
+	switch e.kind {
+	case C.KB_SRIF:
+		return fmt.Sprintf("{\ns=%v\ny=%v\nP=%v\nP-=%v\n}", state, meas, covar, predp)
+	case C.KB_INFORMATION:
+		innov := mat64.Formatted(e.Innovation(), mat64.Prefix("  "))
+		return fmt.Sprintf("{\ns=%v\ny=%v\nP=%v\nP-=%v\ni=%v\n}", state, meas, covar, predp, innov)
+	}
+	gain := mat64.Formatted(e.Gain(), mat64.Prefix("  "))
+	innov := mat64.Formatted(e.Innovation(), mat64.Prefix("  "))
+	return fmt.Sprintf("{\ns=%v\ny=%v\nP=%v\nK=%v\nP-=%v\ni=%v\n}", state, meas, covar, gain, predp, innov)
 }
 
 // stepError turns the status word of the step that just ran into the reference's error value.
@@ -205,7 +221,16 @@ func (kf *Vanilla) SetNoise(n gokalman.Noise) {
 	kf.b.set(C.KB_R, n.MeasurementMatrix(), p)
 }
 func (kf *Vanilla) Reset()         { C.kb_reset(kf.b.h) }
-func (kf *Vanilla) String() string { return "gokalman_amd.Vanilla" }
+// String is vanilla.go:76-78 / squareroot.go:65-67 (information.go:96-98 prints inv(F) instead of F).
+func (kf *Vanilla) String() string {
+	if kf.kind == C.KB_INFORMATION {
+		var finv mat64.Dense
+		if err := finv.Inverse(kf.F); err == nil {
+			return fmt.Sprintf("inv(F)=%v\nG=%v\nH=%v\n%s", mat64.Formatted(&finv, mat64.Prefix("      ")), mat64.Formatted(kf.G, mat64.Prefix("  ")), mat64.Formatted(kf.H, mat64.Prefix("  ")), kf.Noise)
+		}
+	}
+	return fmt.Sprintf("F=%v\nG=%v\nH=%v\n%s", mat64.Formatted(kf.F, mat64.Prefix("  ")), mat64.Formatted(kf.G, mat64.Prefix("  ")), mat64.Formatted(kf.H, mat64.Prefix("  ")), kf.Noise)
+}
 
 var _ gokalman.LDKF = (*Vanilla)(nil)
 var _ gokalman.Estimate = (*Estimate)(nil)
@@ -262,8 +287,9 @@ func NewInformationFromState(x0 *mat64.Vector, P0 mat64.Symmetric, F, G, H mat64
 
 // NLDKF implements gokalman.NLDKF (kalman.go:51-60) for SRIF and HybridKF batches.
 type NLDKF struct {
-	b    *batch
-	kind C.int
+	b     *batch
+	kind  C.int
+	Noise gokalman.Noise
 }
 
 func newNLDKF(kind C.int, x0 *mat64.Vector, P0 mat64.Symmetric, noise gokalman.Noise, measSize int, flags C.uint) (*NLDKF, *Estimate, error) {
@@ -297,7 +323,7 @@ func newNLDKF(kind C.int, x0 *mat64.Vector, P0 mat64.Symmetric, noise gokalman.N
 	if err != nil {
 		return nil, nil, err
 	}
-	return &NLDKF{b, kind}, est0, nil
+	return &NLDKF{b: b, kind: kind, Noise: noise}, est0, nil
 }
 
 // NewSRIF mirrors gokalman.NewSRIF (srif.go:14-49); NewHybridKF mirrors hybrid.go:23-34.
@@ -358,7 +384,15 @@ func (kf *NLDKF) Predict() (gokalman.Estimate, error) { // srif.go:96, hybrid.go
 func (kf *NLDKF) EKFEnabled() bool { return C.kb_ekf_enabled(kf.b.h) != 0 }
 func (kf *NLDKF) EnableEKF()       { C.kb_set_ekf(kf.b.h, 1) }
 func (kf *NLDKF) DisableEKF()      { C.kb_set_ekf(kf.b.h, 0) }
+// String is hybrid.go:63-65 (the reference's SRIF has no String of its own).
+func (kf *NLDKF) String() string {
+	if kf.kind == C.KB_HYBRID {
+		return fmt.Sprintf("HybridKF [k=%d]\n%s", int64(C.kb_step(kf.b.h)), kf.Noise)
+	}
+	return fmt.Sprintf("SRIF [k=%d]", int64(C.kb_step(kf.b.h)))
+}
 func (kf *NLDKF) SetNoise(n gokalman.Noise) {
+	kf.Noise = n
 	p, _ := n.MeasurementMatrix().Dims()
 	kf.b.set(C.KB_R, n.MeasurementMatrix(), p)
 }

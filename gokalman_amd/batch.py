@@ -137,6 +137,24 @@ class Estimate:
     def is_within_2sigma(self):
         return self.is_within_nsigma(2.0)
 
+    def string(self, filt=0):
+        """<Kind>Estimate.String() of one filter of this estimate (vanilla.go:276-284 and the other kinds' equivalents,
+        see strfmt.py).  Members the batch does not keep (no KB_FLAG_FULL_ESTIMATE) print as Go's nil."""
+        from . import strfmt
+        name = {k.VANILLA: "vanilla", k.VANILLA_PREDICT: "vanilla", k.SQUAREROOT: "squareroot", k.INFORMATION: "information",
+                k.SRIF: "srif", k.HYBRID: "hybrid", k.BATCH_LS: "vanilla"}[self._b.kind]
+
+        def member(fn):
+            try:
+                return fn()[filt]
+            except k.KalmanError:
+                return None
+        return strfmt.estimate_string(name, member(self.state), member(self.measurement), member(self.covariance),
+                                      member(self.gain), member(self.pred_covariance), member(self.innovation))
+
+    def __str__(self):
+        return "\n".join(self.string(i) for i in range(self._count))
+
 
 class FilterBatch:
     """N independent filters of one kind on one MI355X (a `kb_batch`)."""
@@ -145,6 +163,7 @@ class FilterBatch:
         self._h = C.c_void_p()
         self.kind, self.n, self.pmax, self.m, self.N, self.dtype = kind, n, p, m, int(nfilters), dtype
         self.flags, self._resets = flags, 0
+        self._noise_name = "noiseless"
         k.check(k.lib().kb_create(C.byref(self._h), kind, n, p, m, int(nfilters), dtype, device, flags))
 
     # ---- constructors mirroring NewVanilla / NewPurePredictorVanilla / NewSquareRoot /
@@ -252,6 +271,7 @@ class FilterBatch:
 
     def set_noise_kind(self, kind, seed=0):
         k.check(k.lib().kb_set_noise_kind(self._h, kind, seed))
+        self._noise_name = {k.NOISE_NOISELESS: "noiseless", k.NOISE_AWGN: "awgn", k.NOISE_BATCH: "batch"}.get(kind, "noiseless")
 
     def set_batch_noise(self, process, measurement):
         """SetNoise(BatchNoise{process, measurement}) (noise.go:67-106); Q and R become zero, as BatchNoise reports them."""
@@ -390,6 +410,26 @@ class FilterBatch:
 
     def synchronize(self):
         k.check(k.lib().kb_synchronize(self._h))
+
+    def string(self, filt=0):
+        """The filter's String() (vanilla.go:76-78, squareroot.go:65-67, information.go:96-98, hybrid.go:63-65) for filter
+        `filt` of the batch, with its noise's String() (noise.go:62-64, :104-106, :162-164); see strfmt.py."""
+        from . import strfmt
+        name = {k.VANILLA: "vanilla", k.VANILLA_PREDICT: "vanilla", k.SQUAREROOT: "squareroot", k.INFORMATION: "information",
+                k.HYBRID: "hybrid"}.get(self.kind)
+        if name is None:
+            return "gokalman_amd.FilterBatch(kind=%d, n=%d, N=%d)" % (self.kind, self.n, self.N)   # SRIF, BatchKF: no String() in the reference
+        noise = strfmt.noise_string(self._noise_name, self.get(k.Q, filt, 1)[0], self.get(k.R, filt, 1)[0])
+        if name == "hybrid":
+            return strfmt.filter_string(name, None, None, None, noise, self.step())
+        F = self.get(k.F, filt, 1)[0]
+        if name == "information":
+            F = np.linalg.inv(F)   # information.go:96 prints the cached inverse
+        G = self.get(k.G, filt, 1)[0] if self.m > 0 else None
+        return strfmt.filter_string(name, F, G, self.get(k.H, filt, 1)[0], noise)
+
+    def __str__(self):
+        return self.string(0)
 
     def noise_sample(self, filt, epoch, step, which, size):
         out = np.zeros(size, dtype=np.float64)

@@ -16,8 +16,11 @@
 // numerical failure of one Update: the filter keeps its previous estimate and the next call runs normally).
 // Update / Predict return an Estimate VALUE that owns its data (see class Estimate).
 #pragma once
+#include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -59,6 +62,53 @@ inline bool IsNil(const Matrix &m) {                               // helper.go:
     return true;
 }
 
+// String() support.  The reference prints through gonum's mat64.Formatted(m, mat64.Prefix(p)) with fmt's %v: box-drawing
+// brackets (square ones for a single row), every element right-aligned to the widest, two spaces between columns, the
+// prefix in front of every line but the first.  Restated from gonum's documented behaviour (gonum is not available here:
+// byte equality with a Go run is unverified); the labels, order and prefixes are the reference's format strings.
+inline std::string go_v(double x) {   // fmt %v of a float64: shortest round-trip digits, %e form for exponents < -4 or >= 21
+    if (std::isnan(x)) return "NaN";
+    if (std::isinf(x)) return x > 0 ? "+Inf" : "-Inf";
+    if (x == 0.0) return std::signbit(x) ? "-0" : "0";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), std::fabs(x), std::chars_format::scientific);
+    std::string sci(buf, r.ptr);   // d[.ddd]e[+-]XX
+    const size_t e = sci.find('e');
+    std::string digits = sci.substr(0, e);
+    digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+    const int e10 = std::stoi(sci.substr(e + 1));
+    const std::string sign = x < 0 ? "-" : "";
+    if (e10 < -4 || e10 >= 21) {
+        char eb[16];
+        std::snprintf(eb, sizeof(eb), "e%c%02d", e10 < 0 ? '-' : '+', std::abs(e10));
+        return sign + digits.substr(0, 1) + (digits.size() > 1 ? "." + digits.substr(1) : "") + eb;
+    }
+    if (e10 >= 0) {
+        if ((int)digits.size() <= e10 + 1) return sign + digits + std::string((size_t)(e10 + 1 - (int)digits.size()), '0');
+        return sign + digits.substr(0, (size_t)e10 + 1) + "." + digits.substr((size_t)e10 + 1);
+    }
+    return sign + "0." + std::string((size_t)(-e10 - 1), '0') + digits;
+}
+inline std::string Formatted(const Matrix &m, const std::string &prefix, int64_t filter = 0) {
+    if (m.rows == 0 || m.cols == 0 || m.data.empty()) return "<nil>";
+    const int64_t f = m.shared() ? 0 : filter;
+    std::vector<std::string> cells;
+    size_t width = 0;
+    for (int i = 0; i < m.rows; i++)
+        for (int j = 0; j < m.cols; j++) { cells.push_back(go_v(m.At(i, j, f))); width = std::max(width, cells.back().size()); }
+    std::string out;
+    for (int i = 0; i < m.rows; i++) {
+        if (i) out += "\n" + prefix;
+        out += m.rows == 1 ? "[" : (i == 0 ? "\u23a1" : (i == m.rows - 1 ? "\u23a3" : "\u23a2"));
+        for (int j = 0; j < m.cols; j++) {
+            const std::string &c = cells[(size_t)i * m.cols + j];
+            out += (j ? "  " : "") + std::string(width - c.size(), ' ') + c;
+        }
+        out += m.rows == 1 ? "]" : (i == 0 ? "\u23a4" : (i == m.rows - 1 ? "\u23a6" : "\u23a5"));
+    }
+    return out;
+}
+
 // noise.go:13-20.  Process/Measurement sampling happens on the device; the host object carries Q, R
 // and which implementation to use.
 struct Noise {
@@ -67,6 +117,10 @@ struct Noise {
     uint64_t seed = 0;
     const Matrix &ProcessMatrix() const { return Q; }
     const Matrix &MeasurementMatrix() const { return R; }
+    std::string String() const {   // noise.go:62-64, :104-106, :162-164
+        if (kind == KB_NOISE_BATCH) return "BatchNoise";
+        return std::string(kind == KB_NOISE_AWGN ? "AWGN" : "Noiseless") + "{\nQ=" + Formatted(Q, "  ") + "\nR=" + Formatted(R, "  ") + "}\n";
+    }
 };
 inline Noise NewNoiseless(Matrix Q, Matrix R) { return Noise{std::move(Q), std::move(R), KB_NOISE_NOISELESS, 0}; }       // noise.go:29-37
 inline Noise NewAWGN(Matrix Q, Matrix R, uint64_t seed = 0) { return Noise{std::move(Q), std::move(R), KB_NOISE_AWGN, seed}; }  // noise.go:117-121
@@ -189,6 +243,20 @@ class Estimate {
         return out;
     }
     std::vector<uint8_t> IsWithin2σ() const { return IsWithinNσ(2); }
+    // <Kind>Estimate.String() of filter f (vanilla.go:276-284, squareroot.go:347-355, hybrid.go:300-308; information.go:318-325
+    // has no gain, srif.go:283-289 neither gain nor innovation); members the batch does not keep print as Go's nil
+    std::string String(int64_t f = 0) const {
+        auto opt = [&](auto getter, const char *prefix) {
+            try { return Formatted((this->*getter)(), prefix, f); } catch (const Error &) { return std::string("<nil>"); }
+        };
+        const std::string s = opt(&Estimate::State, "  "), y = opt(&Estimate::Measurement, "  "), P = opt(&Estimate::Covariance, "  "),
+                          Pm = opt(&Estimate::PredCovariance, "   ");
+        const int kind = b_ ? b_->kind() : KB_VANILLA;
+        if (kind == KB_SRIF) return "{\ns=" + s + "\ny=" + y + "\nP=" + P + "\nP-=" + Pm + "\n}";
+        const std::string i = opt(&Estimate::Innovation, "  ");
+        if (kind == KB_INFORMATION) return "{\ns=" + s + "\ny=" + y + "\nP=" + P + "\nP-=" + Pm + "\ni=" + i + "\n}";
+        return "{\ns=" + s + "\ny=" + y + "\nP=" + P + "\nK=" + opt(&Estimate::Gain, "  ") + "\nP-=" + Pm + "\ni=" + i + "\n}";
+    }
 
    private:
     static std::shared_ptr<const Snapshot> download(Batch &b, bool clear_status) {
@@ -264,6 +332,10 @@ class LDKF {
         b_->set(KB_R, n.R, n.R.rows);
     }
     void Reset() { check(kb_reset(b_->handle())); }
+    // vanilla.go:76-78, squareroot.go:65-67 (filter f of the batch; shared matrices print as they were given)
+    std::string String(int64_t f = 0) const {
+        return "F=" + Formatted(F_, "  ", f) + "\nG=" + Formatted(G_, "  ", f) + "\nH=" + Formatted(H_, "  ", f) + "\n" + noise_.String();
+    }
     int64_t Step() const { return kb_step(b_->handle()); }
     std::shared_ptr<Batch> batch() const { return b_; }
 

@@ -37,6 +37,14 @@ int main() {
         print_vec("x1", est1.State()); print_vec("P1", est1.Covariance());
         print_vec("x2", est2.State()); print_vec("P2", est2.Covariance());
         print_vec("K2", est2.Gain()); print_vec("innov2", est2.Innovation()); print_vec("Ppred2", est2.PredCovariance());
+        // String() of the estimate and of the filter (vanilla.go:276-284, :76-78), hex so that the line format stays one per name
+        auto print_hex = [](const char *name, const std::string &v) {
+            std::printf("%s ", name);
+            for (unsigned char c : v) std::printf("%02x", c);
+            std::printf("\n");
+        };
+        print_hex("str_est2", est2.String());
+        print_hex("str_kf", kf->String());
         // a singular step: H = 0 and R = 0  =>  S = H P H' + R = 0, Inverse fails (vanilla.go:162-167)
         kf->SetMeasurementMatrix(Hzero);
         kf->SetNoise(zeroR);

@@ -133,3 +133,36 @@ def test_batch_noise_zeroes_q_and_r():
     assert np.max(np.abs(est.covariance() - np.array(Ps))) <= 1e-9
     with pytest.raises(ga.KalmanError, match="dimensions must agree"):
         b.set_batch_noise(np.zeros((4, 3)), meas)
+
+
+@pytest.mark.gpu
+def test_string_forms_follow_the_reference():
+    """kf.String() / est.String() (vanilla.go:76-78, :276-284; srif.go:283-289; hybrid.go:63-65; noise.go:62-64): labels,
+    order and prefixes are the reference's format strings, the values are the estimate's own."""
+    import numpy as np
+    import gokalman_amd as ga
+    from gokalman_amd import _capi as k, strfmt
+    F, H = np.array([[1, 0.1], [0, 1.0]]), np.array([[1.0, 0]])
+    Q, R = np.diag([1e-3, 1e-3]), np.array([[0.05]])
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, np.array([0.5, -0.2]), 4.0 * np.eye(2), F, None, H, Q, R, flags=k.FLAG_FULL_ESTIMATE)
+    est = b.update(np.array([0.7]), snapshot=True)
+    s = str(est)
+    assert s == strfmt.estimate_string("vanilla", est.state()[0], est.measurement()[0], est.covariance()[0], est.gain()[0],
+                                       est.pred_covariance()[0], est.innovation()[0])
+    assert s.startswith("{\ns=⎡") and "\nK=⎡" in s and "\nP-=⎡" in s and s.endswith("]\n}")
+    kf = str(b)
+    assert kf.startswith("F=⎡  1  0.1⎤\n  ⎣  0    1⎦\nG=<nil>\nH=[1  0]\nNoiseless{\nQ=⎡0.001      0⎤\n  ⎣    0  0.001⎦\nR=[0.05]}\n")
+    # state-only batch: the extras print as Go's nil
+    b2 = ga.FilterBatch.new_ldkf(k.VANILLA, np.array([0.5, -0.2]), 4.0 * np.eye(2), F, None, H, Q, R)
+    s2 = str(b2.update(np.array([0.7]), snapshot=True))
+    assert "\ny=<nil>\n" in s2 and "\nK=<nil>\n" in s2
+    # SRIF estimate: no gain / innovation lines (srif.go:283-289); HybridKF prints its step counter
+    n, p = 6, 2
+    srif = ga.FilterBatch(k.SRIF, n, p, 0, 1, flags=k.FLAG_FULL_ESTIMATE)
+    srif.set(k.X, np.zeros(n), 1); srif.set(k.P, np.diag([10.0, 10, 10, 1, 1, 1]), 2); srif.set(k.R, np.diag([1e-2, 1e-3]), 2, p_rows=p); srif.init()
+    srif.prepare(np.eye(n), np.array([[1, 0, 0, 0.5, 0, 0], [0, 1, 0, 0, 0.5, 0.0]]))
+    ss = str(srif.update_nl(np.array([0.1, 0.2]), np.array([0.0, 0.0]), snapshot=True))
+    assert "\nK=" not in ss and "\ni=" not in ss and "\nP-=" in ss
+    hyb = ga.FilterBatch(k.HYBRID, n, p, 0, 1)
+    hyb.set(k.X, np.zeros(n), 1); hyb.set(k.P, np.diag([10.0, 10, 10, 1, 1, 1]), 2); hyb.set(k.R, np.diag([1e-6, 1e-6]), 2, p_rows=p); hyb.init()
+    assert str(hyb).startswith("HybridKF [k=0]\nNoiseless{")
