@@ -24,7 +24,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                   exceed 1 because a SymDense carries only its upper triangle.
   out_of_cache -- the same kernel on a batch whose state block cannot stay in the Infinity Cache.
   fused        -- the caller loop inside one launch (VALU-issue-bound), with its issue-rate roofline.
-  extra.mc / extra.hybrid_ekf -- config D sharded over the same ranks.
+  extra.mc / extra.hybrid_ekf -- config D sharded over the same ranks; extra.squareroot (config C) and extra.srif_fp32
+  (config E) likewise, one shard per rank.
   cpu_baseline -- the CPU oracle (reference-order C restatement of vanilla.go:128-220, the
                   reference's Go toolchain is absent) timed on this host's cores on a bounded
                   sample of the same workload.  A reported baseline, not the target.
@@ -57,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")
     ap.add_argument("--mc-steps", type=int, default=1086)
     ap.add_argument("--hybrid-filters", type=int, default=1 << 20, help="Hybrid EKF filters per GPU for extra.hybrid_ekf (0 = skip)")
+    ap.add_argument("--sqrt-filters", type=int, default=1 << 20, help="SquareRoot 6/3 filters per GPU for extra.squareroot, config C (0 = skip)")
+    ap.add_argument("--srif-filters", type=int, default=1 << 18, help="SRIF 12/6 fp32 filters per GPU for extra.srif_fp32, config E (0 = skip)")
     ap.add_argument("--init-dist", action="store_true",
                     help="initialise torch.distributed and run every collective even for ONE rank (exercises the RCCL code path on a single GPU)")
     ap.add_argument("--dist-backend", default="nccl",
@@ -209,6 +212,15 @@ def main():
         barrier()
         return local, ev0.elapsed_time(ev1) / steps
 
+    def warm_clocks(ms=60.0):
+        """Untimed load before a timed region: after the host-side set-up the GPU sits at idle clocks and needs ~25 ms of
+        sustained work to come back (a 256k-filter SRIF step measured 124 us in the first 25 steps of a cold process, 86 us
+        from step 250 on).  Runs the resident headline batch; never inside a timed region."""
+        for t in range(max(1, int(ms / 0.17 * (1 << 20) / max(N, 1 << 14)))):
+            b.update_dev(ptrs[t % POOL], N)
+        b.synchronize()
+
+    warm_clocks()
     local_s, kernel_ms = timed_steps(b, kstream, ptrs, N, args.steps, args.warmup)
     wall_s, per_rank_s = max_over_ranks(local_s)
     nbad = int(np.count_nonzero(b.status()))
@@ -245,8 +257,7 @@ def main():
         except Exception:
             pass
         del yy
-    del b, y_dev
-    torch.cuda.empty_cache()
+    torch.cuda.empty_cache()   # (the headline batch stays: warm_clocks() runs it before every later timed region)
 
     # ---- extra: the same kernel with the state block far outside the 256 MiB Infinity Cache -------------------------
     ooc = None
@@ -258,7 +269,8 @@ def main():
                                      tile(d["Q"]), tile(d["R"]), device=local_rank)
         y2 = torch.from_numpy(np.ascontiguousarray(np.concatenate([d["y"][0]] * reps_n, axis=0)[:M].T)).to(dev)  # [p][M]
         s2 = torch.cuda.ExternalStream(b2.stream(), device=dev)
-        for _ in range(3):
+        warm_clocks()
+        for _ in range(5):
             b2.update_dev(y2.data_ptr(), M)
         b2.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -287,6 +299,7 @@ def main():
                                      nfilters=args.mc_runs, device=local_rank, noise=k.NOISE_AWGN, seed=2016)
         first = rank * args.mc_runs  # a run's noise depends only on its global index
         ga.new_monte_carlo_runs(args.mc_runs, 4, 2, np.zeros((1, 2)), kf, first_run=first)  # warm-up
+        warm_clocks()
         barrier()
         t0 = time.perf_counter()
         mc = ga.new_monte_carlo_runs(args.mc_runs * world, args.mc_steps, 2, np.zeros((1, 2)), kf, first_run=first,
@@ -322,7 +335,8 @@ def main():
         def hstep():
             k.check(k.lib().kb_prepare_dev(hb._h, Phi.data_ptr(), Ht.data_ptr(), M))
             k.check(k.lib().kb_update_nl_dev(hb._h, real.data_ptr(), comp.data_ptr(), M))
-        for _ in range(3):
+        warm_clocks()
+        for _ in range(10):
             hstep()
         hb.synchronize()
         barrier()
@@ -345,6 +359,69 @@ def main():
                                "roofline": rl.hbm_roofline(hms, M, rl.algorithmic_bytes("hybrid", hn, hp), rl.moved_bytes("hybrid", hn, hp)),
                                "filters_with_error_status": int(hbad.item())}
         del hb, Phi, Ht, real, comp
+
+    # ---- extra: configs C (SquareRoot 6/3 fp64 on the headline's batch) and E (SRIF 12/6 fp32), one shard per rank --------
+    def timed_leg(batch, fn, reps):
+        stream = torch.cuda.ExternalStream(batch.stream(), device=dev)
+        warm_clocks()
+        for _ in range(10):
+            fn()
+        batch.synchronize()
+        barrier()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a0.record(stream)
+        for _ in range(reps):
+            fn()
+        a1.record(stream)
+        batch.synchronize()
+        leg_s, _ = max_over_ranks(time.perf_counter() - t0)
+        bad = torch.tensor([float(np.count_nonzero(batch.status()))], dtype=torch.float64, device=coll_dev)
+        if use_dist:
+            dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        return leg_s, a0.elapsed_time(a1) / reps, int(bad.item())
+
+    if args.sqrt_filters > 0:
+        M = args.sqrt_filters
+        dq = synth.linear_batch(M, n, p, 1, seed=synth.SEED + 1000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)  # [p][M]
+        sq = ga.FilterBatch.new_ldkf(k.SQUAREROOT, dq["x0"], dq["P0"], dq["F"], None, dq["H"], dq["Q"], dq["R"], device=local_rank)
+        K4 = 50
+        q_s, qms, qbad = timed_leg(sq, lambda: sq.update_dev(yq.data_ptr(), M), K4)
+        extra["squareroot"] = {"config": "configs[2] C: %d SquareRoot 6/3 fp64 filters per GPU, same synthetic batch as the headline" % M,
+                               "filters_total": world * M, "steps": K4, "value": world * M * K4 / q_s,
+                               "unit": "filter-update steps/s (whole job)", "kernel_ms": qms,
+                               "roofline": rl.hbm_roofline(qms, M, rl.algorithmic_bytes("squareroot", n, p), rl.moved_bytes("squareroot", n, p)),
+                               "filters_with_error_status": qbad}
+        del sq, yq
+    if args.srif_filters > 0:
+        M = args.srif_filters
+        sn, sp = 12, 6
+        rng = np.random.default_rng(5 + rank)
+        x0 = rng.standard_normal((M, sn))
+        P0 = np.zeros((M, sn, sn)); P0[:, np.arange(sn), np.arange(sn)] = [10.0] * 6 + [1.0] * 6
+        R = np.zeros((M, sp, sp)); R[:, np.arange(sp), np.arange(sp)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(M, sp)))
+        sb = ga.FilterBatch(k.SRIF, sn, sp, 0, M, dtype=k.F32, device=local_rank)
+        sb.set(k.X, x0, 1); sb.set(k.P, P0, 2); sb.set(k.R, R, 2, p_rows=sp); sb.init()
+        g = torch.Generator(device=dev)
+        g.manual_seed(11 + rank)
+        Phi = (torch.eye(sn, dtype=torch.float32, device=dev).reshape(sn * sn, 1)
+               + 1e-2 * torch.randn(sn * sn, M, dtype=torch.float32, device=dev, generator=g)).contiguous()
+        Ht = torch.randn(sp * sn, M, dtype=torch.float32, device=dev, generator=g)
+        real = torch.randn(sp, M, dtype=torch.float32, device=dev, generator=g)
+        comp = real + 1e-2 * torch.randn(sp, M, dtype=torch.float32, device=dev, generator=g)
+
+        def sstep():
+            k.check(k.lib().kb_prepare_dev(sb._h, Phi.data_ptr(), Ht.data_ptr(), M))
+            k.check(k.lib().kb_update_nl_dev(sb._h, real.data_ptr(), comp.data_ptr(), M))
+        K5 = 50
+        r_s, rms, rbad = timed_leg(sb, sstep, K5)
+        extra["srif_fp32"] = {"config": "configs[4] E: %d SRIF 12/6 fp32 filters per GPU, per-step Phi/Htilde read in place (kb_prepare_dev + kb_update_nl_dev)" % M,
+                              "filters_total": world * M, "steps": K5, "value": world * M * K5 / r_s,
+                              "unit": "filter-update steps/s (whole job)", "kernel_ms": rms, "dtype": "f32",
+                              "roofline": rl.hbm_roofline(rms, M, 576 * 4, rl.moved_bytes("srif_pair", sn, sp, 4)),
+                              "filters_with_error_status": rbad}
+        del sb, Phi, Ht, real, comp
 
     if rank == 0:
         value = total_filter_steps / wall_s

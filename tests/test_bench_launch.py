@@ -44,7 +44,8 @@ def test_world_size_mismatch_is_refused():
 
 
 SMALL = ["--steps", "30", "--warmup", "5", "--filters", "65536", "--fused-steps", "0", "--ooc-filters", "0",
-         "--mc-runs", "16384", "--mc-steps", "64", "--hybrid-filters", "16384", "--no-cpu-baseline"]
+         "--mc-runs", "16384", "--mc-steps", "64", "--hybrid-filters", "16384", "--sqrt-filters", "16384", "--srif-filters", "8192",
+         "--no-cpu-baseline"]
 
 
 @pytest.mark.gpu
@@ -67,13 +68,16 @@ def test_two_ranks_self_launched_over_gloo_on_one_gpu():
     for a, b in zip(mc1["stddev_last"], mc2["stddev_last"]):
         assert abs(a - b) <= 0.05 * abs(a)
     assert two["extra"]["hybrid_ekf"]["filters_total"] == 2 * 16384
+    assert two["extra"]["squareroot"]["filters_total"] == 2 * 16384 and two["extra"]["squareroot"]["filters_with_error_status"] == 0
+    assert two["extra"]["srif_fp32"]["filters_total"] == 2 * 8192 and two["extra"]["srif_fp32"]["filters_with_error_status"] == 0
     assert two["roofline"]["frac"] <= 1.0 and one["roofline"]["frac"] <= 1.0
 
 
 @pytest.mark.gpu
 def test_bench_line_roofline_is_physical():
     out = _json_line(_run(["--steps", "50", "--warmup", "5", "--ooc-filters", "0", "--mc-runs", "0", "--hybrid-filters", "0",
-                           "--no-cpu-baseline"]).stdout)
+                           "--srif-filters", "0", "--no-cpu-baseline"]).stdout)
+    assert 0.0 < out["extra"]["squareroot"]["roofline"]["frac"] <= 1.0   # config C on the default 1M filters
     roof = out["roofline"]
     assert 0.0 < roof["frac"] <= 1.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
