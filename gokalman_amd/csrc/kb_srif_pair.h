@@ -186,28 +186,35 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     // to LDS, which is what the 256-register budget allows (whitening first would need 39 more accumulators on top).
     T Hc[NM * HS], Lw[tri(NM)], yv[NM];   // Htilde, this half's columns: Hc[m * HS + cs] = Htilde[m][2 cs + l]
     [[maybe_unused]] T yreal[NM], yown[HM];
-    {
-        UniformCursor<T> cur(EXT ? eh : mo);   // walks Htilde two elements at a time
+    auto load_meas = [&]() {
+        {
+            UniformCursor<T> cur(EXT ? eh : mo);   // walks Htilde two elements at a time
 #pragma unroll
-        for (int m = 0; m < NM; m++)
+            for (int m = 0; m < NM; m++)
 #pragma unroll
-            for (int cs = 0; cs < HS; cs++) {
-                if constexpr (EXT) { Hc[m * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
-                else Hc[m * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
-            }
-    }
-#pragma unroll
-    for (int e = 0; e < tri(NM); e++) Lw[e] = ld_mo(a.L.mo_LR + e);   // QUIRK srif.go:48: chol_L(R), not its inverse
-    {
-        UniformCursor<T> cr(yr), cc(yc);
-#pragma unroll
-        for (int r = 0; r < NM; r++) {
-            const T re = cr.load_nt(bx), co = cc.load_nt(bx);
-            cr.advance(a.y_es); cc.advance(a.y2_es);
-            yv[r] = re - co;   // srif.go:143-144
-            if constexpr (FULL) yreal[r] = re;
+                for (int cs = 0; cs < HS; cs++) {
+                    if constexpr (EXT) { Hc[m * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
+                    else Hc[m * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
+                }
         }
-    }
+#pragma unroll
+        for (int e = 0; e < tri(NM); e++) Lw[e] = ld_mo(a.L.mo_LR + e);   // QUIRK srif.go:48: chol_L(R), not its inverse
+        {
+            UniformCursor<T> cr(yr), cc(yc);
+#pragma unroll
+            for (int r = 0; r < NM; r++) {
+                const T re = cr.load_nt(bx), co = cc.load_nt(bx);
+                cr.advance(a.y_es); cc.advance(a.y2_es);
+                yv[r] = re - co;   // srif.go:143-144
+                if constexpr (FULL) yreal[r] = re;
+            }
+        }
+    };
+    // fp64 (one wave per SIMD, nothing else hides its latency): the largest HBM stream, Phi, is requested first -- 3.5 % faster
+    // than with it last; in fp32 the other order is 1 % ahead (b and R, the Infinity-Cache hits State(prev) starts from, arrive earlier)
+    constexpr bool PHI_FIRST = sizeof(T) == 8 && !DENSE;
+    if constexpr (PHI_FIRST) load_phi();
+    load_meas();
     [[maybe_unused]] T bown[HS];   // b of the own rows
     if constexpr (DENSE) {
 #pragma unroll
@@ -225,7 +232,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         for (int s = 0; s < HS; s++)
 #pragma unroll
             for (int j = 0; j < NS; j++) A.set(s, j, j >= 2 * s ? ld_row(NS + 2 * s * NS + j) : T(0));   // (2 s + 1, 2 s) is a stored zero
-        load_phi();
+        if constexpr (!PHI_FIRST) load_phi();
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- State(prev) = R^-1 b (srif.go:223-234) -------------------------------------------------------------------
