@@ -26,15 +26,31 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
     const T *yr = (const T *)a.y + tile * a.y_ts + lane;
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
     T x[NS], P[TR], F[NS * NS];
+    const int64_t fi = tile * KB_TILE + lane;
+    const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
+    const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
+    // Request order "slowest first" (kb_vanilla_reg.h): Phi, Htilde, R and the observations are HBM streams, x and P are
+    // Infinity-Cache hits and go last.  (The SNC / Predict instantiation reads Htilde, R and the observations where it needs them.)
+#pragma unroll
+    for (int e = 0; e < NS * NS; e++) F[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
+    T H[NM * NS], R[tri(NM)], real[NM], yv[NM];
+    if constexpr (!SNCP) {
+#pragma unroll
+        for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
+#pragma unroll
+        for (int e = 0; e < tri(NM); e++) R[e] = ldnt(mo, a.L.mo_R + e);
+#pragma unroll
+        for (int r = 0; r < NM; r++) {
+            real[r] = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
+            const T cv = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
+            yv[r] = real[r] - cv;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
 #pragma unroll
     for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
-    const int64_t fi = tile * KB_TILE + lane;
-    const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
-    const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
-#pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
+    __builtin_amdgcn_sched_barrier(0);
     // :114-116 PBar = Phi P Phi^T (upper triangle)
     T Pm[TR];
 #pragma unroll
@@ -114,11 +130,12 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
         }
         return;
     }
-    T H[NM * NS], R[tri(NM)];
+    if constexpr (SNCP) {
 #pragma unroll
-    for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
+        for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
 #pragma unroll
-    for (int e = 0; e < tri(NM); e++) R[e] = ldnt(mo, a.L.mo_R + e);
+        for (int e = 0; e < tri(NM); e++) R[e] = ldnt(mo, a.L.mo_R + e);
+    }
     // :146-153 K = PBar H^T (H PBar H^T + R)^-1
     T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
 #pragma unroll
@@ -142,12 +159,14 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
     unsigned err = inverse_lu<T, NM>(S, Si) ? KB_ST_SINGULAR : 0u;
     smm_nn<T, NS, NM, NM>(PHt, Si, K);
     // :156-173
-    T yv[NM], real[NM], innov[NM], xn[NS];
+    T innov[NM], xn[NS];
 #pragma unroll
     for (int r = 0; r < NM; r++) {
-        real[r] = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
-        const T cv = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
-        yv[r] = real[r] - cv;
+        if constexpr (SNCP) {
+            real[r] = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
+            const T cv = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
+            yv[r] = real[r] - cv;
+        }
         innov[r] = T(0);
     }
     if constexpr (EKF) {

@@ -36,17 +36,19 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))) + lane;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
+    // request order "slowest first" (kb_vanilla_reg.h): F^-1 is an HBM stream, i and I are Infinity-Cache hits
     T iv[NS], I[TR], Fi[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_Finv + i * rn + j) : T(0);
 #pragma unroll
     for (int i = 0; i < NS; i++) iv[i] = (i < rn) ? ldt(st, i) : T(0);
 #pragma unroll
     for (int j = 0; j < NS; j++)
 #pragma unroll
         for (int i = 0; i <= j; i++) I[symi(i, j)] = (j < rn) ? ldt(st, rn + symi(i, j)) : T(0);
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_Finv + i * rn + j) : T(0);
+    __builtin_amdgcn_sched_barrier(0);
     // :163-165 zk = Finv^T (I Finv), one column at a time: column j of I Finv lives only until column j of zk is formed
     // (the whole intermediate product would put 3 n^2 + n(n+1)/2 doubles in registers at once)
     T zk[NS * NS];

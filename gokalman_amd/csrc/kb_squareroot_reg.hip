@@ -45,17 +45,19 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
 
+    // request order "slowest first" (kb_vanilla_reg.h): F is an HBM stream, x and S are Infinity-Cache hits
     T x[NS], S[TR], F[NS * NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_F + i * rn + j) : T(0);
 #pragma unroll
     for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldt(st, i) : T(0);
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int k2 = 0; k2 <= i; k2++) S[symi(k2, i)] = (i < rn) ? ldt(st, rn + symi(k2, i)) : T(0);  // S[i][k], k <= i, at symi(k, i)
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_F + i * rn + j) : T(0);
+    __builtin_amdgcn_sched_barrier(0);
 
     // :139-147 x- = F x [+ G u]
     T xm[NS];
