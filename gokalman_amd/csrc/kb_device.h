@@ -29,6 +29,10 @@ template <typename T>
 __device__ __forceinline__ T ldnt(const T *p, int e) { return __builtin_nontemporal_load(p + (int64_t)e * KB_TILE); }  // read-once streams
 template <typename T>
 __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] = v; }
+// write-once outputs nobody reads on the device (the Estimate extras: P-, K, innovation, yhat): non-temporal, so that they do
+// not push the state block out of the Infinity Cache
+template <typename T>
+__device__ __forceinline__ void stnt(T *p, int e, T v) { __builtin_nontemporal_store(v, p + (int64_t)e * KB_TILE); }
 
 // pin(v): an empty asm that "modifies" v.  The value must exist in a VGPR at this point of the program, so LLVM can neither
 // sink the computation that produces it into a later basic block (machine sinking does that across the data-dependent

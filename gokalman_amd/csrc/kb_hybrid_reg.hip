@@ -119,13 +119,13 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
             if constexpr (FULL) {
                 T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll
-                for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
+                for (int e = 0; e < TR; e++) stnt(es, a.L.es_ppred + e, Pm[e]);
 #pragma unroll
                 for (int i = 0; i < NS; i++)
 #pragma unroll
-                    for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, T(0));
+                    for (int c = 0; c < NM; c++) stnt(es, a.L.es_gain + i * a.pmax + c, T(0));
 #pragma unroll
-                for (int r = 0; r < NM; r++) { stt(es, a.L.es_innov + r, T(0)); stt(es, a.L.es_yhat + r, T(0)); stt(es, a.L.es_dobs + r, T(0)); }
+                for (int r = 0; r < NM; r++) { stnt(es, a.L.es_innov + r, T(0)); stnt(es, a.L.es_yhat + r, T(0)); stnt(es, a.L.es_dobs + r, T(0)); }
             }
         }
         return;
@@ -247,13 +247,13 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
         if constexpr (FULL) {
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll
-            for (int e = 0; e < TR; e++) stt(es, a.L.es_ppred + e, Pm[e]);
+            for (int e = 0; e < TR; e++) stnt(es, a.L.es_ppred + e, Pm[e]);
 #pragma unroll
             for (int i = 0; i < NS; i++)
 #pragma unroll
-                for (int c = 0; c < NM; c++) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                for (int c = 0; c < NM; c++) stnt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
-            for (int r = 0; r < NM; r++) { stt(es, a.L.es_innov + r, innov[r]); stt(es, a.L.es_yhat + r, real[r]); stt(es, a.L.es_dobs + r, yv[r]); }
+            for (int r = 0; r < NM; r++) { stnt(es, a.L.es_innov + r, innov[r]); stnt(es, a.L.es_yhat + r, real[r]); stnt(es, a.L.es_dobs + r, yv[r]); }
         }
     }
     if (active && err) atomicOr(a.status + tile * KB_TILE + lane, err);

@@ -148,10 +148,10 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             for (int i = 0; i < NS; i++)
 #pragma unroll
                 for (int j = i; j < NS; j++)
-                    if (j < rn) stt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
+                    if (j < rn) stnt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
 #pragma unroll
             for (int r = 0; r < NM; r++)
-                if (r < rp) stt(es, a.L.es_yhat + r, yhat[r]);
+                if (r < rp) stnt(es, a.L.es_yhat + r, yhat[r]);
         }
     }
 #pragma unroll
@@ -214,10 +214,10 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             for (int i = 0; i < NS; i++)
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (i < rn && c < rp) stt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
+                    if (i < rn && c < rp) stnt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
 #pragma unroll
             for (int r = 0; r < NM; r++)
-                if (r < rp) stt(es, a.L.es_innov + r, innov[r]);
+                if (r < rp) stnt(es, a.L.es_innov + r, innov[r]);
         }
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);

@@ -473,11 +473,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
 #pragma unroll
             for (int s = 0; s < HS; s++)
 #pragma unroll
-                for (int j = 0; j < NS; j++) es[(unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow] = A.get(s, j);
+                for (int j = 0; j < NS; j++) __builtin_nontemporal_store(A.get(s, j), es + ((unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow));
 #pragma unroll
             for (int t = 0; t < HM; t++) {
-                es[(unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl] = yown[t];
-                es[(unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl] = A.get(HS + t, NS);
+                __builtin_nontemporal_store(yown[t], es + ((unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl));
+                __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl));
             }
         }
     }
@@ -571,7 +571,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     if constexpr (FULL) {
         if (ok) {
 #pragma unroll
-            for (int t = 0; t < HM; t++) es[(unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl] = A.get(HS + t, NS);
+            for (int t = 0; t < HM; t++) __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl));
         }
     }
     if constexpr (DENSE) {
