@@ -436,3 +436,25 @@ def test_batch_least_squares_normal_equations_vs_oracle():
     c.prepare(np.eye(n), Hs[0, 0]); c.update_nl(real[0, 0], comp[0, 0])
     c.get(k.COVAR)
     assert (c.status() & k.ST_SINGULAR).all()
+
+
+@pytest.mark.gpu
+def test_chisquare_means_are_p_and_n_for_a_consistent_filter_at_scale():
+    """The size-independent property of chisquare.go:16-95: with the filter's model equal to the truth's, NIS ~ chi-square(p)
+    and NEES ~ chi-square(n), so the per-step means over the runs are p and n.  2^16 runs: standard error sqrt(2 k / runs)
+    = 0.008 (p = 2) / 0.011 (n = 4).  Two reference behaviours shape the set-up: the Monte-Carlo truth starts AT x0
+    (montecarlo.go:92-119), so P0 ~ 0; and its measurement is yhat_k = H x_{k-1} + v_k (vanilla.go:155-157: the PREVIOUS
+    state), a one-step delay the filter's model does not have -- with a moving state it inflates the first NIS means by
+    (H (x_k - x_{k-1}))^2 / R (measured: 2.27 at step 0 for 0.03 of motion per step against sigma = 0.06), so the system here
+    is at rest up to its process noise."""
+    n, p, runs, steps, dt = 4, 2, 1 << 16, 40, 0.1
+    F = np.eye(n); F[0, 2] = F[1, 3] = dt
+    H = np.zeros((p, n)); H[0, 0] = H[1, 1] = 1.0
+    Q = 1e-6 * np.array([[dt ** 3 / 3, 0, dt ** 2 / 2, 0], [0, dt ** 3 / 3, 0, dt ** 2 / 2], [dt ** 2 / 2, 0, dt, 0], [0, dt ** 2 / 2, 0, dt]])
+    R = np.diag([4e-3, 9e-3])
+    x0, P0 = np.array([1.0, -0.5, 0.0, 0.0]), 1e-12 * np.eye(n)
+    truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, x0, P0, F, None, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=5)
+    kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, None, H, Q, R, nfilters=runs)
+    nis, nees = ga.new_chi_square(kf, truth, steps, np.zeros((1, 1)), replay_last_mc=False)
+    assert np.all(np.abs(nis - p) < 6 * np.sqrt(2 * p / runs)), nis
+    assert np.all(np.abs(nees[1:] - n) < 6 * np.sqrt(2 * n / runs) + 0.02), nees   # step 0: P+ is still rank-deficient from P0 ~ 0
