@@ -269,3 +269,56 @@ def test_many_handles_with_big_shape_generic_steps_do_not_exhaust_scratch():
     torch.cuda.synchronize()
     held = (free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30
     assert held < 24.0, "scratch retained by the process: %.1f GiB" % held    # one queue's worth (<= 15.3 GiB) + the batches
+
+
+@pytest.mark.parametrize("kind,flags", [(k.SQUAREROOT, 0), (k.INFORMATION, k.FLAG_INFO_FROM_STATE)])
+def test_baseline_size_1m_filters_properties_other_kinds(kind, flags):
+    """Config C's size (1M filters) for SquareRoot and Information: beyond what the oracle replays, so size-independent
+    properties -- status-clean, finite, positive covariance diagonals, and shard invariance: the last 4096 filters of the
+    1M batch are bit-equal to a 4096-filter batch fed the same rows (the oracle-checked size, tests/test_kinds_gpu.py)."""
+    N, small = 1 << 20, 4096
+    base = synth.linear_batch(small, 6, 3, 3)
+    rep = N // small
+    big = {kk: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if kk != "y" else np.tile(v, (1, rep, 1))) for kk, v in base.items()}
+    b = ga.FilterBatch.new_ldkf(kind, big["x0"], big["P0"], big["F"], None, big["H"], big["Q"], big["R"], flags=flags)
+    s = ga.FilterBatch.new_ldkf(kind, base["x0"], base["P0"], base["F"], None, base["H"], base["Q"], base["R"], flags=flags)
+    for t in range(3):
+        b.update(big["y"][t]); s.update(base["y"][t])
+    assert not b.status().any()
+    tail_P, tail_x = b.get(k.COVAR, N - small, small), b.get(k.STATE, N - small, small)
+    assert np.array_equal(tail_P, s.get(k.COVAR)) and np.array_equal(tail_x, s.get(k.STATE))
+    assert np.all(np.isfinite(tail_P)) and np.all(np.diagonal(tail_P, axis1=1, axis2=2) > 0)
+    head_P = b.get(k.COVAR, 0, small)
+    assert np.array_equal(head_P, tail_P)           # the same rows at the other end of the batch
+    assert np.allclose(tail_P, np.swapaxes(tail_P, 1, 2), rtol=1e-12, atol=1e-300)
+
+
+def test_baseline_size_1m_hybrid_ekf_properties():
+    """Config D(ii)'s size: 1M Hybrid EKF filters with per-step Phi / Htilde read in place from planar device arrays; shard
+    invariance against a 4096-filter batch given the same columns, status-clean, symmetric positive covariance."""
+    import torch
+    N, small, n, p = 1 << 20, 4096, 6, 2
+    rng = np.random.default_rng(12)
+    x0s = rng.standard_normal((small, n))
+    P0 = np.diag([10.0, 10, 10, 1, 1, 1])
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    Phi_s = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, small, dtype=torch.float64, device="cuda", generator=gen)).contiguous()
+    Ht_s = torch.randn(p * n, small, dtype=torch.float64, device="cuda", generator=gen)
+    real_s = torch.randn(p, small, dtype=torch.float64, device="cuda", generator=gen)
+    comp_s = real_s + 1e-3 * torch.randn(p, small, dtype=torch.float64, device="cuda", generator=gen)
+    rep = N // small
+    Phi, Ht, real, comp = (v.repeat(1, rep).contiguous() for v in (Phi_s, Ht_s, real_s, comp_s))
+
+    def make(M, x0):
+        h = ga.FilterBatch(k.HYBRID, n, p, 0, M)
+        h.set(k.X, x0, 1); h.set(k.P, P0, 2); h.set(k.R, np.diag([1e-6, 1e-6]), 2, p_rows=p); h.init(); h.enable_ekf()
+        return h
+    big, ref = make(N, np.tile(x0s, (rep, 1))), make(small, x0s)
+    for _ in range(3):
+        for h, (F_, H_, r_, c_, M) in ((big, (Phi, Ht, real, comp, N)), (ref, (Phi_s, Ht_s, real_s, comp_s, small))):
+            k.check(k.lib().kb_prepare_dev(h._h, F_.data_ptr(), H_.data_ptr(), M))
+            k.check(k.lib().kb_update_nl_dev(h._h, r_.data_ptr(), c_.data_ptr(), M))
+    assert not big.status().any()
+    tail_P = big.get(k.COVAR, N - small, small)
+    assert np.array_equal(tail_P, ref.get(k.COVAR)) and np.array_equal(big.get(k.STATE, N - small, small), ref.get(k.STATE))
+    assert np.all(np.isfinite(tail_P)) and np.all(np.diagonal(tail_P, axis1=1, axis2=2) > 0)

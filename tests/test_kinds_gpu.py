@@ -458,3 +458,23 @@ def test_chisquare_means_are_p_and_n_for_a_consistent_filter_at_scale():
     nis, nees = ga.new_chi_square(kf, truth, steps, np.zeros((1, 1)), replay_last_mc=False)
     assert np.all(np.abs(nis - p) < 6 * np.sqrt(2 * p / runs)), nis
     assert np.all(np.abs(nees[1:] - n) < 6 * np.sqrt(2 * n / runs) + 0.02), nees   # step 0: P+ is still rank-deficient from P0 ~ 0
+
+
+def test_monte_carlo_at_baseline_size_matches_the_covariance_recursion():
+    """Config D(i) at its full per-GPU size (2^20 runs x 1086 steps of examples/statOD5044's pure predictor, main.go:36-76):
+    far beyond an oracle replay, so the property montecarlo.go:18-59 exists for -- every run starts at x0 and adds
+    w_k ~ N(0, Q) per step, hence Mean(k) = F^k x0 and StdDev(k)^2 = diag(sum_j F^j Q F^jT) -- within the sampling error of
+    2^20 runs (mean: 6 sigma / sqrt(runs); standard deviation: relative 6 / sqrt(2 runs))."""
+    import bench
+    s = {kk: np.array(v, dtype=np.float64) for kk, v in bench.STATOD.items()}
+    runs, steps = 1 << 20, 1086
+    kf = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, s["x0"], s["P0"], s["F"], s["G"], s["H"], s["Q"], s["R"], nfilters=runs,
+                                 noise=k.NOISE_AWGN, seed=99)
+    mc = ga.new_monte_carlo_runs(runs, steps, 2, np.zeros((1, 2)), kf)
+    x, P = s["x0"].copy(), np.zeros((4, 4))
+    for t in range(steps):
+        x, P = s["F"] @ x, s["F"] @ P @ s["F"].T + s["Q"]
+        if t in (0, 1, 10, 100, 500, steps - 1):
+            sd = np.sqrt(np.diag(P))
+            assert np.all(np.abs(mc.mean(t) - x) <= 6 * sd / np.sqrt(runs) + 1e-12 * np.abs(x)), (t, mc.mean(t), x)
+            assert np.all(np.abs(mc.stddev(t) / sd - 1.0) <= 6 / np.sqrt(2 * runs)), (t, mc.stddev(t), sd)
