@@ -2,7 +2,8 @@
 """examples/statOD5044 of the reference (examples/statOD5044/main.go) on the MI355X engine: Monte-Carlo
 runs of the open- and closed-loop pure predictors (means / stddevs per step), a truth trajectory, the three
 linear filters tracking it, and the NIS / NEES chi-square statistics.  The reference runs 15 Monte-Carlo
-samples sequentially; here `--runs` samples run as one batch.   usage: python examples/statod5044.py [--runs N] [outdir]"""
+samples sequentially on ONE filter; here `--runs` copies of that filter run as one launch and AsCSV writes the reference's
+per-run columns (mc-<ctrl|noctrl>-<header>.csv).   usage: python examples/statod5044.py [--runs N] [outdir]"""
 import argparse
 import os
 import sys
@@ -36,14 +37,13 @@ def main(outdir, runs):
     zero_u = np.zeros((1, 2))
     # Monte-Carlo runs without and with control (main.go:72-90)
     for tag, Fm, Gm in (("noctrl", F, G), ("ctrl", Fcl, Gcl)):
-        mckf = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, x0, P0, Fm, Gm, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=5044)
-        mc = ga.new_monte_carlo_runs(runs, SAMPLES, 2, zero_u, mckf)
-        with open(os.path.join(outdir, "mc-%s.csv" % tag), "w") as fh:
-            fh.write(",".join("%s-mean,%s-stddev" % (h, h) for h in headers) + "\n")
-            for s in range(SAMPLES):
-                fh.write(",".join("%f,%f" % (mc.mean(s)[i], mc.stddev(s)[i]) for i in range(4)) + "\n")
+        mckf = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, x0, P0, Fm, Gm, H, Q, R, noise=k.NOISE_AWGN, seed=5044)   # ONE filter, main.go:74 / :85
+        mc = ga.new_monte_carlo_runs(runs, SAMPLES, 2, zero_u, mckf)                                                  # main.go:76 / :86
+        for i, contents in enumerate(mc.as_csv(headers)):                                                             # main.go:79-83 / :87-91
+            with open(os.path.join(outdir, "mc-%s-%s.csv" % (tag, headers[i])), "w") as fh:
+                fh.write(contents)
         if tag == "ctrl":
-            truth_batch, truth_mc = mckf, mc
+            truth_mc = mc
     # truth generation: one closed-loop pure predictor with AWGN (main.go:56-62, 92-101)
     truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, x0, P0, Fcl, Gcl, H, Q, R, flags=k.FLAG_FULL_ESTIMATE, noise=k.NOISE_AWGN, seed=7)
     state_truth, measurements = np.zeros((SAMPLES, 4)), np.zeros((SAMPLES, 2))
@@ -72,18 +72,19 @@ def main(outdir, runs):
         exps[name].close()
         rms[name] = np.sqrt(err2 / SAMPLES)
     # chi-square on the closed-loop Monte-Carlo runs (main.go:163-175)
-    chikf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, Fcl, Gcl, H, Q, R, nfilters=runs)
-    nis, nees = ga.new_chi_square(chikf, truth_batch, SAMPLES, zero_u)
+    chikf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, Fcl, Gcl, H, Q, R)   # the reference hands over vanillaKF itself; NewChiSquare Reset()s it per run
+    nis, nees = ga.new_chi_square(chikf, truth_mc, zero_u, True, True)      # main.go:165
     with open(os.path.join(outdir, "chisquare.csv"), "w") as fh:
         fh.write("NIS,NEES\n")
         for s in range(SAMPLES):
             fh.write("%f,%f\n" % (nis[s], nees[s]))
-    return {"rms": rms, "history": history, "measurements": measurements, "nis_mean": float(nis.mean()), "nees_mean": float(nees.mean()), "mc_stddev_last": truth_mc.stddev(SAMPLES - 1)}
+    return {"rms": rms, "history": history, "measurements": measurements, "nis_mean": float(nis.mean()), "nees_mean": float(nees.mean()), "mc_stddev_last": truth_mc.stddev(SAMPLES - 1), "mc": truth_mc}
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--runs", type=int, default=4096)
+    ap.add_argument("--runs", type=int, default=15)   # numMC := 15 (main.go:75)
     ap.add_argument("outdir", nargs="?", default="./statod5044_out")
     a = ap.parse_args()
-    print(main(a.outdir, a.runs))
+    out = main(a.outdir, a.runs)
+    print({kk: v for kk, v in out.items() if kk not in ("mc", "history", "measurements")})

@@ -17,6 +17,8 @@ ST_SINGULAR, ST_ASYMMETRIC, ST_NONFINITE, ST_INFO_NOT_INVERTIBLE, ST_NYQUIST = 1
 X, P, F, G, H, Q, R = range(7)
 STATE, COVAR, PRED_COVAR, GAIN, INNOVATION, MEASUREMENT, RAW_VEC, RAW_MAT, RAW_PRED_MAT = range(16, 25)
 NOISE_NOISELESS, NOISE_AWGN, NOISE_BATCH = 0, 1, 2
+MC_KEEP_RUNS = 1
+MC_KEEP_MAX_BYTES = 8 << 30
 
 _vp, _dp, _i, _i64, _u64 = C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_uint64
 
@@ -50,6 +52,9 @@ SIGNATURES = {
     "kb_clear_status": (_i, [_vp]),
     "kb_is_within_nsigma": (_i, [_vp, C.c_double, C.POINTER(C.c_uint8), _i64, _i64]),
     "kb_step": (_i64, [_vp]),
+    "kb_filter_step": (_i, [_vp, _i64, C.POINTER(_i64)]),
+    "kb_calls": (_i64, [_vp]),
+    "kb_replicate": (_i, [_vp, _i64, _i64, C.c_uint, C.POINTER(_vp)]),
     "kb_need_ctrl": (_i, [_vp]),
     "kb_meas_dim": (_i, [_vp]),
     "kb_num_filters": (_i64, [_vp]),
@@ -60,6 +65,8 @@ SIGNATURES = {
     "kb_noise_sample": (_i, [_vp, _i64, _i64, _i64, _i, _dp]),
     "kb_noise_normal": (C.c_double, [_u64, _i64, _i64, _i64, _i, _i]),
     "kb_mc_run": (_i, [_vp, _i, _dp, _i, _i64, _dp]),
+    "kb_mc_run_ex": (_i, [_vp, _i, _dp, _i, _i64, _dp, C.c_uint]),
+    "kb_mc_get_runs": (_i, [_vp, _i64, _i64, _dp, _dp]),
     "kb_chisquare": (_i, [_vp, _vp, _i, _dp, _i, _i64, _i, _i, _i, _dp]),
     "kb_mc_stats": (_i, [_dp, _i, _i, _i64, _dp, _dp]),
     "kb_van_loan": (_i, [_i, _i, _i, _i, _i64, _dp, _dp, _dp, _dp, _i, _dp, _dp, C.POINTER(C.c_uint32)]),

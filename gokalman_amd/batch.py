@@ -45,7 +45,7 @@ class Estimate:
         self._first = first
         self._count = batch.N - first if count is None else count
         self._step = batch.step()
-        self._epoch = batch._resets
+        self._calls = batch.calls()
         self._own = None
         if snapshot:
             self._download(clear_status)
@@ -86,7 +86,7 @@ class Estimate:
         return self._own is not None
 
     def _check_live(self):
-        if self._b.step() != self._step or self._b._resets != self._epoch:
+        if self._b.calls() != self._calls:
             raise StaleEstimateError(
                 "this Estimate is a view of step %d but the batch is at step %d: ask update(..., snapshot=True) or call "
                 "freeze() before the next Update to keep an estimate (vanilla.go:216-218 semantics)" % (self._step, self._b.step()))
@@ -203,6 +203,18 @@ class FilterBatch:
         if noise != k.NOISE_NOISELESS:
             b.set_noise_kind(noise, seed)
         b.init()
+        return b
+
+    def replicate(self, nfilters, filt=0, flags=None):
+        """kb_replicate: a new batch of `nfilters` copies of filter `filt` (model, INITIAL estimate, noise selection)."""
+        flags = (self.flags & (k.FLAG_FULL_ESTIMATE | k.FLAG_STRICT_SYMCHECK)) if flags is None else flags
+        h = C.c_void_p()
+        k.check(k.lib().kb_replicate(self._h, int(filt), int(nfilters), flags, C.byref(h)))
+        b = object.__new__(FilterBatch)
+        b._h = h
+        b.kind, b.n, b.pmax, b.m, b.N, b.dtype = self.kind, self.n, self.pmax, self.m, int(nfilters), self.dtype
+        b.flags = flags | (self.flags & (k.FLAG_INFO_FROM_STATE | k.FLAG_SRIF_NON_TRI_R))
+        b._resets, b._noise_name = 0, self._noise_name
         return b
 
     def __del__(self):
@@ -397,7 +409,18 @@ class FilterBatch:
         return self._estimate(snapshot)
 
     def step(self):
+        """kf.step: not advanced by a failed Update (vanilla.go:164-167).  Exact for filter 0 of a batch of at most 64 filters."""
         return int(k.lib().kb_step(self._h))
+
+    def filter_step(self, filt):
+        """kf.step of any filter of the batch (synchronises)."""
+        out = C.c_int64()
+        k.check(k.lib().kb_filter_step(self._h, int(filt), C.byref(out)))
+        return out.value
+
+    def calls(self):
+        """Update / Predict / Reset calls accepted so far (monotone)."""
+        return int(k.lib().kb_calls(self._h))
 
     def need_ctrl(self):
         return bool(k.lib().kb_need_ctrl(self._h))
@@ -437,16 +460,88 @@ class FilterBatch:
         return out
 
 
-class MonteCarloRuns:
-    """MonteCarloRuns (montecarlo.go:12-59): per-step mean / unbiased stddev over runs."""
+def _go_f(x):
+    """fmt's %f of a float64 (montecarlo.go:71-83, exporter.go): six decimals; Go spells the non-finite values NaN / +Inf / -Inf."""
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "+Inf" if x > 0 else "-Inf"
+    return "%f" % x
 
-    def __init__(self, runs, steps, n, sums):
-        self.runs, self.steps, self.n = runs, steps, n
+
+class MonteCarloEstimate:
+    """MonteCarloRuns.Runs[r].Estimates[k] (montecarlo.go:108-117): the estimate a pure-predictor Vanilla returns
+    (vanilla.go:170-179) = {x-, yhat, 0, sym(P-), sym(P-), K}.  State() and Measurement() differ between the runs (kept on
+    the device by kb_mc_run_ex(KB_MC_KEEP_RUNS)); the covariances and the gain do not depend on the noise and are shared."""
+
+    def __init__(self, mc, run, step):
+        self._mc, self._r, self._k = mc, run, step
+
+    def state(self):
+        return self._mc._states()[self._r, self._k]
+
+    def measurement(self):
+        return self._mc._measurements()[self._r, self._k]
+
+    def innovation(self):
+        return np.zeros(self._mc.p)
+
+    def covariance(self):
+        return self._mc._shared()["pred_covariance"][self._k]
+
+    def pred_covariance(self):
+        return self._mc._shared()["pred_covariance"][self._k]
+
+    def gain(self):
+        return self._mc._shared()["gain"][self._k]
+
+    def is_within_nsigma(self, nsigma):
+        x, d = self.state(), nsigma * np.sqrt(np.diagonal(self.covariance()))
+        return not bool(np.any((x > d) | (x < -d)))
+
+    def is_within_2sigma(self):
+        return self.is_within_nsigma(2.0)
+
+
+class MonteCarloRun:
+    """MonteCarloRun (montecarlo.go:122-124): `Estimates[k]`."""
+
+    class _Estimates:
+        def __init__(self, mc, run):
+            self._mc, self._r = mc, run
+
+        def __len__(self):
+            return self._mc.steps
+
+        def __getitem__(self, k):
+            if k < 0:
+                k += self._mc.steps
+            if not 0 <= k < self._mc.steps:
+                raise IndexError(k)
+            return MonteCarloEstimate(self._mc, self._r, k)
+
+    def __init__(self, mc, run):
+        self.Estimates = MonteCarloRun._Estimates(mc, run)
+        self.estimates = self.Estimates
+
+
+class MonteCarloRuns:
+    """MonteCarloRuns (montecarlo.go:11-89): `Runs[r].Estimates[k]`, `Mean(step)`, `StdDev(step)`, `AsCSV(headers)`.
+
+    Mean / StdDev come from per-step sums reduced on the device (kb_mc_run + kb_mc_stats); Runs and AsCSV need the
+    trajectories, which the engine keeps only when asked (new_monte_carlo_runs(..., keep_runs=...)) and hands over on first
+    use (kb_mc_get_runs)."""
+
+    def __init__(self, runs, steps, n, sums, truth=None, kept=False, first_run=0, template=None, controls=None):
+        self.runs, self.steps, self.n = int(runs), int(steps), int(n)
         self.sums = sums  # [steps, 3, n]: sum(x-c), sum((x-c)^2), c
         mean = np.zeros((steps, n))
         std = np.zeros((steps, n))
         k.check(k.lib().kb_mc_stats(_ptr(_f64(sums)), steps, n, runs, _ptr(mean), _ptr(std)))
         self._mean, self._std = mean, std
+        self._truth, self._kept, self._first_run, self._template, self._controls = truth, kept, first_run, template, controls
+        self.p = truth.meas_dim() if truth is not None else 0
+        self._st = self._me = self._sh = None
 
     def mean(self, step):
         return self._mean[step]
@@ -454,46 +549,153 @@ class MonteCarloRuns:
     def stddev(self, step):
         return self._std[step]
 
+    Mean, StdDev = mean, stddev
 
-def new_monte_carlo_runs(samples, steps, rows_h, controls, kf, first_run=0, reduce=None):
+    # ---- Runs --------------------------------------------------------------------------
+    def _need_kept(self):
+        if not self._kept or self._truth is None:
+            raise k.KalmanError(k.ERR_INVALID, "these Monte-Carlo runs were not kept (new_monte_carlo_runs(..., keep_runs=True)): "
+                                "only Mean / StdDev / new_chi_square are available")
+
+    def _download(self):
+        self._need_kept()
+        N = self._truth.N
+        st, me = np.zeros((N, self.steps, self.n)), np.zeros((N, self.steps, self.p))
+        k.check(k.lib().kb_mc_get_runs(self._truth._h, 0, N, _ptr(st), _ptr(me)))
+        self._st, self._me = st, me
+
+    def _states(self):
+        if self._st is None:
+            self._download()
+        return self._st
+
+    def _measurements(self):
+        if self._me is None:
+            self._download()
+        return self._me
+
+    def _shared(self):
+        """P-_k and K_k, k < steps: identical for every run (they do not see the noise) -- one Noiseless filter stepped through
+        the controls with KB_FLAG_FULL_ESTIMATE."""
+        if self._sh is None:
+            self._need_kept()
+            one = self._truth.replicate(1, flags=k.FLAG_FULL_ESTIMATE)
+            one.set_noise_kind(k.NOISE_NOISELESS)
+            P, K = np.zeros((self.steps, self.n, self.n)), np.zeros((self.steps, self.n, self.p))
+            y0 = np.zeros(self.p)
+            for t in range(self.steps):
+                u = None
+                if one.need_ctrl():
+                    u = np.zeros(one.m) if self._controls is None or len(self._controls) == 1 else self._controls[t]
+                est = one.update(y0, u)
+                P[t], K[t] = est.pred_covariance()[0], est.gain()[0]
+            self._sh = {"pred_covariance": P, "gain": K}
+        return self._sh
+
+    @property
+    def Runs(self):
+        self._need_kept()
+        return [MonteCarloRun(self, r) for r in range(self._truth.N)]
+
+    def as_csv(self, headers):
+        """MonteCarloRuns.AsCSV(headers) (montecarlo.go:62-89): one string per state component -- a header line
+        `h-0,h-1,...,h-mean,h-stddev`, then one line per step with every run's value, the mean and the standard deviation."""
+        st = self._states()
+        runs = st.shape[0]
+        out = []
+        for i in range(self.n):
+            h = headers[i]
+            lines = ["".join("%s-%d," % (h, r) for r in range(runs)) + h + "-mean," + h + "-stddev"]
+            for t in range(self.steps):
+                lines.append("".join(_go_f(v) + "," for v in st[:, t, i]) + _go_f(self._mean[t, i]) + "," + _go_f(self._std[t, i]))
+            out.append("\n".join(lines))
+        return out
+
+    AsCSV = as_csv
+
+
+_AUTO_KEEP_BYTES = 256 << 20   # keep_runs=None keeps ensembles of the reference's size (50 x 120, 15 x 1086 ...), not the benchmark's
+
+
+def _controls_arg(controls, steps, m):
+    """controls []*mat64.Vector (montecarlo.go:98-107): `steps` vectors, or ONE vector standing for zero controls."""
+    c = _f64(controls)
+    if c.ndim == 1:
+        c = c.reshape(1, -1)
+    if c.ndim != 2:
+        raise k.KalmanError(k.ERR_DIMS, "controls must be [steps][m] or [1][m]")
+    if c.shape[0] != 1 and c.shape[0] != steps:
+        raise k.KalmanError(k.ERR_INVALID, "must provide as much control vectors as steps, or just one control vector")
+    return c
+
+
+def new_monte_carlo_runs(samples, steps, rows_h, controls, kf, first_run=0, reduce=None, keep_runs=None):
     """NewMonteCarloRuns(samples, steps, rowsH, controls, kf) (montecarlo.go:92-119).
 
-    `kf` is a pure-predictor Vanilla FilterBatch with N == samples.  `reduce`, when given,
-    is applied to the per-shard sums (e.g. a torch.distributed all-reduce) and `samples`
-    is then the global number of runs."""
+    `kf` is the pure-predictor Vanilla of the reference's call -- ONE filter (FilterBatch with N == 1): the `samples` runs
+    the reference performs one after the other on it (Reset() in between) are `samples` copies of it on the device
+    (kb_replicate), and kf is left Reset(), as montecarlo.go:116 leaves it.  A FilterBatch that already holds one filter per
+    run (N == samples, or a shard of a multi-GPU ensemble together with `first_run` / `reduce`) is used as it is.
+    `reduce`, when given, is applied to the per-shard sums (e.g. a torch.distributed all-reduce) and `samples` is then the
+    global number of runs.  keep_runs: True keeps every run's State() / Measurement() per step on the device for
+    `Runs` / `AsCSV` (refused above KB_MC_KEEP_MAX_BYTES), False keeps only the statistics, None keeps small ensembles."""
     if kf.kind != k.VANILLA_PREDICT:
         raise k.KalmanError(k.ERR_INVALID, "the Kalman filter needed for the Monte Carlo runs must be a pure predictor")
+    controls = _controls_arg(controls, steps, kf.m)
+    if rows_h != kf.meas_dim():   # montecarlo.go:111 feeds Update a zero vector of rowsH rows: vanilla.go:133-135 rejects any other size
+        raise k.KalmanError(k.ERR_DIMS, "dimensions must agree: measurement (y)(%dx...) H(%dx...)" % (rows_h, kf.meas_dim()))
+    template = None
+    truth = kf
+    if kf.N == 1 and samples > 1 and reduce is None:
+        template, truth = kf, kf.replicate(samples)
+    if keep_runs is None:
+        keep_runs = steps * (kf.n + kf.meas_dim()) * truth.N * (8 if kf.dtype == k.F64 else 4) <= _AUTO_KEEP_BYTES
+    sums = np.zeros((steps, 3, kf.n), dtype=np.float64)
+    k.check(k.lib().kb_mc_run_ex(truth._h, steps, _ptr(controls), controls.shape[0], first_run, _ptr(sums), k.MC_KEEP_RUNS if keep_runs else 0))
+    if template is not None:
+        template.reset()
+    if reduce is not None:  # add the shards' partial sums (rows 0, 1); row 2 (the shift) is identical everywhere
+        sums[:, :2, :] = reduce(np.ascontiguousarray(sums[:, :2, :]))
+    return MonteCarloRuns(samples, steps, kf.n, sums, truth=truth, kept=bool(keep_runs), first_run=first_run, template=template, controls=controls)
+
+
+def new_chi_square(kf, runs, controls, with_nees=True, with_nis=True, steps=None, first_run=None, total_runs=None, reduce=None):
+    """NewChiSquare(kf, runs, controls, withNEES, withNIS) (chisquare.go:16-95): returns (NISmeans, NEESmeans).
+
+    `runs` is the MonteCarloRuns the truth comes from and `kf` the Vanilla filter under test -- one filter, as in the
+    reference, which Reset()s it for every run (chisquare.go:39): the engine replays every run of `runs` against its own copy
+    of kf in one launch (kb_chisquare with replay_last_mc: the truth's states and measurements are regenerated from the
+    runs' noise streams, so they need not have been kept).  A Vanilla batch with one filter per run is used as it is.
+    Beyond the reference: `runs` may be the pure-predictor AWGN FilterBatch itself, for which FRESH runs of `steps` steps
+    are drawn.  `reduce` adds the per-shard sums across ranks; `total_runs` is then the global number of runs."""
+    if not with_nees and not with_nis:
+        raise k.KalmanError(k.ERR_INVALID, "Chi Square requires either NEES or NIS or both")
+    if isinstance(runs, MonteCarloRuns):
+        truth, replay = runs._truth, 1
+        if truth is None:
+            raise k.KalmanError(k.ERR_INVALID, "these MonteCarloRuns carry no truth batch (built from sums only)")
+        steps = runs.steps
+        first_run = runs._first_run if first_run is None else first_run
+    elif isinstance(runs, FilterBatch):
+        truth, replay = runs, 0
+        if steps is None:
+            raise ValueError("new_chi_square on a truth batch draws fresh runs: give steps=")
+        first_run = 0 if first_run is None else first_run
+    else:
+        raise TypeError("runs must be the MonteCarloRuns returned by new_monte_carlo_runs (or a pure-predictor AWGN FilterBatch)")
     controls = _f64(controls)
     if controls.ndim == 1:
         controls = controls.reshape(1, -1)
     if controls.shape[0] != 1 and controls.shape[0] != steps:
         raise k.KalmanError(k.ERR_INVALID, "must provide as much control vectors as steps, or just one control vector")
-    sums = np.zeros((steps, 3, kf.n), dtype=np.float64)
-    k.check(k.lib().kb_mc_run(kf._h, steps, _ptr(controls), controls.shape[0], first_run, _ptr(sums)))
-    if reduce is not None:  # add the shards' partial sums (rows 0, 1); row 2 (the shift) is identical everywhere
-        sums[:, :2, :] = reduce(np.ascontiguousarray(sums[:, :2, :]))
-    return MonteCarloRuns(samples, steps, kf.n, sums)
-
-
-def new_chi_square(kf, truth, steps, controls, with_nees=True, with_nis=True, first_run=0, replay_last_mc=True,
-                   total_runs=None, reduce=None):
-    """NewChiSquare(kf, runs, controls, withNEES, withNIS) (chisquare.go:16-95): returns (NISmeans, NEESmeans).
-
-    `truth` is the pure-predictor AWGN batch that generated (or generates) the Monte-Carlo runs, `kf`
-    the Vanilla batch under test.  `reduce` adds the per-shard sums across ranks; `total_runs` is then
-    the global number of runs."""
-    if not with_nees and not with_nis:
-        raise k.KalmanError(k.ERR_INVALID, "Chi Square requires either NEES or NIS or both")
-    controls = _f64(controls)
-    if controls.ndim == 1:
-        controls = controls.reshape(1, -1)
+    kfb = kf.replicate(truth.N, flags=0) if (kf.N == 1 and truth.N > 1) else kf
     sums = np.zeros((steps, 2), dtype=np.float64)
-    k.check(k.lib().kb_chisquare(truth._h, kf._h, steps, _ptr(controls), controls.shape[0], first_run,
-                                 1 if replay_last_mc else 0, int(with_nees), int(with_nis), _ptr(sums)))
+    k.check(k.lib().kb_chisquare(truth._h, kfb._h, steps, _ptr(controls), controls.shape[0], first_run,
+                                 replay, int(with_nees), int(with_nis), _ptr(sums)))
     if reduce is not None:
         sums = reduce(sums)
-    runs = float(total_runs if total_runs is not None else truth.N)
-    return sums[:, 0] / runs, sums[:, 1] / runs
+    n_runs = float(total_runs if total_runs is not None else truth.N)
+    return sums[:, 0] / n_runs, sums[:, 1] / n_runs
 
 
 def van_loan(A, Gamma, W, dt, dtype=k.F64, device=0):

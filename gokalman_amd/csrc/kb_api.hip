@@ -214,7 +214,7 @@ __global__ void pack_planar_kernel(const T *__restrict__ src, int64_t ld, int sr
 
 void fill_step_args(const Batch &b, StepArgs &a) {
     memset(&a, 0, sizeof(a));
-    a.state = b.d_state; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status;
+    a.state = b.d_state; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status; a.lag = b.d_lag;
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p; a.srif_tri = b.srif_tri;
@@ -310,6 +310,14 @@ int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, i
     KB_TRY(hipMalloc(&b->d_state0, b->block_bytes(b->L.st_elems)));
     KB_TRY(hipMalloc(&b->d_model, b->block_bytes(b->L.mo_elems)));
     KB_TRY(hipMalloc((void **)&b->d_status, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
+    if (b->ntiles == 1) {   // kf.step of a drop-in (one-tile) batch is read by the host without touching the device: pinned, device-mapped
+        KB_TRY(hipHostMalloc((void **)&b->h_lag, KB_TILE * sizeof(uint32_t), hipHostMallocMapped));
+        memset(b->h_lag, 0, KB_TILE * sizeof(uint32_t));
+        KB_TRY(hipHostGetDevicePointer((void **)&b->d_lag, b->h_lag, 0));
+    } else {
+        KB_TRY(hipMalloc((void **)&b->d_lag, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
+        KB_TRY(hipMemsetAsync(b->d_lag, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
+    }
     KB_TRY(hipMemsetAsync(b->d_state, 0, b->block_bytes(b->L.st_elems), b->stream));
     KB_TRY(hipMemsetAsync(b->d_state0, 0, b->block_bytes(b->L.st_elems), b->stream));
     KB_TRY(hipMemsetAsync(b->d_model, 0, b->block_bytes(b->L.mo_elems), b->stream));
@@ -329,9 +337,11 @@ void kb_destroy(kb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_est, b->d_model, b->d_status,
-                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas};
+                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
+                    b->h_lag ? nullptr : (void *)b->d_lag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (b->h_lag) (void)hipHostFree(b->h_lag);
     if (b->h_pin) (void)hipHostFree(b->h_pin);
     for (hipEvent_t e : b->ev_heavy)
         if (e) (void)hipEventDestroy(e);
@@ -446,8 +456,11 @@ int kb_reset(kb_batch *b) {
     KB_HIP(hipMemcpyAsync(b->d_state, b->d_state0, b->block_bytes(b->L.st_elems), hipMemcpyDeviceToDevice, b->stream));
     if (b->d_est) KB_HIP(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
     KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
+    if (!b->h_lag) KB_HIP(hipMemsetAsync(b->d_lag, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
     KB_HIP(hipStreamSynchronize(b->stream));
-    b->step = 0;
+    if (b->h_lag) memset(b->h_lag, 0, KB_TILE * sizeof(uint32_t));
+    b->step = 0;   // vanilla.go:123
+    b->calls++;
     b->epoch++;  // AWGN.Reset re-seeds (noise.go:145-146)
     if (is_nldkf(b->kind)) { b->locked = 1; b->snc = 0; b->srif_tri = 1; }
     return KB_OK;
@@ -474,9 +487,16 @@ static int check_update_dims(kb_batch *b, int meas_rows, int ctrl_rows, bool hav
 
 static int check_batch_noise(kb_batch *b, int nsteps) {
     if (b->noise_kind != KB_NOISE_BATCH) return KB_OK;
-    const int64_t last = b->step + nsteps - 1;
-    if (last >= b->bn_nproc) { set_error("no process noise defined at step k=%lld", (long long)(b->step < b->bn_nproc ? b->bn_nproc : b->step)); return KB_ERR_INVALID; }
-    if (last >= b->bn_nmeas) { set_error("no measurement noise defined at step k=%lld", (long long)(b->step < b->bn_nmeas ? b->bn_nmeas : b->step)); return KB_ERR_INVALID; }
+    // the largest kf.step any filter of the batch may be at (exact for one-tile batches, whose failed-step counts the host sees)
+    int64_t step = b->step;
+    if (b->h_lag) {
+        uint32_t least = b->h_lag[0];
+        for (int64_t i = 1; i < b->N; i++) least = b->h_lag[i] < least ? b->h_lag[i] : least;
+        step -= least;
+    }
+    const int64_t last = step + nsteps - 1;
+    if (last >= b->bn_nproc) { set_error("no process noise defined at step k=%lld", (long long)(step < b->bn_nproc ? b->bn_nproc : step)); return KB_ERR_INVALID; }
+    if (last >= b->bn_nmeas) { set_error("no measurement noise defined at step k=%lld", (long long)(step < b->bn_nmeas ? b->bn_nmeas : step)); return KB_ERR_INVALID; }
     if (b->bn_p != b->p) { set_error("dimensions must agree: measurement noise(%dx...) H(%dx...)", b->bn_p, b->p); return KB_ERR_DIMS; }
     return KB_OK;
 }
@@ -513,6 +533,7 @@ int kb_update(kb_batch *b, const double *meas, int meas_rows, const double *ctrl
     if ((rc = launch_step(*b, a, false))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));
     b->step++;
+    b->calls++;
     return KB_OK;
 }
 
@@ -532,6 +553,7 @@ static int update_dev_common(kb_batch *b, const void *meas, int64_t ld_meas, con
     if (b->need_ctrl) { a.u = ctrl; a.u_es = ld_ctrl; a.u_ts = KB_TILE; a.u_step = (int64_t)b->m * ld_ctrl; }
     if ((rc = launch_step(*b, a, fused))) return rc;
     b->step += nsteps;
+    b->calls++;
     return KB_OK;
 }
 
@@ -717,6 +739,13 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
     // Information / SRIF state) first gets its materialise kernel, and pred_covar of those kinds -- which re-uses the scratch
     // block of state / covar -- goes into a second snapshot launch, stream-ordered behind the first.
     const bool lazy = (b->kind == KB_SQUAREROOT || b->kind == KB_INFORMATION || b->kind == KB_SRIF || b->kind == KB_BATCH_LS);
+    // The status words travel (and are cleared) with the LAST launch: a member that cannot be delivered (pred_covariance of a
+    // batch without KB_FLAG_FULL_ESTIMATE, a launch error) fails the call before anything has been cleared.
+    const int status_pass = (lazy && v->pred_covariance) ? 1 : 0;
+    bool cleared = false;
+    // after the clear nothing may fail silently: the SRIF Update finds filters that may hold a dense R through their status
+    // words (kb_srif_pair.h), so a lost word sends the next Update down the dense path
+    auto after_clear = [&](int code) { if (code && cleared && b->kind == KB_SRIF) b->srif_tri = 0; return code; };
     for (int pass = 0; pass < 2; pass++) {
         SnapArgs sa;
         sa.nmembers = 0;
@@ -731,10 +760,13 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
             sa.block[m] = o.block; sa.block_elems[m] = o.block_elems; sa.out_elems[m] = o.out_elems; sa.off[m] = (int64_t)want[i].off;
             memcpy(sa.map[m], o.map, sizeof(sa.map[m]));
         }
-        const bool with_status = v->status && pass == 0;
+        const bool with_status = v->status && pass == status_pass;
         if (sa.nmembers == 0 && !with_status) continue;
         if ((rc = launch_snapshot(*b, sa, first, count, d_area, with_status ? b->d_status : nullptr, (int64_t)st_off, v->clear_status ? 1 : 0))) return rc;
+        if (with_status && v->clear_status) cleared = true;
     }
+#undef KB_HIP
+#define KB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return after_clear(::kb::hip_fail(e__, #call)); } while (0)
     if (pinned) {
         KB_HIP(hipStreamSynchronize(b->stream));
         for (int i = 0; i < 6; i++)
@@ -747,11 +779,13 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
         KB_HIP(hipStreamSynchronize(b->stream));
     }
     if (v->status && v->clear_status && b->kind == KB_SRIF) {
-        // the fused SRIF Update finds filters that may hold a dense R through their status words (kb_srif_reg.hip)
+        // the SRIF Update finds filters that may hold a dense R through their status words (kb_srif_pair.h)
         for (int64_t k = 0; k < count; k++)
             if (v->status[k]) { b->srif_tri = 0; break; }
     }
     return KB_OK;
+#undef KB_HIP
+#define KB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return ::kb::hip_fail(e__, #call); } while (0)
 }
 
 int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count) {
@@ -803,7 +837,26 @@ int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first
     return rc;
 }
 
-int64_t kb_step(const kb_batch *b) { return b ? b->step : -1; }
+// kf.step: a failed Update does not advance it (vanilla.go:164-167 returns before :218).  One-tile batches: exact, filter 0's
+// counter (the host sees the failed-step counts); larger batches: the counter of a filter that never failed.
+int64_t kb_step(const kb_batch *b) { return b ? b->step - (b->h_lag ? (int64_t)b->h_lag[0] : 0) : -1; }
+int64_t kb_calls(const kb_batch *b) { return b ? b->calls : -1; }
+int kb_filter_step(kb_batch *b, int64_t filter, int64_t *step) {
+    if (!b || !step) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (filter < 0 || filter >= b->N) { set_error("filter %lld outside the batch", (long long)filter); return KB_ERR_INVALID; }
+    int rc = use_device(*b);
+    if (rc) return rc;
+    uint32_t lag = 0;
+    if (b->h_lag) {
+        KB_HIP(hipStreamSynchronize(b->stream));
+        lag = b->h_lag[filter];
+    } else {
+        KB_HIP(hipMemcpyAsync(&lag, b->d_lag + filter, sizeof(lag), hipMemcpyDeviceToHost, b->stream));
+        KB_HIP(hipStreamSynchronize(b->stream));
+    }
+    *step = b->step - (int64_t)lag;
+    return KB_OK;
+}
 int kb_need_ctrl(const kb_batch *b) { return b ? b->need_ctrl : 0; }
 int kb_meas_dim(const kb_batch *b) { return b ? b->p : 0; }
 int64_t kb_num_filters(const kb_batch *b) { return b ? b->N : 0; }

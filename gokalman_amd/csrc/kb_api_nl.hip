@@ -1,5 +1,6 @@
 // kb_api_nl.hip -- C ABI, second half: the NLDKF interface (kalman.go:51-60) for SRIF and
 // Hybrid batches, the Noise selection (noise.go) and the Monte-Carlo fan-out (montecarlo.go).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -79,10 +80,18 @@ static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
     }
     if ((rc = launch_nl(b, a))) return rc;
     b->step++;
+    b->calls++;
     b->srif_tri = predict ? 0 : 1;  // Predict() leaves the full RBar in R (srif.go:134-141), an Update a triangular R_k
     b->snc = 0;     // hybrid.go:201
     b->locked = 1;  // srif.go:158, hybrid.go:202
     return KB_OK;
+}
+
+// The reference returns from a failed step before `kf.sncEnabled = false; kf.locked = true` (hybrid.go:150-152 against :201-202,
+// srif.go:112-114 against :157-158): the filter stays prepared and the caller may retry.  A one-filter batch (the drop-in
+// use) sees its failed-step count from the host after the synchronisation and keeps that behaviour.
+static void nl_after_sync(kb_batch *b, uint32_t lag_before, int snc_before) {
+    if (b->N == 1 && b->h_lag && b->h_lag[0] != lag_before) { b->locked = 0; b->snc = snc_before; }
 }
 
 // Update(realObservation, computedObservation): srif.go:90-92, hybrid.go:93-95
@@ -106,8 +115,11 @@ int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const doubl
     fill_step_args(*b, a);
     a.y = rtile; a.y_es = KB_TILE; a.y_ts = (int64_t)KB_TILE * real_rows;
     a.y2 = ctile; a.y2_es = KB_TILE; a.y2_ts = (int64_t)KB_TILE * real_rows;
+    const uint32_t lag_before = b->h_lag ? b->h_lag[0] : 0u;
+    const int snc_before = b->snc;
     if ((rc = nl_common(b, a, false))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));
+    nl_after_sync(b, lag_before, snc_before);
     return KB_OK;
 }
 
@@ -130,8 +142,11 @@ int kb_predict_nl(kb_batch *b) {
     if (b->kind == KB_BATCH_LS) { set_error("BatchKF has no Predict()"); return KB_ERR_UNSUPPORTED; }
     StepArgs a;
     fill_step_args(*b, a);
+    const uint32_t lag_before = b->h_lag ? b->h_lag[0] : 0u;
+    const int snc_before = b->snc;
     if ((rc = nl_common(b, a, true))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));
+    nl_after_sync(b, lag_before, snc_before);
     return KB_OK;
 }
 
@@ -141,8 +156,8 @@ int kb_smooth_all_dev(kb_batch *b, const void *phis, int64_t ld, int steps, void
     if (rc) return rc;
     if (!phis || !x_out || !P_out) { set_error("null argument"); return KB_ERR_INVALID; }
     if (ld < b->N) { set_error("ld < N"); return KB_ERR_INVALID; }
-    if (steps != b->step) {  // hybrid.go:210-212
-        set_error("incorrect number of estimates provided: %d instead of expected %lld", steps, (long long)b->step);
+    if (steps != kb_step(b)) {  // hybrid.go:210-212
+        set_error("incorrect number of estimates provided: %d instead of expected %lld", steps, (long long)kb_step(b));
         return KB_ERR_INVALID;
     }
     const int n = b->n;
@@ -225,7 +240,12 @@ double kb_noise_normal(uint64_t seed, int64_t filter, int64_t epoch, int64_t ste
 
 // ---- Monte-Carlo (montecarlo.go:92-119) ----------------------------------------------------
 int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols, int64_t first_run, double *sums) {
+    return kb_mc_run_ex(b, steps, controls, ncontrols, first_run, sums, 0u);
+}
+
+int kb_mc_run_ex(kb_batch *b, int steps, const double *controls, int ncontrols, int64_t first_run, double *sums, unsigned mc_flags) {
     if (!b || !sums) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (mc_flags & ~(unsigned)KB_MC_KEEP_RUNS) { set_error("unknown Monte-Carlo flags 0x%x", mc_flags); return KB_ERR_INVALID; }
     if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
     if (b->kind != KB_VANILLA_PREDICT) {  // montecarlo.go:93-95 (a panic there)
         set_error("the Kalman filter needed for the Monte Carlo runs must be a pure predictor");
@@ -270,12 +290,33 @@ int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols, int
         b->mc_bytes = ndbl * sizeof(double);
     }
     KB_HIP(hipMemsetAsync(b->d_mc, 0, ndbl * sizeof(double), b->stream));
+    b->mc_epoch = -1;   // a previous trajectory buffer no longer describes "the last Monte-Carlo run"
+    void *traj = nullptr;
+    const int64_t traj_ld = b->ntiles * KB_TILE;
+    if (mc_flags & KB_MC_KEEP_RUNS) {
+        // MonteCarloRuns.Runs (montecarlo.go:11-15, :108-117): samples x steps estimates, what AsCSV and NewChiSquare read
+        const size_t bytes = (size_t)steps * (size_t)(n + b->p) * (size_t)traj_ld * b->esize();
+        if (bytes > (size_t)KB_MC_KEEP_MAX_BYTES) {
+            set_error("keeping %lld runs x %d steps needs %.1f GiB on the device, above the %d GiB cap: run without KB_MC_KEEP_RUNS "
+                      "(Mean / StdDev / NewChiSquare do not need the trajectories)", (long long)b->N, steps, bytes / 1073741824.0,
+                      (int)(KB_MC_KEEP_MAX_BYTES >> 30));
+            return KB_ERR_INVALID;
+        }
+        if (b->traj_bytes < bytes) {
+            if (b->d_traj) KB_HIP(hipFree(b->d_traj));
+            b->d_traj = nullptr; b->traj_bytes = 0;
+            KB_HIP(hipMalloc(&b->d_traj, bytes));
+            b->traj_bytes = bytes;
+        }
+        traj = b->d_traj;
+    }
     StepArgs a;
     fill_step_args(*b, a);
     a.nsteps = steps;
     a.first_filter = first_run;
     a.step0 = 0;
-    if ((rc = launch_mc(*b, a, b->d_ctrl, ncontrols, b->d_mc))) return rc;
+    if ((rc = launch_mc(*b, a, b->d_ctrl, ncontrols, b->d_mc, traj, traj_ld))) return rc;
+    if (traj) { b->mc_steps = steps; b->mc_p = b->p; b->mc_ld = traj_ld; b->mc_first_run = first_run; b->mc_epoch = b->epoch; }
     std::vector<double> host(ndbl);
     KB_HIP(hipMemcpyAsync(host.data(), b->d_mc, ndbl * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     KB_HIP(hipStreamSynchronize(b->stream));
@@ -293,6 +334,64 @@ int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols, int
             sums[((size_t)t * 3 + 2) * n + i] = shift[(size_t)t * n + i];
         }
     b->epoch++;  // kf.Reset() after the sample (montecarlo.go:116): state untouched, noise re-seeded
+    return KB_OK;
+}
+
+// MonteCarloRuns.Runs[first + k].Estimates[t].State() / .Measurement() of the last kb_mc_run_ex(..., KB_MC_KEEP_RUNS)
+int kb_mc_get_runs(kb_batch *b, int64_t first, int64_t count, double *states, double *measurements) {
+    if (!b || (!states && !measurements)) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (!b->d_traj || b->mc_epoch < 0) { set_error("no Monte-Carlo runs kept on this batch: call kb_mc_run_ex with KB_MC_KEEP_RUNS first"); return KB_ERR_INVALID; }
+    if (first < 0 || count < 0 || first + count > b->N) { set_error("runs [%lld,+%lld) outside the batch", (long long)first, (long long)count); return KB_ERR_INVALID; }
+    if (count == 0) return KB_OK;
+    int rc = use_device(*b);
+    if (rc) return rc;
+    const int n = b->n, p = b->mc_p, steps = b->mc_steps;
+    const size_t per_run = (size_t)steps * (size_t)(n + p) * sizeof(double);
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(count, (int64_t)((size_t)256 << 20) / (int64_t)per_run));
+    if ((rc = ensure_stage(*b, (size_t)chunk * per_run))) return rc;
+    for (int64_t k0 = 0; k0 < count; k0 += chunk) {
+        const int64_t c = std::min(chunk, count - k0);
+        double *d_states = (double *)b->d_stage, *d_meas = d_states + (size_t)c * steps * n;
+        if ((rc = launch_traj_unpack(*b, first + k0, c, states ? d_states : nullptr, measurements ? d_meas : nullptr))) return rc;
+        if (states) KB_HIP(hipMemcpyAsync(states + (size_t)k0 * steps * n, d_states, (size_t)c * steps * n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        if (measurements) KB_HIP(hipMemcpyAsync(measurements + (size_t)k0 * steps * p, d_meas, (size_t)c * steps * p * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        KB_HIP(hipStreamSynchronize(b->stream));
+    }
+    return KB_OK;
+}
+
+// N copies of one filter of an initialised batch (model, initial estimate, noise) as a new batch
+int kb_replicate(kb_batch *src, int64_t filter, int64_t nfilters, unsigned flags, kb_batch **out) {
+    if (!src || !out) { set_error("null argument"); return KB_ERR_INVALID; }
+    *out = nullptr;
+    if (!src->initialized) { set_error("kb_init has not been called on the source batch"); return KB_ERR_INVALID; }
+    if (filter < 0 || filter >= src->N) { set_error("filter %lld outside the source batch", (long long)filter); return KB_ERR_INVALID; }
+    const unsigned inherit = KB_FLAG_INFO_FROM_STATE | KB_FLAG_SRIF_NON_TRI_R;
+    kb_batch *d = nullptr;
+    int rc = kb_create(&d, src->kind, src->n, src->pmax, src->m, nfilters, src->dtype, src->device,
+                       (flags & ~inherit) | (src->flags & inherit));
+    if (rc) return rc;
+    auto fail = [&](int code) { kb_destroy(d); return code; };
+    hipError_t e = hipStreamSynchronize(src->stream);   // the source's pending setters have landed
+    if (e != hipSuccess) return fail(hip_fail(e, "kb_replicate"));
+    if ((rc = launch_replicate(*d, src->d_state0, src->L.st_elems, filter, d->d_state0))) return fail(rc);
+    if ((rc = launch_replicate(*d, src->d_state0, src->L.st_elems, filter, d->d_state))) return fail(rc);
+    if ((rc = launch_replicate(*d, src->d_model, src->L.mo_elems, filter, d->d_model))) return fail(rc);
+    d->p = src->p; d->r_p = src->r_p; d->rinv_p = src->rinv_p; d->sqrt_p = src->sqrt_p; d->need_ctrl = src->need_ctrl;
+    for (int i = 0; i < 8; i++) d->have[i] = src->have[i];
+    d->noise_kind = src->noise_kind; d->seed = src->seed; d->epoch = src->epoch; d->ekf = src->ekf;
+    if (src->noise_kind == KB_NOISE_BATCH) {   // BatchNoise: the recorded vectors are shared by every filter of a batch
+        const size_t pb = (size_t)src->bn_nproc * src->n * src->esize(), mb = (size_t)src->bn_nmeas * src->bn_p * src->esize();
+        if ((e = hipMalloc(&d->d_bn_proc, pb)) != hipSuccess || (e = hipMalloc(&d->d_bn_meas, mb)) != hipSuccess ||
+            (e = hipMemcpyAsync(d->d_bn_proc, src->d_bn_proc, pb, hipMemcpyDeviceToDevice, d->stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d->d_bn_meas, src->d_bn_meas, mb, hipMemcpyDeviceToDevice, d->stream)) != hipSuccess)
+            return fail(hip_fail(e, "kb_replicate (BatchNoise)"));
+        d->bn_nproc = src->bn_nproc; d->bn_nmeas = src->bn_nmeas; d->bn_p = src->bn_p;
+    }
+    if ((e = hipStreamSynchronize(d->stream)) != hipSuccess) return fail(hip_fail(e, "kb_replicate"));
+    d->initialized = true;
+    d->step = 0;
+    *out = d;
     return KB_OK;
 }
 

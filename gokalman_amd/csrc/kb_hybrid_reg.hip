@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
         T chk0 = T(0);
 #pragma unroll
         for (int e = 0; e < TR; e++) chk0 += Pm[e] * T(0);
-        if (chk0 != chk0) { if (active) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE); return; }
+        if (chk0 != chk0) { if (active) fail_step(a, tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE); return; }
         if (active) {
 #pragma unroll
             for (int i = 0; i < NS; i++) {
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
             for (int r = 0; r < NM; r++) { stnt(es, a.L.es_innov + r, innov[r]); stnt(es, a.L.es_yhat + r, real[r]); stnt(es, a.L.es_dobs + r, yv[r]); }
         }
     }
-    if (active && err) atomicOr(a.status + tile * KB_TILE + lane, err);
+    if (active && err) fail_step(a, tile * KB_TILE + lane, err);   // hybrid.go:150-152 returns before kf.step++
 }
 
 static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {

@@ -9,10 +9,6 @@
 
 namespace kb {
 
-// Transient bit of the per-filter status word, private to the library: set by the first kernel of a two-launch step whose
-// time update failed for that filter, consumed (and cleared) by the second kernel of the same step.  Never reported.
-constexpr uint32_t KB_ST_SKIP_STEP = 0x80000000u;
-
 // ---------------------------------------------------------------------------
 // HBM layout of one batch (all blocks AoSoA-64, see kb_device.h).
 //
@@ -46,6 +42,13 @@ struct Batch {
     void *d_est = nullptr;
     void *d_model = nullptr;
     uint32_t *d_status = nullptr;
+    // kf.step per filter.  The reference returns from a failed Update BEFORE `kf.step++` (vanilla.go:164-167 / :207-215 against
+    // :218; srif.go:112-114; hybrid.go:150-152): such a filter's step counter -- the index of its BatchNoise vectors and the k of
+    // its error messages -- falls one behind the number of Update calls.  lag[i] = calls that failed for filter i that way;
+    // kf.step of filter i = step - lag[i].  One-tile batches (the drop-in use, N = 1) keep the words in pinned, device-mapped
+    // host memory so that kb_step() is exact without a device read.
+    uint32_t *d_lag = nullptr, *h_lag = nullptr;
+    int64_t calls = 0;         // Update / Predict / Reset calls accepted so far (monotone: stale-view detection in the host mirrors)
     void *d_stage = nullptr;   // AoS staging for host <-> device transfers
     size_t stage_bytes = 0;
     void *d_y = nullptr, *d_u = nullptr;  // AoSoA staging of host measurements / controls
@@ -56,10 +59,13 @@ struct Batch {
     void *d_xp = nullptr;      // cached getter scratch: materialised State() | Covariance() (x[n] | P packed) per filter
     uint8_t *d_flags = nullptr;  // cached IsWithinNsigma output
     double *d_mc = nullptr; size_t mc_bytes = 0;
+    // Monte-Carlo runs kept on the device (kb_mc_run_ex with KB_MC_KEEP_RUNS): traj[(t * (n + p) + e) * mc_ld + run] = State() element
+    // e < n, Measurement() element e - n of run `run` at step t, in the batch dtype
+    void *d_traj = nullptr; size_t traj_bytes = 0; int mc_steps = 0, mc_p = 0; int64_t mc_ld = 0, mc_first_run = 0, mc_epoch = -1;
     bool initialized = false;
     bool have[8] = {false, false, false, false, false, false, false, false};  // KB_X..KB_R staged
     int need_ctrl = 0;
-    int64_t step = 0;
+    int64_t step = 0;          // step calls since construction / Reset (kf.step of a filter that never failed)
     int srif_tri = 1;      // KB_SRIF: R is upper triangular (constructor / measurement update wrote it; Predict() stores the full RBar)
     int rinv_p = 0;        // KB_INFORMATION: dimension R^-1 was computed for (stale-Rinv quirk)
     int sqrt_p = 0;        // KB_SQUAREROOT: dimension of chol(R)
@@ -90,6 +96,7 @@ int hip_fail(hipError_t e, const char *what);
 struct StepArgs {
     void *state, *est, *model;
     uint32_t *status;
+    uint32_t *lag;                               // per-filter failed-step count (Batch::d_lag)
     const void *y; int64_t y_es, y_ts, y_step;   // element stride, tile stride, step stride (elements)
     const void *y2; int64_t y2_es, y2_ts;        // NLDKF: computed observation
     const void *u; int64_t u_es, u_ts, u_step;
@@ -107,6 +114,13 @@ struct StepArgs {
     const void *bn_proc, *bn_meas; int bn_p;     // BatchNoise: [step][n], [step][bn_p]
 };
 
+// A step that fails the way the reference's Update returns (nil, err) BEFORE kf.step++ (vanilla.go:164-167, :207-215; srif.go:112-114;
+// hybrid.go:150-152): the status bits are reported and the filter's step counter stays behind by the steps that were not applied.
+__device__ __forceinline__ void fail_step(const StepArgs &a, int64_t fi, unsigned bits, unsigned nsteps = 1u) {
+    atomicOr(a.status + fi, bits);
+    a.lag[fi] += nsteps;   // the filter is owned by this lane: no atomic needed
+}
+
 // kb_pack.hip
 struct SnapArgs {   // kernel argument of the one-launch Estimate snapshot (kb_get_estimate): at most 6 members
     const void *block[6];
@@ -122,6 +136,8 @@ int launch_unpack(const Batch &b, const void *src_block, int src_elems, const in
                   int dst_elems, double *dst_aos, int64_t first, int64_t count);
 int launch_unpack_planar(const Batch &b, const void *src_block, int src_elems, const int16_t *map, int dst_elems,
                          void *dst, int64_t ld);
+int launch_replicate(const Batch &dst, const void *src_block, int elems, int64_t src_filter, void *dst_block);
+int launch_traj_unpack(const Batch &b, int64_t first, int64_t count, double *d_states, double *d_meas);
 
 // kb_vanilla.hip
 int launch_vanilla(const Batch &b, const StepArgs &a, bool fused);
@@ -147,7 +163,8 @@ bool hybrid_reg_ok(const Batch &b, const StepArgs &a);
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip
-int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums);
+// traj != nullptr: keep every run's State() and Measurement() per step (Batch::d_traj layout)
+int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, void *traj, int64_t traj_ld);
 int mc_repl();
 // shared host helpers (kb_api.hip)
 int use_device(const Batch &b);

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64) squareroot_gen_kernel(const StepArgs a) {
         for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
     unsigned err_acc = 0;
     for (int t = 0; t < a.nsteps; t++) {
-        const uint32_t stepno = (uint32_t)(a.step0 + t);
+        const uint32_t stepno = (uint32_t)(a.step0 + t) - a.lag[fi];   // kf.step of this filter
         // :139-147 x- = F x [+ G u]   (no process noise here)
         T xm[LD];
         mv_n<T, LD>(n, n, F, x, xm);
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
         for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
     unsigned err_acc = 0;
     for (int t = 0; t < a.nsteps; t++) {
-        const uint32_t stepno = (uint32_t)(a.step0 + t);
+        const uint32_t stepno = (uint32_t)(a.step0 + t) - a.lag[fi];   // kf.step of this filter
         // :163-165 zk = Finv^T (I Finv)
         T t1[LD * LD], zk[LD * LD], zq[LD * LD], zqi[LD * LD], Z[LD * LD];
         mm_nn<T, LD, LD, LD>(n, n, n, I, Fi, t1);
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
                     for (int j = 0; j < n; j++) stt(es, a.L.es_ppred + i * n + j, RBar[i * LD + j]);
                 for (int r = 0; r < p; r++) { stt(es, a.L.es_yhat + r, T(0)); stt(es, a.L.es_dobs + r, T(0)); }
             }
-        } else atomicOr(a.status + fi, err);
+        } else fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
         return;
     }
     const T *yr = (const T *)a.y + tile * a.y_ts + lane;
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) srif_gen_kernel(const StepArgs a) {
     bool finite = true;
     for (int i = 0; i < n; i++)
         for (int j = 0; j <= n; j++) finite = finite && (A[i * PC + j] * T(0) == T(0));
-    if (err) { atomicOr(a.status + fi, err); return; }   // singular Phi / R: srif.go:111-114 returns before any assignment
+    if (err) { fail_step(a, fi, err); return; }   // singular Phi / R: srif.go:111-114 returns before any assignment (and before kf.step++)
     // a non-finite Householder result is stored as it is (helper.go:142-172 has no guard) and flagged, as on the register paths
     if (!finite) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
     for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, A[i * PC + n]);
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
                 if (i != j) sym = sym && sym_close(PBar[j * LD + i], PBar[i * LD + j]);
             }
         if (!finite) err |= KB_ST_NONFINITE; else if (!sym) err |= KB_ST_ASYMMETRIC;
-        if (err) { atomicOr(a.status + fi, err); return; }
+        if (err) { fail_step(a, fi, err); return; }   // hybrid.go:136-138 returns before kf.step++
         for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, xBar[i]);
         for (int i = 0; i < n; i++)
             for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), PBar[i * LD + j]);
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(64) hybrid_gen_kernel(const StepArgs a) {
         }
     }
     if (!finite) err |= KB_ST_NONFINITE; else if (!sym) err |= KB_ST_ASYMMETRIC;
-    if (err) { atomicOr(a.status + fi, err); return; }
+    if (err) { fail_step(a, fi, err); return; }   // hybrid.go:150-152, :184-192 return before kf.step++
     for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, xh[i]);
     for (int i = 0; i < n; i++)
         for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), Pn[i * LD + j]);

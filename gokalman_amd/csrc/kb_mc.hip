@@ -38,10 +38,15 @@ __device__ __forceinline__ void wave_sum_multi(double (&v)[V], int lane) {
     for (int o = V; o < 64; o <<= 1) v[0] += __shfl_xor(v[0], o, 64);
 }
 
-template <typename T, int NS, int NC>
+// KEEP: every run's estimate is also written out per step (MonteCarloRun.Estimates[k], montecarlo.go:108-117, as far as it
+// differs between runs): State() = x_k and Measurement() = yhat_k = H x_{k-1} + v_k (vanilla.go:155-157; the draw the
+// chi-square replay of kb_chisq.hip makes), traj[(t (n + p) + e) ld + run].  The measurement dimension is a run-time loop
+// over the model block: this variant serves the reference-sized ensembles (50 x 120, 15 x 1086), not the benchmark.
+template <typename T, int NS, int NC, bool KEEP = false>
 __global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__restrict__ controls, int ncontrols,
                                                  double *__restrict__ sums /* [REPL][steps][2][NS] */,
-                                                 double *__restrict__ shift /* [steps][NS] */) {
+                                                 double *__restrict__ shift /* [steps][NS] */,
+                                                 T *__restrict__ traj = nullptr, int64_t traj_ld = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= a.ntiles) return;
@@ -64,6 +69,20 @@ __global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__re
     double *my = sums + (size_t)(tile % MC_REPL) * a.nsteps * 2 * NS;
     const uint64_t gfi = (uint64_t)(a.first_filter + fi);
     for (int t = 0; t < a.nsteps; t++) {
+        if constexpr (KEEP) {
+            if (active) {
+                T *row = traj + ((int64_t)t * (NS + a.p) + NS) * traj_ld + fi;
+                for (int r = 0; r < a.p; r++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int l = 0; l < NS; l++) s += ldt(mo, a.L.mo_H + r * NS + l) * x[l];   // yhat = H x_prev ...
+                    T v = T(0);
+                    for (int k = 0; k <= r; k++)                                                // ... + v_k, v = L_R z (Noise.Measurement(k))
+                        v += ldt(mo, a.L.mo_LR + symi(k, r)) * (T)normal_at(a.seed, gfi, (uint32_t)(a.step0 + t), (uint32_t)(a.epoch * 4 + 1), k);
+                    row[(int64_t)r * traj_ld] = s + v;
+                }
+            }
+        }
         T xn[NS], cn[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) {
@@ -101,6 +120,12 @@ __global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__re
             x[i] = xn[i] + s;
             c[i] = cn[i];
         }
+        if constexpr (KEEP) {
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < NS; i++) traj[((int64_t)t * (NS + a.p) + i) * traj_ld + fi] = x[i];
+            }
+        }
         constexpr int V = NS <= 2 ? 4 : (NS <= 4 ? 8 : 16);   // 2 NS values, padded to a power of two
         double acc[V];
 #pragma unroll
@@ -119,22 +144,27 @@ __global__ void __launch_bounds__(256) mc_kernel(const StepArgs a, const T *__re
 }
 
 template <typename T, int NS>
-static bool mc_try(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift) {
+static bool mc_try(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift, void *traj, int64_t traj_ld) {
     if (a.n != NS) return false;
     const int nc = a.need_ctrl ? a.m : 0;
     const dim3 grid = tile_grid(a.ntiles), block(256);
+#define KB_MC(NC_) do { \
+        if (traj) hipLaunchKernelGGL((mc_kernel<T, NS, NC_, true>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift, (T *)traj, traj_ld); \
+        else hipLaunchKernelGGL((mc_kernel<T, NS, NC_, false>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift, (T *)nullptr, (int64_t)0); \
+        return true; } while (0)
     switch (nc) {
-    case 0: hipLaunchKernelGGL((mc_kernel<T, NS, 0>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift); return true;
-    case 1: hipLaunchKernelGGL((mc_kernel<T, NS, 1>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift); return true;
-    case 2: hipLaunchKernelGGL((mc_kernel<T, NS, 2>), grid, block, 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift); return true;
+    case 0: KB_MC(0);
+    case 1: KB_MC(1);
+    case 2: KB_MC(2);
     }
+#undef KB_MC
     return false;
 }
 
 template <typename T>
-static int launch_mc_t(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift) {
-    const bool ok = mc_try<T, 2>(b, a, d_controls, ncontrols, d_sums, d_shift) || mc_try<T, 3>(b, a, d_controls, ncontrols, d_sums, d_shift) ||
-                    mc_try<T, 4>(b, a, d_controls, ncontrols, d_sums, d_shift) || mc_try<T, 6>(b, a, d_controls, ncontrols, d_sums, d_shift);
+static int launch_mc_t(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift, void *traj, int64_t traj_ld) {
+    const bool ok = mc_try<T, 2>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) || mc_try<T, 3>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) ||
+                    mc_try<T, 4>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) || mc_try<T, 6>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld);
     if (!ok) {
         set_error("kb_mc_run: no Monte-Carlo kernel for n=%d, m=%d (built: n in {2,3,4,6}, m <= 2)", a.n, a.need_ctrl ? a.m : 0);
         return KB_ERR_UNSUPPORTED;
@@ -144,10 +174,10 @@ static int launch_mc_t(const Batch &b, const StepArgs &a, const void *d_controls
 }
 
 // d_sums: [MC_REPL][steps][2][n] followed by shift [steps][n]
-int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums) {
+int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, void *traj, int64_t traj_ld) {
     double *d_shift = d_sums + (size_t)MC_REPL * a.nsteps * 2 * a.n;
-    if (b.dtype == KB_F64) return launch_mc_t<double>(b, a, d_controls, ncontrols, d_sums, d_shift);
-    return launch_mc_t<float>(b, a, d_controls, ncontrols, d_sums, d_shift);
+    if (b.dtype == KB_F64) return launch_mc_t<double>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld);
+    return launch_mc_t<float>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld);
 }
 
 int mc_repl() { return MC_REPL; }

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64) snapshot_kernel(SnapArgs sa, int64_t first
     }
     if (status && threadIdx.x == 0) {
         const uint32_t v = clear ? atomicExch(status + i, 0u) : status[i];
-        ((uint32_t *)(area + status_off))[k] = v & ~KB_ST_SKIP_STEP;
+        ((uint32_t *)(area + status_off))[k] = v;
     }
 }
 
@@ -77,6 +77,53 @@ int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t c
         hipLaunchKernelGGL(snapshot_kernel<double>, dim3((unsigned)count), dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear);
     else
         hipLaunchKernelGGL(snapshot_kernel<float>, dim3((unsigned)count), dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+// kb_replicate: every filter of dst becomes a copy of filter `sf` of src (same block layout)
+template <typename T>
+__global__ void replicate_kernel(const T *__restrict__ src, int elems, int64_t sf, T *__restrict__ dst, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const T *s = src + (sf / KB_TILE) * ((int64_t)KB_TILE * elems) + (sf % KB_TILE);
+    T *d = dst + (i / KB_TILE) * ((int64_t)KB_TILE * elems) + (i % KB_TILE);
+    for (int e = 0; e < elems; e++) d[(int64_t)e * KB_TILE] = s[(int64_t)e * KB_TILE];
+}
+
+int launch_replicate(const Batch &dst, const void *src_block, int elems, int64_t src_filter, void *dst_block) {
+    const unsigned blocks = (unsigned)((dst.N + 255) / 256);
+    if (dst.dtype == KB_F64)
+        hipLaunchKernelGGL(replicate_kernel<double>, dim3(blocks), dim3(256), 0, dst.stream, (const double *)src_block, elems, src_filter, (double *)dst_block, dst.N);
+    else
+        hipLaunchKernelGGL(replicate_kernel<float>, dim3(blocks), dim3(256), 0, dst.stream, (const float *)src_block, elems, src_filter, (float *)dst_block, dst.N);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
+// kb_mc_get_runs: trajectory buffer [(t * (n + p) + e) * ld + run] -> host layout [run][step][n] (states) and [run][step][p]
+// (measurements), float64.  One thread per (run, step), runs fastest: the reads are coalesced.
+template <typename T>
+__global__ void traj_unpack_kernel(const T *__restrict__ traj, int64_t ld, int n, int p, int steps, int64_t first, int64_t count,
+                                   double *__restrict__ states, double *__restrict__ meas) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * steps) return;
+    const int64_t k = idx % count;
+    const int t = (int)(idx / count);
+    const T *s = traj + ((int64_t)t * (n + p)) * ld + first + k;
+    if (states)
+        for (int e = 0; e < n; e++) states[(k * steps + t) * n + e] = (double)s[(int64_t)e * ld];
+    if (meas)
+        for (int e = 0; e < p; e++) meas[(k * steps + t) * p + e] = (double)s[(int64_t)(n + e) * ld];
+}
+
+int launch_traj_unpack(const Batch &b, int64_t first, int64_t count, double *d_states, double *d_meas) {
+    const int64_t total = count * b.mc_steps;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (b.dtype == KB_F64)
+        hipLaunchKernelGGL(traj_unpack_kernel<double>, dim3(blocks), dim3(256), 0, b.stream, (const double *)b.d_traj, b.mc_ld, b.n, b.mc_p, b.mc_steps, first, count, d_states, d_meas);
+    else
+        hipLaunchKernelGGL(traj_unpack_kernel<float>, dim3(blocks), dim3(256), 0, b.stream, (const float *)b.d_traj, b.mc_ld, b.n, b.mc_p, b.mc_steps, first, count, d_states, d_meas);
     KB_HIP(hipGetLastError());
     return KB_OK;
 }

@@ -1,7 +1,7 @@
 // kb_srif_pair.h -- SRIF Update (srif.go:101-160, :298-340, helper.go:142-172) with TWO LANES PER FILTER.
 //
 // Why: with one filter per lane the 18 x 13 Householder panel alone is 234 values per lane, so the one-filter-per-lane
-// kernels (kb_srif_reg.hip) run at one wave per SIMD out of the 512-register budget: a lone wave issues one vector
+// kernels of round 1 ran at one wave per SIMD out of the 512-register budget: a lone wave issues one vector
 // instruction every 4 cycles instead of 2, cannot overlap its own loads with its own arithmetic, and values beyond the
 // 256 architectural VGPRs cost a copy per use.  Here a wave owns 32 filters: lane f (0..31) and lane 32 + f share filter
 // f, the lower half of the wave holding the EVEN rows of every row-distributed matrix and the upper half the ODD rows.
@@ -24,11 +24,10 @@
 //   measurement    rows of [L Htilde | L y] are formed where they live; Householder with rows distributed over the halves:
 //                  per column one partial dot product per half + one exchange.  Row k is final after step k and is stored
 //                  from the half that owns it.
-// Arithmetic follows kb_srif_reg.hip (LU solves instead of inverse-then-multiply; exact singularity / non-finite flags);
+// Arithmetic as in the Predict() kernel of kb_srif_reg.hip (LU solves instead of inverse-then-multiply; exact singularity / non-finite flags);
 // dot products that span both halves are summed as (even rows) + (odd rows), a rounding-level reordering.
 // Failure semantics as everywhere (kb_srif_reg.hip header): a singular Phi / R skips this step for that filter only.
 #pragma once
-#include <cstdlib>
 #include <type_traits>
 
 #include "kb_internal.h"
@@ -332,7 +331,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         err = elo | ehi;
     }
     const bool ok = inb && err == 0;   // failed: (b, R) stay as they are, srif.go:111-114 returns before any assignment
-    if (err && inb && !is_hi) atomicOr(a.status + fi, err);
+    if (err && inb && !is_hi) fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- whitened measurement rows (srif.go:146-148): [L Htilde | L y].  Each half forms ALL rows of L Htilde for ITS
@@ -606,8 +605,8 @@ __global__ void __launch_bounds__(64 * KB_PAIR_WPB, (srif_pair_waves_per_simd<T,
     const int64_t first = tile * KB_TILE + half * 32;
     if (first >= a.N) return;
     const int64_t fi = first + (lane & 31);
-    // a non-zero status word: that filter may hold a dense R (it skipped the Update after a Predict()), see kb_srif_reg.hip
-    const bool flagged = fi < a.N && (a.status[fi] & ~KB_ST_SKIP_STEP) != 0u;
+    // a non-zero status word: that filter may hold a dense R (it skipped the Update after a Predict(), whose kernel stores the full RBar)
+    const bool flagged = fi < a.N && a.status[fi] != 0u;
     T *lds_lu = lds + wv * (NS * NS * 32);
     if (!a.srif_tri || __any(flagged)) srif_pair_tile<T, NS, NM, FULL, EXT, true>(a, tile, half, lane, lds_lu);
     else srif_pair_tile<T, NS, NM, FULL, EXT, false>(a, tile, half, lane, lds_lu);
@@ -619,8 +618,7 @@ static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
     if (a.ext_phi && a.ext_ld >= (int64_t(1) << 28)) return false;   // the upper half's Phi offset (+ ld elements) is a 32-bit byte offset
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
     const dim3 grid((unsigned)((2 * a.ntiles + KB_PAIR_WPB - 1) / KB_PAIR_WPB)), block(64 * KB_PAIR_WPB);
-    static const unsigned pad = getenv("KB_SRIF_PAIR_LDS_PAD") ? (unsigned)atoi(getenv("KB_SRIF_PAIR_LDS_PAD")) : 0u;   // occupancy experiments only
-#define KB_P(F_, E_) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, pad, b.stream, a)
+#define KB_P(F_, E_) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
     if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
     else      { if (ext) KB_P(false, true); else KB_P(false, false); }
 #undef KB_P

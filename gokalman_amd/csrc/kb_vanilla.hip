@@ -56,9 +56,10 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
         for (int j = 0; j < n; j++) H[r * LD + j] = ldt(mo, a.L.mo_H + r * n + j);
         for (int c = 0; c < p; c++) R[r * LD + c] = ldt(mo, a.L.mo_R + symi(r, c));
     }
-    unsigned err_acc = 0;
+    unsigned err_acc = 0, nfail = 0;
+    const uint32_t lag0 = a.lag[fi];   // kf.step of this filter = calls - failed calls (kb_internal.h)
     for (int t = 0; t < a.nsteps; t++) {
-        const uint32_t stepno = (uint32_t)(a.step0 + t);
+        const uint32_t stepno = (uint32_t)(a.step0 + t) - lag0;
         // x- = F x [+ G u] + w
         T xm[LD];
         for (int i = 0; i < n; i++) {
@@ -214,6 +215,7 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
         if (err_acc) err = 0;
         const bool ok = (err | err_acc) == 0;
         err_acc |= err;
+        nfail += ok ? 0u : 1u;
         if (ok) {
             if (full) {
                 T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
     for (int i = 0; i < n; i++) stt(st, a.L.st_vec + i, x[i]);
     for (int i = 0; i < n; i++)
         for (int j = i; j < n; j++) stt(st, a.L.st_mat + symi(i, j), P[i * LD + j]);
-    if (err_acc) atomicOr(a.status + fi, err_acc);
+    if (err_acc) fail_step(a, fi, err_acc, nfail);
 }
 
 // ---------------------------------------------------------------------------------

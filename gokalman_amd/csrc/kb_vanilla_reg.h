@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #endif
     __builtin_amdgcn_sched_barrier(0);
 
-    unsigned err_acc = 0;
+    unsigned err_acc = 0, nfail = 0;
     const int nsteps = FUSED ? a.nsteps : 1;
     for (int t = 0; t < nsteps; t++) {
         // ---- x- = F x [+ G u]
@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
         if (err_acc) err = 0;  // already frozen: keep the first failure only
         const bool ok = (err | err_acc) == 0;
         err_acc |= err;
+        nfail += ok ? 0u : 1u;   // vanilla.go:164-167, :207-215 return before kf.step++ (:218)
 
         if constexpr (FULL) {
             // Estimate extras of this step (only meaningful for the last fused step)
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
                     if (j < rn) stt(st, rn + symi(i, j), P[symi(i, j)]);
         }
     }
-    if (active && err_acc) atomicOr(a.status + tile * KB_TILE + lane, err_acc);
+    if (active && err_acc) fail_step(a, tile * KB_TILE + lane, err_acc, nfail);
 }
 
 template <typename T, int NS, int NM, int NC, bool WITH_FUSED = true>

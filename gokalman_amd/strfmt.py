@@ -13,7 +13,9 @@ import numpy as np
 
 
 def go_v(x):
-    """fmt's %v of a float64: shortest representation that round-trips, %e form for exponents < -4 or >= 21."""
+    """fmt's %v of a float64 = strconv's 'g' with the shortest digits that round-trip: %e form for decimal exponents < -4 or
+    >= 6 (ftoa.go: "if precision was the shortest possible, use precision 6 for this decision"), so fmt.Println(1e6) prints
+    1e+06 and 123456789.0 prints 1.23456789e+08.  (The threshold 21 belongs to encoding/json, not to fmt.)"""
     x = float(x)
     if math.isnan(x):
         return "NaN"
@@ -39,7 +41,7 @@ def go_v(x):
     e10 = ex + (lead - 1 if ip.strip("0") else lead - 1)
     digits = digits.rstrip("0") or "0"
     sign = "-" if x < 0 else ""
-    if e10 < -4 or e10 >= 21:
+    if e10 < -4 or e10 >= 6:
         m = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
         return "%s%se%s%02d" % (sign, m, "-" if e10 < 0 else "+", abs(e10))
     if e10 >= 0:

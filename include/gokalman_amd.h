@@ -143,6 +143,14 @@ int kb_set_dev(kb_batch *b, int field, const void *src, int64_t ld, int p_rows);
  * snapshots the initial estimate for kb_reset and unlocks kb_update. */
 int kb_init(kb_batch *b);
 
+/* A new batch of `nfilters` filters, every one a copy of filter `filter` of the initialised batch `src`: same kind, shape,
+ * dtype and device, its model (incl. the constructor products), its INITIAL estimate and its noise selection; step 0.
+ * This is how a host shim turns the reference's one-filter arguments into device batches without a host round trip:
+ * NewMonteCarloRuns(samples, ..., kf) runs `samples` copies of kf (montecarlo.go:108-117 re-uses kf after Reset()),
+ * NewChiSquare(kf, runs, ...) `runs` copies of kf (chisquare.go:38-41).  flags: KB_FLAG_FULL_ESTIMATE /
+ * KB_FLAG_STRICT_SYMCHECK of the new batch (the kind-defining flags are inherited). */
+int kb_replicate(kb_batch *src, int64_t filter, int64_t nfilters, unsigned flags, kb_batch **out);
+
 /* LDKF.Reset (vanilla.go:121-125): restore the initial estimate, step = 0,
  * clear status words, advance the noise stream (AWGN re-seeds on Reset). */
 int kb_reset(kb_batch *b);
@@ -222,7 +230,16 @@ int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count);
 int kb_clear_status(kb_batch *b);
 /* Estimate.IsWithinNsigma(N) (vanilla.go:231-239): out[i] = 1/0. */
 int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first, int64_t count);
-int64_t kb_step(const kb_batch *b);       /* kf.step */
+/* kf.step.  The reference does not advance it on a failed Update (it returns before `kf.step++`: vanilla.go:164-167 / :207-215
+ * against :218; srif.go:112-114; hybrid.go:150-152), so a filter's counter -- the index of its BatchNoise vectors, the k of its
+ * error messages -- falls behind the number of calls by the steps that failed FOR THAT FILTER.  The engine keeps that count per
+ * filter on the device.  kb_step: for a batch of at most 64 filters (the drop-in use: 1) the exact kf.step of filter 0, without
+ * a device read (valid after a synchronising call); for larger batches the counter of a filter that never failed.
+ * kb_filter_step: the exact kf.step of any filter (synchronises).  kb_calls: step / reset calls accepted so far (monotone:
+ * what a host mirror compares to tell a live estimate view from a stale one). */
+int64_t kb_step(const kb_batch *b);
+int kb_filter_step(kb_batch *b, int64_t filter, int64_t *step);
+int64_t kb_calls(const kb_batch *b);
 int kb_need_ctrl(const kb_batch *b);      /* kf.needCtrl (vanilla.go:39) */
 int kb_meas_dim(const kb_batch *b);       /* current rows of H */
 int64_t kb_num_filters(const kb_batch *b);
@@ -269,6 +286,19 @@ double kb_noise_normal(uint64_t seed, int64_t filter, int64_t epoch, int64_t ste
  * stream of a run depends only on its global index). */
 int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols,
               int64_t first_run, double *sums);
+/* Same with options.  KB_MC_KEEP_RUNS keeps what differs between the runs of MonteCarloRuns.Runs[r].Estimates[k]
+ * (montecarlo.go:11-15, :108-117) on the device -- State() = x_k and Measurement() = yhat_k = H x_{k-1} + v_k of every run
+ * and step, in the batch dtype, (n + p) x steps x N values -- for kb_mc_get_runs; AsCSV (montecarlo.go:62-89) and the
+ * NewChiSquare of the reference read exactly these.  Covariance / PredCovariance / Gain of those estimates do not depend on
+ * the run (a one-filter Noiseless batch stepped `steps` times gives them).  Refused above KB_MC_KEEP_MAX_BYTES: the
+ * statistics (Mean / StdDev, kb_chisquare with replay_last_mc) never need the trajectories. */
+#define KB_MC_KEEP_RUNS 0x1u
+#define KB_MC_KEEP_MAX_BYTES (8ll << 30)
+int kb_mc_run_ex(kb_batch *b, int steps, const double *controls, int ncontrols, int64_t first_run, double *sums,
+                 unsigned mc_flags);
+/* Runs [first, first + count) of the last kb_mc_run_ex(..., KB_MC_KEEP_RUNS): states[count][steps][n] and
+ * measurements[count][steps][p] (host, float64; either may be NULL). */
+int kb_mc_get_runs(kb_batch *b, int64_t first, int64_t count, double *states, double *measurements);
 /* MonteCarloRuns.Mean / StdDev (montecarlo.go:18-59) from (all-reduced) sums over
  * `runs` runs: mean[steps][n], stddev[steps][n] (unbiased, n-1, as gonum stat.StdDev). */
 int kb_mc_stats(const double *sums, int steps, int n, int64_t runs, double *mean, double *stddev);

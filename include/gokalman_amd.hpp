@@ -46,7 +46,7 @@ struct Matrix {
     Matrix(int r, int c, std::vector<double> d) : rows(r), cols(c), data(std::move(d)) {}
     Matrix(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0.0) {}
     bool shared() const { return data.size() == (size_t)rows * cols; }
-    int64_t count() const { return rows * cols ? (int64_t)(data.size() / ((size_t)rows * cols)) : 0; }
+    int64_t count() const { return (rows && cols) ? (int64_t)(data.size() / ((size_t)rows * cols)) : 0; }
     double At(int i, int j, int64_t filter = 0) const { return data[(size_t)filter * rows * cols + (size_t)i * cols + j]; }
 };
 using Vector = Matrix;  // cols == 1
@@ -66,7 +66,7 @@ inline bool IsNil(const Matrix &m) {                               // helper.go:
 // brackets (square ones for a single row), every element right-aligned to the widest, two spaces between columns, the
 // prefix in front of every line but the first.  Restated from gonum's documented behaviour (gonum is not available here:
 // byte equality with a Go run is unverified); the labels, order and prefixes are the reference's format strings.
-inline std::string go_v(double x) {   // fmt %v of a float64: shortest round-trip digits, %e form for exponents < -4 or >= 21
+inline std::string go_v(double x) {   // fmt %v of a float64 = strconv 'g', shortest round-trip digits: %e form for exponents < -4 or >= 6 (1e6 prints 1e+06)
     if (std::isnan(x)) return "NaN";
     if (std::isinf(x)) return x > 0 ? "+Inf" : "-Inf";
     if (x == 0.0) return std::signbit(x) ? "-0" : "0";
@@ -78,7 +78,7 @@ inline std::string go_v(double x) {   // fmt %v of a float64: shortest round-tri
     digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
     const int e10 = std::stoi(sci.substr(e + 1));
     const std::string sign = x < 0 ? "-" : "";
-    if (e10 < -4 || e10 >= 21) {
+    if (e10 < -4 || e10 >= 6) {
         char eb[16];
         std::snprintf(eb, sizeof(eb), "e%c%02d", e10 < 0 ? '-' : '+', std::abs(e10));
         return sign + digits.substr(0, 1) + (digits.size() > 1 ? "." + digits.substr(1) : "") + eb;
@@ -140,6 +140,12 @@ class Batch {
         : kind_(kind), n_(n), N_(N), flags_(flags) {
         check(kb_create(&h_, kind, n, p, m, N, dtype, device, flags));
     }
+    // N copies of filter `filter` of an initialised batch (kb_replicate): its model, its INITIAL estimate, its noise selection
+    static std::shared_ptr<Batch> Replicate(const Batch &src, int64_t filter, int64_t N, unsigned flags) {
+        kb_batch *h = nullptr;
+        check(kb_replicate(src.h_, filter, N, flags, &h));
+        return std::shared_ptr<Batch>(new Batch(h, src.kind_, src.n_, N, flags | (src.flags_ & (KB_FLAG_INFO_FROM_STATE | KB_FLAG_SRIF_NON_TRI_R))));
+    }
     ~Batch() { kb_destroy(h_); }
     Batch(const Batch &) = delete;
     Batch &operator=(const Batch &) = delete;
@@ -159,6 +165,7 @@ class Batch {
     }
 
    private:
+    Batch(kb_batch *adopted, int kind, int n, int64_t N, unsigned flags) : h_(adopted), kind_(kind), n_(n), N_(N), flags_(flags) {}
     kb_batch *h_ = nullptr;
     int kind_, n_;
     int64_t N_;
@@ -185,7 +192,7 @@ class Estimate {
     };
     Estimate() = default;
     // snapshot == true: download now (clear_status: read-and-clear the status words, the per-call error semantics)
-    Estimate(std::shared_ptr<Batch> b, bool snapshot, bool clear_status = false) : b_(std::move(b)), step_(kb_step(b_->handle())) {
+    Estimate(std::shared_ptr<Batch> b, bool snapshot, bool clear_status = false) : b_(std::move(b)), step_(kb_step(b_->handle())), calls_(kb_calls(b_->handle())) {
         if (snapshot) snap_ = download(*b_, clear_status);
     }
     bool Owning() const { return snap_ != nullptr; }
@@ -284,7 +291,7 @@ class Estimate {
     }
     void live() const {
         if (!b_) throw Error(KB_ERR_INVALID, "empty Estimate");
-        if (kb_step(b_->handle()) != step_)
+        if (kb_calls(b_->handle()) != calls_)   // kb_step is kf.step, which a failed Update does not advance: the call counter is monotone
             throw Error(KB_ERR_INVALID, "this Estimate is a view of step " + std::to_string(step_) + " but the batch is at step " +
                                             std::to_string(kb_step(b_->handle())) + ": Freeze() it before the next Update to keep it");
     }
@@ -293,16 +300,20 @@ class Estimate {
     }
     std::shared_ptr<Batch> b_;
     std::shared_ptr<const Snapshot> snap_;
-    int64_t step_ = 0;
+    int64_t step_ = 0, calls_ = 0;
 };
 
-// The estimate of the step that just ran, with the reference's per-call error behaviour.
-inline Estimate step_estimate(const std::shared_ptr<Batch> &b, const char *what_failed) {
+// The estimate of the step that just ran, with the reference's per-call error behaviour.  at_k: srif.go:113 and hybrid.go:151
+// print the step ("... at k=%d: ..."), vanilla.go:166 does not.  kf.step is not advanced by the failed call (kb_step), so it
+// still is the k of the step that failed.
+inline Estimate step_estimate(const std::shared_ptr<Batch> &b, const char *what_failed, bool at_k) {
     if (b->N() > kSnapshotMaxFilters) return Estimate(b, false);
     Estimate est(b, true, /*clear_status=*/true);
     if (b->N() == 1) {
         const uint32_t st = est.Status()[0];
-        if (st & KB_ST_SINGULAR) throw StepError(st, std::string("could not invert ") + what_failed + ": matrix singular or near-singular");
+        if (st & KB_ST_SINGULAR)
+            throw StepError(st, std::string("could not invert ") + what_failed + (at_k ? " at k=" + std::to_string(kb_step(b->handle())) : std::string()) +
+                                    ": matrix singular or near-singular");
         if (st & KB_ST_ASYMMETRIC) throw StepError(st, "matrix is not symmetric");                       // helper.go:76
         if (st & KB_ST_NONFINITE) throw StepError(st, "matrix is not symmetric (non-finite covariance)");  // NaN fails helper.go:75's comparison
     }
@@ -317,7 +328,7 @@ class LDKF {
     Estimate Update(const Vector &measurement, const Vector &control) {
         const std::vector<double> y = expand(measurement), u = expand(control);
         check(kb_update(b_->handle(), y.data(), measurement.rows, control.rows ? u.data() : nullptr, control.rows));
-        return step_estimate(b_, "`H*P_kp1_minus*H' + R`");   // vanilla.go:166
+        return step_estimate(b_, "`H*P_kp1_minus*H' + R`", false);   // vanilla.go:166
     }
     const Noise &GetNoise() const { return noise_; }
     const Matrix &GetStateTransition() const { return F_; }
@@ -425,12 +436,13 @@ class NLDKF {
     void Prepare(const Matrix &Phi, const Matrix &Htilde) {
         check(kb_prepare(b_->handle(), Phi.data.data(), Htilde.data.data(), Phi.shared() ? 1 : b_->N(), Phi.shared() ? 1 : 0));
     }
-    Estimate Predict() { check(kb_predict_nl(b_->handle())); return step_estimate(b_, what_failed()); }
+    Estimate Predict() { check(kb_predict_nl(b_->handle())); return step_estimate(b_, what_failed(), true); }
     Estimate Update(const Vector &realObservation, const Vector &computedObservation) {
         const std::vector<double> r = expand(realObservation), c = expand(computedObservation);
         check(kb_update_nl(b_->handle(), r.data(), realObservation.rows, c.data(), computedObservation.rows));
-        return step_estimate(b_, what_failed());
+        return step_estimate(b_, what_failed(), true);
     }
+    int64_t Step() const { return kb_step(b_->handle()); }
     bool EKFEnabled() const { return kb_ekf_enabled(b_->handle()) != 0; }
     void EnableEKF() { check(kb_set_ekf(b_->handle(), 1)); }
     void DisableEKF() { check(kb_set_ekf(b_->handle(), 0)); }
@@ -472,39 +484,186 @@ struct HybridKF : NLDKF {  // NewHybridKF(x0, P0, noise, measSize)   hybrid.go:2
     void SetNoise(const Noise &n) { b_->set(KB_R, n.R, n.R.rows); if (n.Q.rows > 0) b_->set(KB_Q, n.Q); }  // hybrid.go:68-70
 };
 
-// montecarlo.go:12-59, :92-119
-struct MonteCarloRuns {
-    int64_t runs;
-    int steps, n;
-    std::vector<double> mean, stddev;  // [steps][n]
-    std::vector<double> Mean(int step) const { return {mean.begin() + (size_t)step * n, mean.begin() + (size_t)(step + 1) * n}; }
-    std::vector<double> StdDev(int step) const { return {stddev.begin() + (size_t)step * n, stddev.begin() + (size_t)(step + 1) * n}; }
+// ---- Monte-Carlo runs (montecarlo.go:11-124) and the chi-square tests (chisquare.go:16-95) -------------------------------
+// Everything the reference's MonteCarloRuns holds, behind the same names.  The runs live on the device: per-step sums for
+// Mean / StdDev always, every run's State() / Measurement() per step (Runs, AsCSV) when the ensemble was kept.
+struct MonteCarloData {
+    int64_t runs = 0;        // all runs of the ensemble (montecarlo.go:12)
+    int steps = 0, n = 0, p = 0;
+    std::vector<double> mean, stddev;            // [steps][n]
+    std::shared_ptr<Batch> truth;                // one pure-predictor AWGN filter per run
+    std::vector<double> controls; int ncontrols = 0;
+    bool kept = false;
+    mutable std::vector<double> states, meas;    // [runs][steps][n], [runs][steps][p]: downloaded on first use
+    mutable std::vector<double> ppred, gain;     // [steps][n][n], [steps][n][p]: identical for every run
+    void need_kept() const {
+        if (!kept) throw Error(KB_ERR_INVALID, "these Monte-Carlo runs were not kept (NewMonteCarloRuns(..., keepRuns = true)): only Mean / StdDev / NewChiSquare are available");
+    }
+    void download() const {
+        need_kept();
+        if (!states.empty()) return;
+        const int64_t N = truth->N();
+        states.assign((size_t)N * steps * n, 0.0);
+        meas.assign((size_t)N * steps * p, 0.0);
+        check(kb_mc_get_runs(truth->handle(), 0, N, states.data(), meas.data()));
+    }
+    // P-_k and K_k do not see the noise: one Noiseless copy of the filter stepped through the controls with KB_FLAG_FULL_ESTIMATE
+    void shared() const {
+        need_kept();
+        if (!ppred.empty()) return;
+        auto one = Batch::Replicate(*truth, 0, 1, KB_FLAG_FULL_ESTIMATE);
+        check(kb_set_noise_kind(one->handle(), KB_NOISE_NOISELESS, 0));
+        const int m = ncontrols ? (int)(controls.size() / (size_t)ncontrols) : 0;
+        std::vector<double> y0((size_t)p, 0.0), u0((size_t)(m > 0 ? m : 1), 0.0), P((size_t)steps * n * n), K((size_t)steps * n * p);
+        const bool ctrl = kb_need_ctrl(one->handle()) != 0;
+        for (int t = 0; t < steps; t++) {
+            const double *u = !ctrl ? nullptr : (ncontrols == 1 ? u0.data() : controls.data() + (size_t)t * m);
+            check(kb_update(one->handle(), y0.data(), p, u, ctrl ? m : 0));
+            kb_estimate_view v{};
+            v.pred_covariance = P.data() + (size_t)t * n * n;
+            v.gain = K.data() + (size_t)t * n * p;
+            check(kb_get_estimate(one->handle(), 0, 1, &v));
+        }
+        ppred = std::move(P); gain = std::move(K);
+    }
 };
-inline MonteCarloRuns NewMonteCarloRuns(int64_t samples, int steps, int rowsH, const std::vector<Vector> &controls, Vanilla &kf) {
-    (void)rowsH;
-    if (kf.batch()->N() != samples) throw Error(KB_ERR_INVALID, "the batch must hold `samples` runs");
-    std::vector<double> ctrl;
-    for (const auto &c : controls) ctrl.insert(ctrl.end(), c.data.begin(), c.data.end());
-    const int n = kf.batch()->n();
-    std::vector<double> sums((size_t)steps * 3 * n);
-    check(kb_mc_run(kf.batch()->handle(), steps, ctrl.data(), (int)controls.size(), 0, sums.data()));
-    MonteCarloRuns r{samples, steps, n, std::vector<double>((size_t)steps * n), std::vector<double>((size_t)steps * n)};
-    check(kb_mc_stats(sums.data(), steps, n, samples, r.mean.data(), r.stddev.data()));
-    return r;
+
+// MonteCarloRun.Estimates[k] (montecarlo.go:108-117): what a pure-predictor Vanilla returns (vanilla.go:170-179):
+// {x-, yhat, 0, sym(P-), sym(P-), K}
+class MonteCarloEstimate {
+   public:
+    MonteCarloEstimate(std::shared_ptr<const MonteCarloData> d, int64_t run, int step) : d_(std::move(d)), r_(run), k_(step) {}
+    Vector State() const { d_->download(); return slice(d_->states, ((size_t)r_ * d_->steps + k_) * d_->n, d_->n, 1); }
+    Vector Measurement() const { d_->download(); return slice(d_->meas, ((size_t)r_ * d_->steps + k_) * d_->p, d_->p, 1); }
+    Vector Innovation() const { return Matrix(d_->p, 1); }
+    Matrix Covariance() const { return PredCovariance(); }
+    Matrix PredCovariance() const { d_->shared(); return slice(d_->ppred, (size_t)k_ * d_->n * d_->n, d_->n, d_->n); }
+    Matrix Gain() const { d_->shared(); return slice(d_->gain, (size_t)k_ * d_->n * d_->p, d_->n, d_->p); }
+    bool IsWithinNσ(double N) const {
+        const Vector x = State();
+        const Matrix P = Covariance();
+        for (int i = 0; i < d_->n; i++) {
+            const double ns = N * std::sqrt(P.At(i, i));
+            if (x.data[(size_t)i] > ns || x.data[(size_t)i] < -ns) return false;
+        }
+        return true;
+    }
+    bool IsWithin2σ() const { return IsWithinNσ(2); }
+
+   private:
+    static Matrix slice(const std::vector<double> &v, size_t off, int r, int c) {
+        return Matrix(r, c, std::vector<double>(v.begin() + (std::ptrdiff_t)off, v.begin() + (std::ptrdiff_t)(off + (size_t)r * c)));
+    }
+    std::shared_ptr<const MonteCarloData> d_;
+    int64_t r_;
+    int k_;
+};
+struct MonteCarloRun {   // montecarlo.go:122-124
+    std::vector<MonteCarloEstimate> Estimates;
+};
+
+struct MonteCarloRuns {   // montecarlo.go:11-15
+    int64_t runs = 0;
+    int steps = 0;
+    std::vector<MonteCarloRun> Runs;   // empty when the ensemble was not kept
+    std::shared_ptr<const MonteCarloData> data;
+    std::vector<double> Mean(int step) const {     // montecarlo.go:18-37
+        return {data->mean.begin() + (std::ptrdiff_t)((size_t)step * data->n), data->mean.begin() + (std::ptrdiff_t)((size_t)(step + 1) * data->n)};
+    }
+    std::vector<double> StdDev(int step) const {   // montecarlo.go:40-59 (stat.StdDev: n - 1)
+        return {data->stddev.begin() + (std::ptrdiff_t)((size_t)step * data->n), data->stddev.begin() + (std::ptrdiff_t)((size_t)(step + 1) * data->n)};
+    }
+    // AsCSV(headers) (montecarlo.go:62-89): one string per state component: "h-0,h-1,...,h-mean,h-stddev", then per step every
+    // run's value, the mean and the standard deviation, all %f
+    std::vector<std::string> AsCSV(const std::vector<std::string> &headers) const {
+        data->download();
+        const MonteCarloData &d = *data;
+        const int64_t N = d.truth->N();
+        auto f = [](double x) {   // Go's %f
+            if (std::isnan(x)) return std::string("NaN");
+            if (std::isinf(x)) return std::string(x > 0 ? "+Inf" : "-Inf");
+            char buf[400];
+            std::snprintf(buf, sizeof(buf), "%f", x);
+            return std::string(buf);
+        };
+        std::vector<std::string> rtn((size_t)d.n);
+        for (int i = 0; i < d.n; i++) {
+            const std::string &h = headers.at((size_t)i);
+            std::string out;
+            for (int64_t r = 0; r < N; r++) out += h + "-" + std::to_string(r) + ",";
+            out += h + "-mean," + h + "-stddev";
+            for (int k = 0; k < d.steps; k++) {
+                out += "\n";
+                for (int64_t r = 0; r < N; r++) out += f(d.states[((size_t)r * d.steps + k) * d.n + i]) + ",";
+                out += f(d.mean[(size_t)k * d.n + i]) + "," + f(d.stddev[(size_t)k * d.n + i]);
+            }
+            rtn[(size_t)i] = std::move(out);
+        }
+        return rtn;
+    }
+};
+
+constexpr size_t kMonteCarloAutoKeepBytes = (size_t)256 << 20;   // keepRuns < 0 keeps ensembles of the reference's size, not the benchmark's
+
+// NewMonteCarloRuns(samples, steps, rowsH, controls, kf) MonteCarloRuns   montecarlo.go:92-119.
+// kf is the reference's argument: ONE pure-predictor Vanilla (AWGN noise).  The `samples` runs the reference performs one after
+// the other on it, Reset() in between, are `samples` copies of it in one launch (kb_replicate + kb_mc_run_ex), and kf is left
+// Reset() as montecarlo.go:116 leaves it.  A kf that already is a batch of `samples` filters is used as it is.
+// keepRuns: 1 keeps every run for Runs / AsCSV (refused above KB_MC_KEEP_MAX_BYTES), 0 only the statistics, -1 decides by size.
+// firstRun: global index of this process's first run when an ensemble is sharded over GPUs.
+inline MonteCarloRuns NewMonteCarloRuns(int64_t samples, int steps, int rowsH, const std::vector<Vector> &controls, Vanilla &kf,
+                                        int keepRuns = -1, int64_t firstRun = 0) {
+    if (kf.batch()->kind() != KB_VANILLA_PREDICT)
+        throw Error(KB_ERR_INVALID, "the Kalman filter needed for the Monte Carlo runs must be a pure predictor");   // montecarlo.go:93-95 (a panic)
+    if ((int)controls.size() != 1 && (int)controls.size() != steps)
+        throw Error(KB_ERR_INVALID, "must provide as much control vectors as steps, or just one control vector");    // montecarlo.go:105-107 (a panic)
+    const int p = kb_meas_dim(kf.batch()->handle());
+    if (rowsH != p)   // montecarlo.go:111 hands Update a zero vector of rowsH rows; vanilla.go:133-135 rejects any other size
+        throw Error(KB_ERR_DIMS, "dimensions must agree: measurement (y)(" + std::to_string(rowsH) + "x...) H(" + std::to_string(p) + "x...)");
+    auto d = std::make_shared<MonteCarloData>();
+    d->runs = samples; d->steps = steps; d->n = kf.batch()->n(); d->p = p;
+    for (const auto &c : controls) d->controls.insert(d->controls.end(), c.data.begin(), c.data.end());
+    d->ncontrols = (int)controls.size();
+    const bool single = kf.batch()->N() == 1 && samples > 1;
+    d->truth = single ? Batch::Replicate(*kf.batch(), 0, samples, 0u) : kf.batch();
+    if (keepRuns < 0) keepRuns = (size_t)steps * (size_t)(d->n + p) * (size_t)d->truth->N() * sizeof(double) <= kMonteCarloAutoKeepBytes ? 1 : 0;
+    std::vector<double> sums((size_t)steps * 3 * d->n);
+    check(kb_mc_run_ex(d->truth->handle(), steps, d->controls.data(), d->ncontrols, firstRun, sums.data(), keepRuns ? KB_MC_KEEP_RUNS : 0u));
+    d->kept = keepRuns != 0;
+    if (single) kf.Reset();
+    d->mean.assign((size_t)steps * d->n, 0.0);
+    d->stddev.assign((size_t)steps * d->n, 0.0);
+    check(kb_mc_stats(sums.data(), steps, d->n, samples, d->mean.data(), d->stddev.data()));
+    MonteCarloRuns mc{samples, steps, {}, d};
+    if (d->kept) {
+        mc.Runs.resize((size_t)d->truth->N());
+        for (int64_t r = 0; r < d->truth->N(); r++) {
+            mc.Runs[(size_t)r].Estimates.reserve((size_t)steps);
+            for (int k = 0; k < steps; k++) mc.Runs[(size_t)r].Estimates.emplace_back(d, r, k);
+        }
+    }
+    return mc;
 }
 
-// NewChiSquare(kf, runs, controls, withNEES, withNIS) (NISmeans, NEESmeans, error)   chisquare.go:16-95
-// `truth` is the pure-predictor AWGN filter that generated the Monte-Carlo runs, `kf` the filter under test.
-inline std::pair<std::vector<double>, std::vector<double>> NewChiSquare(Vanilla &kf, Vanilla &truth, int steps, const std::vector<Vector> &controls,
+// NewChiSquare(kf LDKF, runs MonteCarloRuns, controls, withNEES, withNIS) (NISmeans, NEESmeans, error)   chisquare.go:16-95.
+// kf is the Vanilla filter under test -- one filter, which the reference Reset()s for every run (chisquare.go:39): every run of
+// `runs` is replayed against its own copy of kf in one launch (kb_chisquare with replay_last_mc; the truth's states and
+// measurements are regenerated from the runs' noise streams, they need not have been kept).
+inline std::pair<std::vector<double>, std::vector<double>> NewChiSquare(LDKF &kf, const MonteCarloRuns &runs, const std::vector<Vector> &controls,
                                                                         bool withNEES, bool withNIS) {
-    if (!withNEES && !withNIS) throw Error(KB_ERR_INVALID, "Chi Square requires either NEES or NIS or both");
+    if (!withNEES && !withNIS) throw Error(KB_ERR_INVALID, "Chi Square requires either NEES or NIS or both");   // chisquare.go:17-19
+    const int steps = runs.steps;
+    if ((int)controls.size() != 1 && (int)controls.size() != steps)
+        throw Error(KB_ERR_INVALID, "must provide as much control vectors as steps, or just one control vector");   // chisquare.go:35
     std::vector<double> ctrl;
     for (const auto &c : controls) ctrl.insert(ctrl.end(), c.data.begin(), c.data.end());
+    const auto &truth = runs.data->truth;
+    auto kfb = (kf.batch()->N() == 1 && truth->N() > 1) ? Batch::Replicate(*kf.batch(), 0, truth->N(), 0u) : kf.batch();
     std::vector<double> sums((size_t)steps * 2);
-    check(kb_chisquare(truth.batch()->handle(), kf.batch()->handle(), steps, ctrl.data(), (int)controls.size(), 0, 1, withNEES, withNIS, sums.data()));
+    check(kb_chisquare(truth->handle(), kfb->handle(), steps, ctrl.data(), (int)controls.size(), 0, 1, withNEES, withNIS, sums.data()));
     std::vector<double> nis((size_t)steps), nees((size_t)steps);
-    const double runs = (double)truth.batch()->N();
-    for (int t = 0; t < steps; t++) { nis[t] = sums[(size_t)t * 2] / runs; nees[t] = sums[(size_t)t * 2 + 1] / runs; }
+    const double n_runs = (double)truth->N();
+    for (int t = 0; t < steps; t++) { nis[(size_t)t] = sums[(size_t)t * 2] / n_runs; nees[(size_t)t] = sums[(size_t)t * 2 + 1] / n_runs; }
     return {nis, nees};
 }
 

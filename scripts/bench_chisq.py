@@ -16,9 +16,9 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 zero_u = np.zeros((1, 2))
 truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, m.x0, m.P0, m.Fcl, m.Gcl, m.H, m.Q, m.R, nfilters=runs, noise=k.NOISE_AWGN, seed=5044)
 kf = ga.FilterBatch.new_ldkf(k.VANILLA, m.x0, m.P0, m.Fcl, m.Gcl, m.H, m.Q, m.R, nfilters=runs)
-ga.new_chi_square(kf, truth, 600, zero_u, replay_last_mc=False)     # warm-up, ~30 ms: the GPU clocks are back up (bench.py warm_clocks)
+ga.new_chi_square(kf, truth, zero_u, steps=600)     # warm-up, ~30 ms: the GPU clocks are back up (bench.py warm_clocks)
 t0 = time.perf_counter()
-nis, nees = ga.new_chi_square(kf, truth, m.SAMPLES, zero_u, replay_last_mc=False)
+nis, nees = ga.new_chi_square(kf, truth, zero_u, steps=m.SAMPLES)
 dt_s = time.perf_counter() - t0
 print(json.dumps({"config": "chi-square, statOD5044 closed loop n=4 p=2", "runs": runs, "steps": m.SAMPLES, "seconds": dt_s,
                   "run_steps_per_s": runs * m.SAMPLES / dt_s, "nis_mean": float(nis.mean()), "nees_mean": float(nees.mean())}))

@@ -2,8 +2,13 @@
 //  1. an Estimate held across the next Update still reads ITS step (vanilla.go:216-218: a fresh estimate per Update);
 //  2. an Update that fails numerically throws (the reference's `return nil, err`, vanilla.go:164-167), leaves the
 //     previous estimate in place, and the next valid Update succeeds;
-//  3. the same for an SRIF whose Phi is singular at one step (srif.go:112-114).
+//  3. the same for an SRIF whose Phi is singular at one step (srif.go:112-114);
+//  4. kf.step is not advanced by the failed call (vanilla.go:164-167 returns before :218; srif.go:112-114 before :157), and
+//     the SRIF stays prepared (srif.go:158 `kf.locked = true` is not reached);
+//  5. NewMonteCarloRuns(samples, steps, rowsH, controls, kf) / runs.Runs[r].Estimates[k] / runs.AsCSV(headers) /
+//     NewChiSquare(kf, runs, controls, withNEES, withNIS) with the reference's signatures (montecarlo.go:92, :62-89, chisquare.go:16).
 // Prints "name v0 v1 ..." lines; tests/test_cpp_host.py compares them with the oracle.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -49,6 +54,7 @@ int main() {
         kf->SetMeasurementMatrix(Hzero);
         kf->SetNoise(zeroR);
         int threw = 0;
+        const long long step_before_fail = (long long)kf->Step();
         try {
             (void)kf->Update(NewVector(1, {1.1}), NewVector(0));
         } catch (const StepError &e) {
@@ -56,12 +62,14 @@ int main() {
             std::printf("step_error %s\n", e.what());
         }
         std::printf("singular_step_threw %d\n", threw);
+        const long long step_after_fail = (long long)kf->Step();
         // the filter kept est2 (prevEst untouched), and the next valid Update succeeds without any clean-up call
         kf->SetMeasurementMatrix(H);
         kf->SetNoise(good);
         const Estimate est3 = kf->Update(NewVector(1, {1.3}), NewVector(0));
         print_vec("x3", est3.State()); print_vec("P3", est3.Covariance());
         std::printf("status3 %u\n", est3.Status()[0]);
+        std::printf("vanilla_steps %lld %lld %lld\n", step_before_fail, step_after_fail, (long long)kf->Step());
 
         // ---- 3: SRIF 6 states / 2 measurements, singular Phi at the second step --------------------------------------
         const int n = 6, p = 2;
@@ -82,6 +90,7 @@ int main() {
         for (int j = 0; j < n; j++) bad.data[(size_t)2 * n + j] = 0.0;   // a zero row: exactly singular
         srif.Prepare(bad, Ht);
         int sthrew = 0;
+        const long long sstep_before = (long long)srif.Step();
         try {
             (void)srif.Update(NewVector(p, {0.5, -0.2}), NewVector(p, {0.45, -0.15}));
         } catch (const StepError &e) {
@@ -89,10 +98,52 @@ int main() {
             std::printf("srif_step_error %s\n", e.what());
         }
         std::printf("srif_singular_step_threw %d\n", sthrew);
+        const long long sstep_after = (long long)srif.Step();
+        // the failed call returned before `kf.locked = true` (srif.go:112-114 against :158): a second Update without a new
+        // Prepare() is accepted (and fails the same way), a successful one locks the filter again
+        int relocked = 0, retry_threw = 0;
+        try { (void)srif.Update(NewVector(p, {0.5, -0.2}), NewVector(p, {0.45, -0.15})); } catch (const StepError &) { retry_threw = 1; }
         srif.Prepare(phi(0.03), Ht);
         const Estimate s3 = srif.Update(NewVector(p, {0.6, -0.1}), NewVector(p, {0.55, -0.05}));
+        try { (void)srif.Update(NewVector(p, {0.6, -0.1}), NewVector(p, {0.55, -0.05})); } catch (const Error &e) { relocked = e.code == KB_ERR_LOCKED; }
+        std::printf("srif_steps %lld %lld %lld retry_threw %d relocked %d\n", sstep_before, sstep_after, (long long)srif.Step(), retry_threw, relocked);
         print_vec("srif_x1", s1.State());
         print_vec("srif_x3", s3.State()); print_vec("srif_P3", s3.Covariance());
+
+        // ---- 5: Monte-Carlo runs and chi-square with the reference's signatures (examples/robot/main.go:31-49) -------------
+        {
+            const double dt = 0.1;
+            Matrix Fr(2, 2, {1, dt, 0, 1}), Gr(2, 1, {0.5 * dt * dt, dt}), Hr(1, 2, {1, 0});
+            Matrix Qr(2, 2, {5e-2, 5e-4, 5e-4, 1e-3}), Rr(1, 1, {0.05});
+            const int sims = 6, steps = 5;
+            auto mcKF = NewPurePredictorVanilla(NewVector(2, {0.7, -0.3}), ScaledIdentity(2, 2.0), Fr, Gr, Hr, NewAWGN(Qr, Rr, 4242)).first;
+            auto chiKF = NewVanilla(NewVector(2, {0.0, 0.0}), ScaledIdentity(2, 2.0), Fr, Gr, Hr, NewNoiseless(Qr, Rr)).first;
+            std::vector<Vector> controls;
+            for (int k = 0; k < steps; k++) controls.push_back(NewVector(1, {std::cos(0.75 * (k + 1) * 0.1)}));
+            const MonteCarloRuns runs = NewMonteCarloRuns(sims, steps, 1, controls, *mcKF);
+            std::printf("mc_shape %lld %d %zu %zu\n", (long long)runs.runs, runs.steps, runs.Runs.size(), runs.Runs[0].Estimates.size());
+            for (int r = 0; r < sims; r++)
+                for (int k = 0; k < steps; k++) {
+                    char name[64];
+                    std::snprintf(name, sizeof(name), "mc_x_%d_%d", r, k);
+                    print_vec(name, runs.Runs[(size_t)r].Estimates[(size_t)k].State());
+                    std::snprintf(name, sizeof(name), "mc_y_%d_%d", r, k);
+                    print_vec(name, runs.Runs[(size_t)r].Estimates[(size_t)k].Measurement());
+                }
+            print_vec("mc_P_3", runs.Runs[2].Estimates[3].Covariance());
+            print_vec("mc_K_3", runs.Runs[2].Estimates[3].Gain());
+            std::printf("mc_mean_4 %.17g %.17g\nmc_std_4 %.17g %.17g\n", runs.Mean(4)[0], runs.Mean(4)[1], runs.StdDev(4)[0], runs.StdDev(4)[1]);
+            const auto csv = runs.AsCSV({"xi", "xi_dot"});
+            print_hex("mc_csv_0", csv[0]);
+            print_hex("mc_csv_1", csv[1]);
+            const auto chi = NewChiSquare(*chiKF, runs, controls, true, true);
+            std::printf("chi_nis");
+            for (double v : chi.first) std::printf(" %.17g", v);
+            std::printf("\nchi_nees");
+            for (double v : chi.second) std::printf(" %.17g", v);
+            std::printf("\n");
+            std::printf("mckf_step_after %lld\n", (long long)mcKF->Step());   // left Reset() (montecarlo.go:116)
+        }
     } catch (const Error &e) {
         std::fprintf(stderr, "gokalman error %d: %s\n", e.code, e.what());
         return 3;

@@ -76,7 +76,11 @@ def test_cpp_estimate_is_a_value_and_errors_are_per_call():
         out[name] = rest
     vec = lambda name: np.array([float(v) for v in out[name].split()])
     assert out["held_estimate_unchanged"] == "1"
-    assert out["singular_step_threw"] == "1" and "could not invert `H*P_kp1_minus*H' + R`" in out["step_error"]
+    assert out["singular_step_threw"] == "1" and "could not invert `H*P_kp1_minus*H' + R`: " in out["step_error"]   # vanilla.go:166: no "at k="
+    # kf.step (vanilla.go:164-167 returns before :218's kf.step++): 2 Updates, the failed one, one more
+    assert out["vanilla_steps"] == "2 2 3"
+    # srif.go:112-114 returns before :157 kf.step++ and :158 kf.locked = true; the message carries the k of the failed step (:113)
+    assert out["srif_steps"] == "1 1 2 retry_threw 1 relocked 1" and "could not invert `Φ` at k=1: " in out["srif_step_error"]
     assert out["status3"] == "0"          # the failed call did not poison the next one
     F, H = np.array([[1, 0.1], [0, 1.0]]), np.array([[1.0, 0]])
     Q, R = np.diag([1e-3, 1e-3]), np.array([[0.05]])
@@ -129,3 +133,40 @@ def test_cpp_estimate_is_a_value_and_errors_are_per_call():
     assert s.update_nl([0.6, -0.1], [0.55, -0.05]) == orc.OK
     np.testing.assert_allclose(vec("srif_x3"), s.state(), rtol=1e-9)
     np.testing.assert_allclose(vec("srif_P3").reshape(n, n), s.covariance(), rtol=1e-8, atol=1e-14)
+    # ---- NewMonteCarloRuns / Runs / AsCSV / NewChiSquare with the reference's signatures, one-filter arguments ------------
+    from gokalman_amd import _capi as kk
+    dt, sims, steps, seed = 0.1, 6, 5, 4242
+    Fr, Gr, Hr = np.array([[1, dt], [0, 1]]), np.array([[0.5 * dt * dt], [dt]]), np.array([[1.0, 0]])
+    Qr, Rr = np.array([[5e-2, 5e-4], [5e-4, 1e-3]]), np.array([[0.05]])
+    controls = np.cos(0.75 * (np.arange(steps) + 1) * 0.1).reshape(steps, 1)
+    assert out["mc_shape"] == "%d %d %d %d" % (sims, steps, sims, steps) and out["mckf_step_after"] == "0"
+    LQ, LR = orc.cholesky_lower(Qr)[1], orc.cholesky_lower(Rr)[1]
+    z = lambda r, t, which, cnt: np.array([kk.lib().kb_noise_normal(seed, r, 0, t, which, i) for i in range(cnt)])
+    ts, tm = np.zeros((sims, steps, 2)), np.zeros((sims, steps, 1))
+    for r in range(sims):
+        fr = orc.Filter.ldkf(orc.VANILLA_PREDICT, [0.7, -0.3], 2.0 * np.eye(2), Fr, Gr, Hr, Qr, Rr)
+        for t in range(steps):
+            assert fr.update(np.zeros(1), controls[t], w_pred=LQ @ z(r, t, 0, 2), v_meas=LR @ z(r, t, 1, 1)) == orc.OK
+            ts[r, t], tm[r, t] = fr.state(), fr.measurement()
+            np.testing.assert_allclose(vec("mc_x_%d_%d" % (r, t)), ts[r, t], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(vec("mc_y_%d_%d" % (r, t)), tm[r, t], rtol=1e-12, atol=1e-14)
+            if r == 2 and t == 3:
+                np.testing.assert_allclose(vec("mc_P_3").reshape(2, 2), fr.covariance(), rtol=1e-12)
+                np.testing.assert_allclose(vec("mc_K_3"), fr.gain().ravel(), rtol=1e-11)
+    np.testing.assert_allclose(vec("mc_mean_4"), ts[:, 4].mean(axis=0), rtol=1e-10)
+    np.testing.assert_allclose(vec("mc_std_4"), ts[:, 4].std(axis=0, ddof=1), rtol=1e-9)
+    for i, h in enumerate(["xi", "xi_dot"]):       # montecarlo.go:62-89
+        lines = bytes.fromhex(out["mc_csv_%d" % i]).decode().split("\n")
+        assert lines[0] == "".join("%s-%d," % (h, r) for r in range(sims)) + h + "-mean," + h + "-stddev" and len(lines) == steps + 1
+        for t in range(steps):
+            want = ["%f" % v for v in ts[:, t, i]] + ["%f" % ts[:, t, i].mean(), "%f" % ts[:, t, i].std(ddof=1)]
+            got = lines[t + 1].split(",")
+            assert len(got) == sims + 2 and np.allclose([float(v) for v in got], [float(v) for v in want], atol=1.01e-6)
+
+    def factory():
+        fo = orc.Filter.ldkf(orc.VANILLA, [0.0, 0.0], 2.0 * np.eye(2), Fr, Gr, Hr, Qr, Rr)
+        fo._H, fo._R = Hr, Rr
+        return fo
+    onis, onees = orc.chisquare(factory, ts, tm, controls)       # chisquare.go:16-95 on the same runs
+    np.testing.assert_allclose(vec("chi_nis"), onis, rtol=1e-8)
+    np.testing.assert_allclose(vec("chi_nees"), onees, rtol=1e-8)

@@ -30,14 +30,23 @@ def test_jerkcar_example_reproduces_reference_csv_rows(tmp_path):
 
 def test_robot_example_chisquare_is_consistent(tmp_path):
     import robot as ex
-    out = ex.main(str(tmp_path), runs=4096)
+    out = ex.main(str(tmp_path), runs=2048)
     assert 0.8 < out["nis_mean"] < 1.25          # p = 1
-    assert os.path.exists(tmp_path / "chisquare.csv") and os.path.exists(tmp_path / "montecarlo-xi.csv")
+    assert os.path.exists(tmp_path / "chisquare.csv")
+    # runs.AsCSV(headers) (examples/robot/main.go:43-47, montecarlo.go:62-89): every run's column, then mean and stddev
+    lines = open(tmp_path / "montecarlo-xi.csv").read().split("\n")
+    assert len(lines) == ex.STEPS + 1
+    assert lines[0].startswith("xi-0,xi-1,") and lines[0].endswith("xi-2047,xi-mean,xi-stddev")
+    row = np.array([float(v) for v in lines[ex.STEPS].split(",")])
+    assert row.shape == (2048 + 2,)
+    assert abs(row[:-2].mean() - row[-2]) <= 1.01e-6 and abs(row[:-2].std(ddof=1) - row[-1]) <= 1.01e-6   # all rounded to %f
 
 
 def test_statod5044_example_runs_end_to_end(tmp_path):
     import statod5044 as ex
-    out = ex.main(str(tmp_path), runs=1024)
+    out = ex.main(str(tmp_path), runs=64)
+    hdr = open(tmp_path / "mc-ctrl-dr.csv").readline().strip().split(",")   # AsCSV: main.go:87-91
+    assert hdr[0] == "dr-0" and hdr[-3:] == ["dr-63", "dr-mean", "dr-stddev"]
     assert np.all(np.isfinite(out["mc_stddev_last"])) and np.all(out["mc_stddev_last"] > 0)
     # every filter must follow the oracle (reference-order CPU restatement) run on the same measurements
     from oracle import oracle as orc

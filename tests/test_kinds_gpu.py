@@ -355,7 +355,7 @@ def test_chisquare_nees_nis_vs_oracle_replay():
     truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=77)
     kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, nfilters=runs)
     mc = ga.new_monte_carlo_runs(runs, steps, 1, controls, truth)
-    nis, nees = ga.new_chi_square(kf, truth, steps, controls)           # same runs as `mc`
+    nis, nees = ga.new_chi_square(kf, mc, controls)           # chisquare.go:16: (kf, runs, controls, withNEES, withNIS)
     LQ, LR = orc.cholesky_lower(Q)[1], orc.cholesky_lower(R)[1]
     ts, tm = np.zeros((runs, steps, 2)), np.zeros((runs, steps, 1))
     for r in range(runs):
@@ -366,6 +366,34 @@ def test_chisquare_nees_nis_vs_oracle_replay():
             ts[r, t], tm[r, t] = f.state(), f.measurement()
     for t in range(steps):
         assert np.allclose(mc.mean(t), ts[:, t].mean(axis=0), rtol=1e-9, atol=1e-12)
+        assert np.allclose(mc.stddev(t), ts[:, t].std(axis=0, ddof=1), rtol=1e-9, atol=1e-12)   # stat.StdDev: n - 1
+    # MonteCarloRuns.Runs[r].Estimates[k] (montecarlo.go:11-15, :108-117) against the oracle replay of every run
+    assert len(mc.Runs) == runs and len(mc.Runs[0].Estimates) == steps
+    for r in (0, 1, 17, runs - 1):
+        for t in (0, 1, steps // 2, steps - 1):
+            est = mc.Runs[r].Estimates[t]
+            assert np.allclose(est.state(), ts[r, t], rtol=1e-12, atol=1e-13) and np.allclose(est.measurement(), tm[r, t], rtol=1e-12, atol=1e-13)
+    assert synth.rel_frobenius(mc._states(), ts) <= 1e-12 and synth.rel_frobenius(mc._measurements(), tm) <= 1e-12
+    # the run-independent members: {x-, yhat, 0, sym(P-), sym(P-), K} (vanilla.go:170-179)
+    f = orc.Filter.ldkf(orc.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R)
+    for t in range(steps):
+        assert f.update(np.zeros(1), controls[t]) == orc.OK
+        e = mc.Runs[3].Estimates[t]
+        assert np.allclose(e.covariance(), f.covariance(), rtol=1e-12) and np.allclose(e.pred_covariance(), f.pred_covariance(), rtol=1e-12)
+        assert np.allclose(e.gain(), f.gain(), rtol=1e-11, atol=1e-14) and not e.innovation().any()
+    # AsCSV (montecarlo.go:62-89): per component, header + one line per step: every run, mean, stddev, all %f
+    csv = mc.as_csv(["xi", "xi_dot"])
+    assert len(csv) == 2
+    for i, text in enumerate(csv):
+        lines = text.split("\n")
+        assert len(lines) == steps + 1
+        h = ["xi", "xi_dot"][i]
+        assert lines[0] == "".join("%s-%d," % (h, r) for r in range(runs)) + h + "-mean," + h + "-stddev"
+        for t in (0, steps - 1):
+            want = "".join("%f," % v for v in ts[:, t, i]) + "%f,%f" % (ts[:, t, i].mean(), ts[:, t, i].std(ddof=1))
+            got = lines[t + 1]
+            assert len(got.split(",")) == runs + 2
+            assert np.allclose([float(v) for v in got.split(",")], [float(v) for v in want.split(",")], atol=1.01e-6)
 
     def factory():
         f = orc.Filter.ldkf(orc.VANILLA, x0, P0, F, G, H, Q, R)
@@ -376,9 +404,9 @@ def test_chisquare_nees_nis_vs_oracle_replay():
     assert np.allclose(nis, onis, rtol=1e-8) and np.allclose(nees, onees, rtol=1e-8)
     assert 0.3 < nis.mean() < 3.0     # a consistent filter has E[NIS] = p = 1
     with pytest.raises(ga.KalmanError, match="either NEES or NIS"):
-        ga.new_chi_square(kf, truth, steps, controls, with_nees=False, with_nis=False)
+        ga.new_chi_square(kf, mc, controls, with_nees=False, with_nis=False)
     with pytest.raises(ga.KalmanError, match="as much control vectors as steps"):
-        ga.new_chi_square(kf, truth, steps, controls[:2])
+        ga.new_chi_square(kf, mc, controls[:2])
 
 
 @pytest.mark.parametrize("kind", [k.HYBRID, k.SRIF])
@@ -455,7 +483,7 @@ def test_chisquare_means_are_p_and_n_for_a_consistent_filter_at_scale():
     x0, P0 = np.array([1.0, -0.5, 0.0, 0.0]), 1e-12 * np.eye(n)
     truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, x0, P0, F, None, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=5)
     kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, None, H, Q, R, nfilters=runs)
-    nis, nees = ga.new_chi_square(kf, truth, steps, np.zeros((1, 1)), replay_last_mc=False)
+    nis, nees = ga.new_chi_square(kf, truth, np.zeros((1, 1)), steps=steps)   # fresh runs drawn from the truth batch
     assert np.all(np.abs(nis - p) < 6 * np.sqrt(2 * p / runs)), nis
     assert np.all(np.abs(nees[1:] - n) < 6 * np.sqrt(2 * n / runs) + 0.02), nees   # step 0: P+ is still rank-deficient from P0 ~ 0
 

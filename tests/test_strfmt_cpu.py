@@ -6,7 +6,9 @@ from gokalman_amd import strfmt
 
 
 def test_go_v_matches_fmt_percent_v():
-    cases = {1.0: "1", 0.45: "0.45", 1e-5: "1e-05", 123456789.0: "123456789", 1e21: "1e+21", 1e20: "100000000000000000000",
+    # strconv 'g', shortest digits: exponent form from 1e6 on (fmt.Println(1e6) prints 1e+06) and below 1e-4
+    cases = {1.0: "1", 0.45: "0.45", 1e-5: "1e-05", 123456789.0: "1.23456789e+08", 1e21: "1e+21", 1e20: "1e+20", 1e6: "1e+06",
+             999999.0: "999999", 123456.789: "123456.789", 1234567.0: "1.234567e+06", -2.5e7: "-2.5e+07",
              0.0001: "0.0001", -2.5: "-2.5", 1 / 3: "0.3333333333333333", 5e-324: "5e-324", 100.0: "100", 0.0: "0",
              float("inf"): "+Inf", float("-inf"): "-Inf", 1.5e-7: "1.5e-07", 12345.678: "12345.678"}
     for x, want in cases.items():
