@@ -1,11 +1,12 @@
 // kb_information_reg.hip -- register-resident Information filter step (information.go:153-227)
-// for the benchmark shape (n = 6, p = 3, fp64), state-only outputs (i+, I+).  Batches created
-// with KB_FLAG_FULL_ESTIMATE (which also need yhat = H State(prev), i.e. one more n x n inverse,
-// and I-) and the stale-1x1-Rinv quirk go through the generic kernel.
+// for the benchmark shape (n = 6, p = 3, fp64) and the padded family up to 6 / 4 / 2.  FULL (KB_FLAG_FULL_ESTIMATE) also
+// writes I- and yhat = H State(prev) [+ Measurement(k) for an AWGN batch, information.go:192-194], which costs one more
+// n x n inverse per step (State() inverts I on every call, information.go:257-293); the stale-1x1-Rinv quirk is a template flag.
 // Per filter-step it reads i[n], I (packed), F^-1 [n^2], Q^-1 [n^2], H [p n], R^-1 [p^2], y[p] and
 // writes i, I.  The (M + Q^-1)^-1 inverse is the LU-pivoted register inverse (kb_device.h).
 #include "kb_internal.h"
 #include "kb_static.h"
+#include "kb_vanilla_reg.h"   // draw_normals / chol_times / TilePtr (the AWGN draw of the register kernels)
 
 namespace kb {
 #ifndef INFO_WPB
@@ -24,8 +25,9 @@ constexpr bool info_stash() { return INFO_STASH && sizeof(T) == 8 && NS > 4; }
 // PAD: run-time dimensions a.n <= NS, a.p <= NM, a.m <= NC on operands padded with zeros and an identity block in
 // Q^-1 (so that M + Q^-1 stays invertible; Z, I- and i- keep exact zeros in the padding): only loads and stores see
 // the real sizes (cf. kb_vanilla_reg.h).
-template <typename T, int NS, int NM, int NC, bool SCALAR_RINV, bool PAD = false>
+template <typename T, int NS, int NM, int NC, bool SCALAR_RINV, bool PAD = false, bool FULL = false, bool NOISE = false>
 __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_kernel(const StepArgs a) {
+    static_assert(FULL || !NOISE, "Information draws Measurement(k) only: nothing but the FULL estimate's yhat sees it");
     constexpr int TR = tri(NS);
     constexpr bool STASH = info_stash<T, NS>();
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
@@ -163,6 +165,16 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
             for (int l = 0; l < NS; l++) s += Z[i * NS + l] * zk[j * NS + l];
             Im[symi(i, j)] = zk[i * NS + j] + s;
         }
+    if constexpr (FULL) {   // I- leaves at once (Estimate.PredCovariance, information.go:295-316 inverts it lazily)
+        T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+#pragma unroll
+                for (int j = i; j < NS; j++)
+                    if (j < rn) stnt(es, a.L.es_ppred + symi(i, j), Im[symi(i, j)]);
+        }
+    }
     // H and R^-1 are only requested once zk and Z are dead (the other wave of the SIMD covers the latency)
 #pragma unroll
     for (int i = 0; i < TR; i++) pin(Im[i]);
@@ -219,6 +231,29 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         }
     }
     const bool ok = !(chk != chk);
+    [[maybe_unused]] T iprev[NS], Iprev[NS * NS];
+    if constexpr (FULL) {
+        // information.go:192-194 yhat = H State(prev) + Measurement(k), State() = inverse(I) i with the inverse mirrored from
+        // its upper triangle (AsSymDense), or ZEROS when gonum's Inverse reports a Condition error (singular, or cond > 1e16:
+        // information.go:284-288 -- the zero-covariance-until-observable rows of examples/jerkcar/information.csv).  The previous
+        // (i, I) are read again here (cache hits), BEFORE the state block is rewritten; H is requested again afterwards.
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(ip[i]);
+#pragma unroll
+        for (int e = 0; e < TR; e++) pin(Ip[e]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NS; i++) iprev[i] = (i < rn) ? ldt(st, i) : T(0);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) Iprev[i * NS + j] = (i < rn && j < rn) ? ldt(st, rn + symi(i, j)) : (i == j ? T(1) : T(0));
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(iprev[i]);
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) pin(Iprev[e]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (active && ok) {
 #pragma unroll
         for (int i = 0; i < NS; i++)
@@ -230,15 +265,72 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
                 if (j < rn) stt(st, rn + symi(i, j), Ip[symi(i, j)]);
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
+    if constexpr (FULL) {
+        __builtin_amdgcn_sched_barrier(0);
+        T Pp[NS * NS], xp[NS], yhat[NM];
+        const bool bad = inverse_lu<T, NS>(Iprev, Pp, rn);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int j = 0; j < NS; j++) s += (bad ? T(0) : Pp[(i <= j ? i : j) * NS + (i <= j ? j : i)]) * iprev[j];
+            xp[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(xp[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < NM; r++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
+            yhat[r] = s;
+        }
+        if constexpr (NOISE) {
+#pragma unroll
+            for (int r = 0; r < NM; r++) pin(yhat[r]);
+            __builtin_amdgcn_sched_barrier(0);
+            const TilePtr<const T> mot{(const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems), (unsigned)lane};
+            const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
+            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
+            T z1[NM], v[NM];
+            draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+            chol_times<T, NM>(mot.field(a.L.mo_LR), rp, z1, v);
+#pragma unroll
+            for (int r = 0; r < NM; r++) yhat[r] += v[r];
+        }
+        T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+        if (active && ok) {
+#pragma unroll
+            for (int r = 0; r < NM; r++)
+                if (r < rp) stnt(es, a.L.es_yhat + r, yhat[r]);
+        }
+    }
 }
+
+// Which instantiation a batch needs: the draws of an Information step only reach yhat (information.go:194), so a batch
+// without KB_FLAG_FULL_ESTIMATE runs the plain kernel whatever its Noise is; BatchNoise stays on the generic kernel.
+static bool info_variant(const StepArgs &a, bool &full, bool &noise) {
+    if (a.flags & KB_FLAG_STRICT_SYMCHECK) return false;
+    full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    noise = full && a.noise_kind == KB_NOISE_AWGN;
+    return a.noise_kind != KB_NOISE_BATCH;
+}
+#define KB_INFO_GO(SC_, PAD_)                                                                                                        \
+    do {                                                                                                                             \
+        if (!full) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, false, false>), grid, block, 0, b.stream, a); \
+        else if (!noise) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, false>), grid, block, 0, b.stream, a); \
+        else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, true>), grid, block, 0, b.stream, a);      \
+    } while (0)
 
 template <typename T, int NS, int NM, int NC = 0>
 static bool info_try(const Batch &b, const StepArgs &a) {
-    if (a.n != NS || a.p != NM || (a.rinv_p != NM && a.rinv_p != 1) || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 ||
-        (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) || a.noise_kind != KB_NOISE_NOISELESS)
+    bool full = false, noise = false;
+    if (a.n != NS || a.p != NM || (a.rinv_p != NM && a.rinv_p != 1) || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 || !info_variant(a, full, noise))
         return false;
-    if (a.rinv_p == 1) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, true>), dim3((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), dim3(64 * INFO_WPB), 0, b.stream, a);
-    else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, false>), dim3((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), dim3(64 * INFO_WPB), 0, b.stream, a);
+    const dim3 grid((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), block(64 * INFO_WPB);
+    if (a.rinv_p == 1) KB_INFO_GO(true, false);
+    else KB_INFO_GO(false, false);
     return true;
 }
 
@@ -246,12 +338,12 @@ static bool info_try(const Batch &b, const StepArgs &a) {
 template <typename T, int NS, int NM, int NC>
 static bool info_try_pad(const Batch &b, const StepArgs &a) {
     const int m = a.need_ctrl ? a.m : 0;
-    if (a.n > NS || a.p > NM || (a.rinv_p != a.p && a.rinv_p != 1) || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1 ||
-        (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) || a.noise_kind != KB_NOISE_NOISELESS)
+    bool full = false, noise = false;
+    if (a.n > NS || a.p > NM || (a.rinv_p != a.p && a.rinv_p != 1) || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1 || !info_variant(a, full, noise))
         return false;
     const dim3 grid((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), block(64 * INFO_WPB);
-    if (a.rinv_p == 1 && a.p != 1) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, true, true>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, false, true>), grid, block, 0, b.stream, a);
+    if (a.rinv_p == 1 && a.p != 1) KB_INFO_GO(true, true);
+    else KB_INFO_GO(false, true);
     return true;
 }
 

@@ -10,6 +10,7 @@
 // P, Q, R.
 #include "kb_internal.h"
 #include "kb_static.h"
+#include "kb_vanilla_reg.h"   // draw_normals / chol_times / TilePtr (the AWGN draws of the register kernels)
 
 namespace kb {
 #ifndef SQRT_WPB
@@ -33,7 +34,10 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 // PAD: run-time dimensions a.n <= NS, a.p <= NM, a.m <= NC on operands padded with zeros (and an identity block in
 // chol(R)): zero rows / columns of a QR panel produce no reflection (sqr_r's `refl` test) and leave the real entries
 // untouched, so only loads and stores see the real sizes (cf. kb_vanilla_reg.h).
-template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false>
+// NOISE: the batch's Noise is AWGN (noise.go:109-164).  SquareRoot.Update draws twice per step (squareroot.go:239, :268):
+// Measurement(k) into yhat -- only a FULL estimate keeps it -- and Process(k) into x+; x- carries no noise (:139-147).  The
+// draws come at the very end, when only x+, S+ (and K) are alive, with the stream indices of the generic kernel (which = 1, 2).
+template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false, bool NOISE = false>
 __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PAD>())) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
@@ -136,12 +140,14 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     smv<T, NM, NS>(H, xm, Hxm);
     if constexpr (FULL) {
         // :237-239 yhat = H x_prev.  x_prev is read a second time here (an L2 hit) instead of being kept in registers
-        // through the first factorisation; yhat and Uc leave at once.
+        // through the first factorisation; yhat and Uc leave at once.  (With NOISE yhat is formed at the end, next to its draw.)
         asm volatile("" ::: "memory");
-        T xp[NS], yhat[NM];
+        [[maybe_unused]] T xp[NS], yhat[NM];
+        if constexpr (!NOISE) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) xp[i] = (i < rn) ? ldt(st, i) : T(0);
-        smv<T, NM, NS>(H, xp, yhat);
+            for (int i = 0; i < NS; i++) xp[i] = (i < rn) ? ldt(st, i) : T(0);
+            smv<T, NM, NS>(H, xp, yhat);
+        }
         T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
         if (active) {
 #pragma unroll
@@ -149,9 +155,11 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
                 for (int j = i; j < NS; j++)
                     if (j < rn) stnt(es, a.L.es_ppred + symi(i, j), C[i * NS + j]);
+            if constexpr (!NOISE) {
 #pragma unroll
-            for (int r = 0; r < NM; r++)
-                if (r < rp) stnt(es, a.L.es_yhat + r, yhat[r]);
+                for (int r = 0; r < NM; r++)
+                    if (r < rp) stnt(es, a.L.es_yhat + r, yhat[r]);
+            }
         }
     }
 #pragma unroll
@@ -192,8 +200,53 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
         for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
         xn[i] = xm[i] + s;
-        chk += xn[i] * T(0);
     }
+    if constexpr (NOISE) {
+        // pin: keeps the factorisation and the gain in front of the (wave-uniform) noise branch -- see kb_vanilla_reg.h
+#pragma unroll
+        for (int i = 0; i < NS; i++) pin(xn[i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) pin(D[(NM + j) * DD + (NM + i)]);
+        if constexpr (FULL) {
+#pragma unroll
+            for (int e = 0; e < NS * NM; e++) pin(K[e]);
+#pragma unroll
+            for (int r = 0; r < NM; r++) pin(innov[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const TilePtr<const T> mot{(const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems), (unsigned)lane};
+        const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
+        const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
+        T z2[NS], w[NS];
+        draw_normals<T, NS>(a, gfi, stepno, 2u, z2);
+        chol_times<T, NS>(mot.field(a.L.mo_LQ), rn, z2, w);
+#pragma unroll
+        for (int i = 0; i < NS; i++) xn[i] += w[i];                      // squareroot.go:268 Process(k)
+        if constexpr (FULL) {
+            T z1[NM], v[NM], xp[NS], yhat[NM];
+            draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+            chol_times<T, NM>(mot.field(a.L.mo_LR), rp, z1, v);
+#pragma unroll
+            for (int i = 0; i < NS; i++) xp[i] = (i < rn) ? ldt(st, i) : T(0);   // x_prev: the state block is rewritten below
+#pragma unroll
+            for (int r = 0; r < NM; r++) {                               // squareroot.go:237-239 yhat = H x_prev + Measurement(k)
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
+                yhat[r] = s + v[r];
+            }
+            T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < NM; r++)
+                    if (r < rp) stnt(es, a.L.es_yhat + r, yhat[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++) chk += xn[i] * T(0);
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -223,23 +276,25 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
 }
 
-template <typename T, int NS, int NM, int NC = 0>
+template <typename T, int NS, int NM, int NC = 0, bool NOISE = false>
 static bool sqrt_try(const Batch &b, const StepArgs &a) {
-    if (a.n != NS || a.p != NM || a.sqrt_p != NM || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    if (a.n != NS || a.p != NM || a.sqrt_p != NM || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1) return false;
+    if (a.noise_kind != (NOISE ? KB_NOISE_AWGN : KB_NOISE_NOISELESS)) return false;
     const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, false, NOISE>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, false, NOISE>), grid, block, 0, b.stream, a);
     return true;
 }
 
 // any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input) on the padded instantiation
-template <typename T, int NS, int NM, int NC>
+template <typename T, int NS, int NM, int NC, bool NOISE = false>
 static bool sqrt_try_pad(const Batch &b, const StepArgs &a) {
     const int m = a.need_ctrl ? a.m : 0;
-    if (a.n > NS || a.p > NM || a.sqrt_p != a.p || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1 || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    if (a.n > NS || a.p > NM || a.sqrt_p != a.p || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1) return false;
+    if (a.noise_kind != (NOISE ? KB_NOISE_AWGN : KB_NOISE_NOISELESS)) return false;
     const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, true>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, true>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, true, NOISE>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, true, NOISE>), grid, block, 0, b.stream, a);
     return true;
 }
 
@@ -252,6 +307,9 @@ int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
     if (!done && b.dtype == KB_F64)   // shapes without an exact instantiation: padded register kernels up to 6 / 4 / 2
         done = sqrt_try_pad<double, 4, 2, 0>(b, a) || sqrt_try_pad<double, 4, 2, 2>(b, a) || sqrt_try_pad<double, 6, 4, 0>(b, a) ||
                sqrt_try_pad<double, 6, 4, 2>(b, a);
+    if (!done && b.dtype == KB_F64)   // AWGN batches: the benchmark shape exactly, everything else up to 6 / 4 / 2 padded
+        done = sqrt_try<double, 6, 3, 0, true>(b, a) || sqrt_try_pad<double, 4, 2, 0, true>(b, a) || sqrt_try_pad<double, 4, 2, 2, true>(b, a) ||
+               sqrt_try_pad<double, 6, 4, 0, true>(b, a) || sqrt_try_pad<double, 6, 4, 2, true>(b, a);
     if (!done) return launch_squareroot_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -55,8 +55,41 @@ __device__ __forceinline__ void stnt(const TilePtr<T> &p, int e, T v) { p.stnt(e
 // which leaves every real entry of the result unchanged (the extra terms are exact zeros); only loads, stores and
 // the condition-number test see the real sizes.  This is how shapes without an exact instantiation still get a
 // register-resident kernel (kb_vanilla_pad.hip).
-template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false>
+// NOISE: the batch's Noise is AWGN or BatchNoise (noise.go:67-164; wave-uniform choice at run time).  The three draws of a step
+// keep the reference's call order -- Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
+// into x+ (:195) -- and its index k = kf.step of THIS filter (calls minus failed calls, kb_internal.h).  They are made where
+// the register file has room: right in front of the innovation, after the gain, when F, P and Q are dead (x- is not used
+// before that point, so the sums are the reference's, in the reference's order).  chol(Q) / chol(R) (AWGN) are requested there,
+// once, after the normals have been drawn.
+// NV standard normals of the draw (filter, kf.step, which) (kb_device.h: Philox4x32-10 + Box-Muller, two per block)
+template <typename T, int NV>
+__device__ __forceinline__ void draw_normals(const StepArgs &a, uint64_t gfi, uint32_t stepno, uint32_t which, T (&z)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
+        uint32_t r[4];
+        Philox::gen(a.seed, gfi, stepno, ((uint32_t)(a.epoch * 4 + which) << 8) | (uint32_t)(k >> 1), r);
+        double z0, z1;
+        box_muller(r, z0, z1);
+        z[k] = (T)z0;
+        if (k + 1 < NV) z[k + 1] = (T)z1;
+        __builtin_amdgcn_sched_barrier(0);   // one Box-Muller at a time: interleaved, their temporaries (log, sincospi in fp64) add up
+    }
+}
+// w = L z with L = chol_L packed in the model block (L[i][k] at symi(k, i)); rows >= rv are padding
+template <typename T, int NV>
+__device__ __forceinline__ void chol_times(const TilePtr<const T> &moL, int rv, const T (&z)[NV], T (&w)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k <= i; k++) s += ((i < rv) ? ldnt(moL, symi(k, i)) : T(0)) * z[k];
+        w[i] = s;
+    }
+}
+
+template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false, bool NOISE = false>
 __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(T) * (NS * NS + NS * NM) > 8 * 56)) ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
+    static_assert(!(NOISE && FUSED), "the time-fused variant is Noiseless");
     constexpr int TR = tri(NS);
     constexpr int TM = tri(NM);
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;   // real sizes (compile-time constants unless PAD)
@@ -118,7 +151,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
             for (int c = 0; c < NC; c++) G[i * NC + c] = (i < rn && c < rm) ? ldnt(moG, i * rm + c) : T(0);
     }
-    if constexpr (!PREDICT) {
+    if constexpr (!PREDICT && !NOISE) {   // (with NOISE the measurement is requested behind the draws: NM fewer values alive through them)
 #pragma unroll
         for (int r = 0; r < NM; r++) y0[r] = (active && r < rp) ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
     }
@@ -134,6 +167,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 
     unsigned err_acc = 0, nfail = 0;
     const int nsteps = FUSED ? a.nsteps : 1;
+    [[maybe_unused]] const bool awgn = a.noise_kind == KB_NOISE_AWGN;
     for (int t = 0; t < nsteps; t++) {
         // ---- x- = F x [+ G u]
         T xm[NS];
@@ -190,6 +224,68 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
                 yhat[r] = s;
             }
         }
+        [[maybe_unused]] T wpost[(NOISE && !PREDICT) ? NS : 1];
+        if constexpr (NOISE) {
+            // The draws sit between the time update and the gain: the point of the step with the fewest live values (P-, H, R, x-:
+            // F, P and Q are dead, PH^T, S, K not yet formed).
+            // pin (kb_device.h): the wave-uniform AWGN / BatchNoise branch below splits the kernel into basic blocks, and without it
+            // LLVM sinks the whole time update BEHIND the branch, i.e. requests chol(Q) at the top of the kernel and carries it
+            // through the register peak (measured: 272 B of scratch per lane)
+#pragma unroll
+            for (int e = 0; e < TR; e++) pin(Pm[e]);
+#pragma unroll
+            for (int i = 0; i < NS; i++) pin(xm[i]);
+            if constexpr (FULL) {
+#pragma unroll
+                for (int r = 0; r < NM; r++) pin(yhat[r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the draws stay behind the gain (see the comment above draw_normals)
+            // (global filter index and kf.step are formed HERE, not at the top: nothing of the noise path is alive in the load phase)
+            const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
+            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
+            if (awgn) {
+                // all the normals first (only they are alive beside the filter's own values while the fp64 log / sincospi run),
+                // then chol(Q) is requested ONCE and applied to both Process draws; w' waits in 2 NS registers for x+
+                T z0[NS];
+                [[maybe_unused]] T z2[PREDICT ? 1 : NS];
+                [[maybe_unused]] T z1[FULL ? NM : 1];
+                draw_normals<T, NS>(a, gfi, stepno, 0u, z0);
+                if constexpr (FULL) draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+                if constexpr (!PREDICT) draw_normals<T, NS>(a, gfi, stepno, 2u, z2);
+                const TilePtr<const T> moLQ = mo.field(a.L.mo_LQ);
+                T w[NS];
+                chol_times<T, NS>(moLQ, rn, z0, w);
+#pragma unroll
+                for (int i = 0; i < NS; i++) xm[i] += w[i];                                        // Process(k), vanilla.go:146
+                if constexpr (!PREDICT) chol_times<T, NS>(moLQ, rn, z2, wpost);
+                if constexpr (FULL) {
+                    T v[NM];
+                    chol_times<T, NM>(mo.field(a.L.mo_LR), rp, z1, v);
+#pragma unroll
+                    for (int r = 0; r < NM; r++) yhat[r] += v[r];                                  // Measurement(k), vanilla.go:157
+                }
+            } else {   // BatchNoise: the recorded vectors of step k (noise.go:72-86)
+                const T *bp = (const T *)a.bn_proc + (int64_t)stepno * rn;
+#pragma unroll
+                for (int i = 0; i < NS; i++) {
+                    const T w = (i < rn) ? bp[i] : T(0);
+                    xm[i] += w;
+                    if constexpr (!PREDICT) wpost[i] = w;
+                }
+                if constexpr (FULL) {
+                    const T *bm = (const T *)a.bn_meas + (int64_t)stepno * rp;
+#pragma unroll
+                    for (int r = 0; r < NM; r++) yhat[r] += (r < rp) ? bm[r] : T(0);
+                }
+            }
+            if constexpr (!PREDICT) {
+#pragma unroll
+                for (int i = 0; i < NS; i++) pin(wpost[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) pin(xm[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- gain K = P- H^T (H P- H^T + R)^-1
         T PHt[NS * NM];
 #pragma unroll
@@ -237,7 +333,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
             // ---- innovation and state update
 #pragma unroll
             for (int r = 0; r < NM; r++) {
-                const T yv = (t == 0) ? y0[r] : ((active && r < rp) ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
+                const T yv = (t == 0 && !NOISE) ? y0[r] : ((active && r < rp) ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
                 T s = T(0);
 #pragma unroll
                 for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];
@@ -249,6 +345,10 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
                 for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
                 xn[i] = xm[i] + s;
+            }
+            if constexpr (NOISE) {
+#pragma unroll
+                for (int i = 0; i < NS; i++) xn[i] += wpost[i];   // vanilla.go:195: Process(k) a second time
             }
             // ---- Joseph form, upper triangle: P+ = K R K^T + A P- A^T,  A = I - K H
 #pragma unroll
@@ -367,14 +467,15 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
     if (active && err_acc) fail_step(a, tile * KB_TILE + lane, err_acc, nfail);
 }
 
-template <typename T, int NS, int NM, int NC, bool WITH_FUSED = true>
+template <typename T, int NS, int NM, int NC, bool WITH_FUSED = true, bool NOISE = false>
 static inline bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
     if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC) return false;
     if (fused && !WITH_FUSED) return false;
+    if ((a.noise_kind != KB_NOISE_NOISELESS) != NOISE) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
 #define KB_GO(FULL_, PRED_, FUSED_) \
-    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_>), grid, block, 0, b.stream, a)
+    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_, false, NOISE>), grid, block, 0, b.stream, a)
     if constexpr (WITH_FUSED) {
         if (fused) {
             if (a.predict) { if (full) KB_GO(true, true, true); else KB_GO(false, true, true); }
@@ -389,13 +490,14 @@ static inline bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
 }
 
 // Padded launch: any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input), one step per launch.
-template <typename T, int NS, int NM, int NC>
+template <typename T, int NS, int NM, int NC, bool NOISE = false>
 static inline bool try_pad(const Batch &b, const StepArgs &a) {
     const int m = a.need_ctrl ? a.m : 0;
     if (a.n > NS || a.p > NM || m > NC || (NC == 0) != (m == 0)) return false;
+    if ((a.noise_kind != KB_NOISE_NOISELESS) != NOISE) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
-#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true>), grid, block, 0, b.stream, a)
+#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true, NOISE>), grid, block, 0, b.stream, a)
     if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
     else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
 #undef KB_GO
@@ -406,5 +508,8 @@ static inline bool try_pad(const Batch &b, const StepArgs &a) {
 bool launch_vanilla_extra_shapes(const Batch &b, const StepArgs &a, bool fused);
 bool launch_vanilla_padded(const Batch &b, const StepArgs &a);
 bool launch_vanilla_padded8(const Batch &b, const StepArgs &a);
+// AWGN / BatchNoise batches (kb_vanilla_noise.hip, kb_vanilla_noise_pad.hip): every shape up to n = 8, p = 4, m = 2, fp64
+bool launch_vanilla_noise(const Batch &b, const StepArgs &a);
+bool launch_vanilla_noise_padded(const Batch &b, const StepArgs &a);
 
 }  // namespace kb

@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vfull", "sqrt", "info", "srif", "hybrid", "mc"]
+which = args or ["vfull", "vnoise", "sqrt", "info", "srif", "hybrid", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -75,6 +75,18 @@ if "vfull" in which:
     ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
     report("B': Vanilla 6/3 f64, FULL_ESTIMATE (also writes P-, K, innovation, yhat: +480 B)", N, ms, 1488 + 480, {"errors": int(np.count_nonzero(b.status()))},
            moved=rl.moved_bytes("vanilla_full", 6, 3))
+    del b
+
+if "vnoise" in which:
+    # config B with the reference's usual Noise object: AWGN (noise.go:109-164) -- three draws per filter-step (Process, Measurement,
+    # Process: vanilla.go:146,157,195) from the device's Philox stream, on the register kernel (kb_vanilla_reg.h, NOISE = true)
+    N = Nopt or (1 << 20)
+    d = synth.linear_batch(N, 6, 3, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], noise=k.NOISE_AWGN, seed=17)
+    ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+    report("B + AWGN: Vanilla 6/3 f64, noise drawn on the device", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))},
+           moved=rl.moved_bytes("vanilla_awgn", 6, 3))
     del b
 
 if "sqrt" in which or "info" in which:

@@ -218,3 +218,56 @@ def test_parity_gate_4096_filters_100_steps(kind, okind):
     ex = np.linalg.norm(x - xo, axis=1) / np.linalg.norm(xo, axis=1)
     eP = np.linalg.norm((P - Po).reshape(N, -1), axis=1) / np.linalg.norm(Po.reshape(N, -1), axis=1)
     assert ex.max() <= 1e-9 and eP.max() <= 1e-9, (ex.max(), eP.max())
+
+
+@pytest.mark.parametrize("n,p,m,full,predict", [(6, 3, 0, False, False), (6, 3, 0, True, False), (4, 2, 0, False, False), (4, 2, 2, True, False),
+                                                (2, 1, 1, True, False), (5, 3, 1, False, False), (8, 4, 2, True, False), (7, 2, 0, False, False),
+                                                (6, 3, 0, True, True), (4, 2, 2, False, True)])
+def test_vanilla_awgn_on_the_register_kernels_replayed_through_the_oracle(n, p, m, full, predict):
+    """AWGN (noise.go:109-164) on the register kernels (kb_vanilla_reg.h, NOISE): the device's draws (kb_noise_sample: the
+    standard normals of (filter, epoch, kf.step, which)) are replayed through the oracle in the reference's call order --
+    Process(k) into x-, Measurement(k) into yhat, Process(k) again into x+ (vanilla.go:146,157,195) -- 4096 filters x 20
+    steps for the benchmark shape, every other register-kernel family member (exact, padded, with / without control, pure
+    predictor) on a smaller batch."""
+    bench_shape = (n, p, m) == (6, 3, 0) and not predict
+    N, steps = (4096, 20) if bench_shape else (192, 6)
+    rng = np.random.default_rng(100 * n + 10 * p + m + (7 if full else 0))
+    F, G, H, Q, R, x0, P0, y, u = _random_model(rng, N, n, p, m, steps)
+    kind, okind = (k.VANILLA_PREDICT, orc.VANILLA_PREDICT) if predict else (k.VANILLA, orc.VANILLA)
+    b = ga.FilterBatch.new_ldkf(kind, x0, P0, F, G, H, Q, R, flags=k.FLAG_FULL_ESTIMATE if full else 0, noise=k.NOISE_AWGN, seed=4711)
+    for t in range(steps):
+        est = b.update(y[t], u[t] if m else None, snapshot=(t == steps - 1))
+    check = range(N) if not bench_shape else list(range(0, N, 37)) + [N - 1]
+    xs, Ps, ys, inn = [], [], [], []
+    for i in check:
+        LQ, LR = orc.cholesky_lower(Q[i])[1], orc.cholesky_lower(R[i])[1]
+        f = orc.Filter.ldkf(okind, x0[i], P0[i], F[i], G[i] if m else None, H[i], Q[i], R[i])
+        for t in range(steps):
+            w0, v, w2 = LQ @ b.noise_sample(i, 0, t, 0, n), LR @ b.noise_sample(i, 0, t, 1, p), LQ @ b.noise_sample(i, 0, t, 2, n)
+            assert f.update(y[t, i], u[t, i] if m else None, w_pred=w0, v_meas=v, w_post=w2) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); ys.append(f.measurement()); inn.append(f.innovation())
+    idx = np.array(list(check))
+    assert synth.rel_frobenius(est.state()[idx], np.array(xs)) <= TOL
+    assert synth.rel_frobenius(est.covariance()[idx], np.array(Ps)) <= TOL
+    if full:
+        assert synth.rel_frobenius(est.measurement()[idx], np.array(ys)) <= TOL
+        if not predict:
+            assert synth.rel_frobenius(est.innovation()[idx], np.array(inn)) <= 1e-7   # differences of O(1) numbers: absolute 1e-16
+    assert not b.status().any() and b.step() == steps
+
+
+def test_vanilla_noise_register_kernel_is_the_one_that_runs():
+    """The AWGN batch above must not fall back to the scratch-array generic kernel (the 16-30x cliff of round 2): the register
+    kernel and the generic kernel differ in FMA contraction, so their results differ in the last bits, while a second register
+    run is bit-identical.  KB_FLAG_STRICT_SYMCHECK forces the generic kernel."""
+    N, n, p, steps = 256, 6, 3, 5
+    d = synth.linear_batch(N, n, p, steps)
+    runs = []
+    for flags in (0, 0, k.FLAG_STRICT_SYMCHECK):
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=flags, noise=k.NOISE_AWGN, seed=9)
+        for t in range(steps):
+            b.update(d["y"][t])
+        runs.append((b.get(k.STATE), b.get(k.COVAR)))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert not np.array_equal(runs[0][1], runs[2][1])                      # another kernel ...
+    assert synth.rel_frobenius(runs[0][0], runs[2][0]) <= 1e-12 and synth.rel_frobenius(runs[0][1], runs[2][1]) <= 1e-12   # ... same filter
