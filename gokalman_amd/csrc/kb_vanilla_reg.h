@@ -59,8 +59,7 @@ __device__ __forceinline__ void stnt(const TilePtr<T> &p, int e, T v) { p.stnt(e
 // keep the reference's call order -- Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
 // into x+ (:195) -- and its index k = kf.step of THIS filter (calls minus failed calls, kb_internal.h).  They are made where
 // the register file has room: right in front of the innovation, after the gain, when F, P and Q are dead (x- is not used
-// before that point, so the sums are the reference's, in the reference's order).  chol(Q) / chol(R) (AWGN) are requested there,
-// once, after the normals have been drawn.
+// before that point, so the sums are the reference's, in the reference's order).
 // NV standard normals of the draw (filter, kf.step, which) (kb_device.h: Philox4x32-10 + Box-Muller, two per block)
 template <typename T, int NV>
 __device__ __forceinline__ void draw_normals(const StepArgs &a, uint64_t gfi, uint32_t stepno, uint32_t which, T (&z)[NV]) {
@@ -83,6 +82,42 @@ __device__ __forceinline__ void chol_times(const TilePtr<const T> &moL, int rv, 
         T s = T(0);
 #pragma unroll
         for (int k = 0; k <= i; k++) s += ((i < rv) ? ldnt(moL, symi(k, i)) : T(0)) * z[k];
+        w[i] = s;
+    }
+}
+// chol_L of a packed symmetric positive definite matrix held in registers (A[i][j] at symi(i, j)), Dpotrf's order of
+// operations (kb_dense.h cholesky_lower_rt); L[i][k], k <= i, at symi(k, i); rows / columns >= rv are padding and stay zero.
+// The noise kernels form chol(Q) / chol(R) from the Q / R they have loaded anyway instead of reading the factors the
+// constructor stored: 8 tri(n) bytes per filter-step less (168 of 1276 at n = 6), for ~60 FMAs.  kb_set_noise_kind has
+// checked positive definiteness (noise.go:148-156 panics otherwise).
+template <typename T, int NV>
+__device__ __forceinline__ void chol_packed(const T (&A)[tri(NV)], int rv, T (&L)[tri(NV)]) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        T ajj = A[symi(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) ajj -= L[symi(k, j)] * L[symi(k, j)];
+        const bool real = j < rv;
+        const T d = real ? sqrt(ajj) : T(0);
+        const T inv = real ? T(1) / d : T(0);
+        L[symi(j, j)] = d;
+#pragma unroll
+        for (int i = j + 1; i < NV; i++) {
+            T sum = A[symi(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; k++) sum -= L[symi(k, j)] * L[symi(k, i)];
+            L[symi(j, i)] = (real && i < rv) ? sum * inv : T(0);
+        }
+    }
+}
+// w = L z, L packed as above
+template <typename T, int NV>
+__device__ __forceinline__ void tri_times(const T (&L)[tri(NV)], const T (&z)[NV], T (&w)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k <= i; k++) s += L[symi(k, i)] * z[k];
         w[i] = s;
     }
 }
@@ -151,7 +186,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
             for (int c = 0; c < NC; c++) G[i * NC + c] = (i < rn && c < rm) ? ldnt(moG, i * rm + c) : T(0);
     }
-    if constexpr (!PREDICT && !NOISE) {   // (with NOISE the measurement is requested behind the draws: NM fewer values alive through them)
+    if constexpr (!PREDICT) {
 #pragma unroll
         for (int r = 0; r < NM; r++) y0[r] = (active && r < rp) ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
     }
@@ -245,22 +280,27 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
             if (awgn) {
                 // all the normals first (only they are alive beside the filter's own values while the fp64 log / sincospi run),
-                // then chol(Q) is requested ONCE and applied to both Process draws; w' waits in 2 NS registers for x+
+                // then chol(Q) is formed ONCE (from Q, kept alive until here) and applied to both Process draws; w' waits in
+                // 2 NS registers for x+
                 T z0[NS];
                 [[maybe_unused]] T z2[PREDICT ? 1 : NS];
                 [[maybe_unused]] T z1[FULL ? NM : 1];
                 draw_normals<T, NS>(a, gfi, stepno, 0u, z0);
                 if constexpr (FULL) draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
                 if constexpr (!PREDICT) draw_normals<T, NS>(a, gfi, stepno, 2u, z2);
-                const TilePtr<const T> moLQ = mo.field(a.L.mo_LQ);
                 T w[NS];
-                chol_times<T, NS>(moLQ, rn, z0, w);
+                {
+                    T LQ[TR];
+                    chol_packed<T, NS>(Q, rn, LQ);   // from the Q of the time update: no second stream (see chol_packed)
+                    tri_times<T, NS>(LQ, z0, w);
+                    if constexpr (!PREDICT) tri_times<T, NS>(LQ, z2, wpost);
+                }
 #pragma unroll
                 for (int i = 0; i < NS; i++) xm[i] += w[i];                                        // Process(k), vanilla.go:146
-                if constexpr (!PREDICT) chol_times<T, NS>(moLQ, rn, z2, wpost);
                 if constexpr (FULL) {
-                    T v[NM];
-                    chol_times<T, NM>(mo.field(a.L.mo_LR), rp, z1, v);
+                    T v[NM], LR[TM];
+                    chol_packed<T, NM>(R, rp, LR);
+                    tri_times<T, NM>(LR, z1, v);
 #pragma unroll
                     for (int r = 0; r < NM; r++) yhat[r] += v[r];                                  // Measurement(k), vanilla.go:157
                 }
@@ -333,7 +373,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
             // ---- innovation and state update
 #pragma unroll
             for (int r = 0; r < NM; r++) {
-                const T yv = (t == 0 && !NOISE) ? y0[r] : ((active && r < rp) ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
+                const T yv = (t == 0) ? y0[r] : ((active && r < rp) ? ldnt_at(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0));
                 T s = T(0);
 #pragma unroll
                 for (int l = 0; l < NS; l++) s += H[r * NS + l] * xm[l];

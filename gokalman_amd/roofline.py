@@ -48,8 +48,8 @@ def moved_bytes(kind, n, p, w=8):
         return w * (n + t + n * n + p * n + t + tp + p + n + t)
     if kind == "vanilla_full":  # + P-, K, innovation, yhat written
         return w * (n + t + n * n + p * n + t + tp + p + n + t + t + n * p + 2 * p)
-    if kind == "vanilla_awgn":  # + chol(Q) (requested once for both Process draws) and the filter's 4-byte step lag
-        return w * (n + t + n * n + p * n + t + tp + p + n + t + t) + 4
+    if kind == "vanilla_awgn":  # the Noiseless working set + the filter's 4-byte step lag (chol(Q) is formed in registers from Q)
+        return w * (n + t + n * n + p * n + t + tp + p + n + t) + 4
     if kind == "squareroot":    # x, S, F, H, chol Q, chol R, y -> x, S
         return w * (n + t + n * n + p * n + t + tp + p + n + t)
     if kind == "information":   # i, I, F^-1, Q^-1 (full), H, R^-1 (full), y -> i, I

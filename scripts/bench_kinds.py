@@ -77,6 +77,15 @@ if "vfull" in which:
            moved=rl.moved_bytes("vanilla_full", 6, 3))
     del b
 
+if "vbase" in which:   # the headline configuration (bench.py times it too): here as the same-box reference of the legs below
+    N = Nopt or (1 << 20)
+    d = synth.linear_batch(N, 6, 3, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+    report("B: Vanilla 6/3 f64", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("vanilla", 6, 3))
+    del b
+
 if "vnoise" in which:
     # config B with the reference's usual Noise object: AWGN (noise.go:109-164) -- three draws per filter-step (Process, Measurement,
     # Process: vanilla.go:146,157,195) from the device's Philox stream, on the register kernel (kb_vanilla_reg.h, NOISE = true)
