@@ -124,6 +124,12 @@ HeavyScope::~HeavyScope() {
             if (ev_[i]) (void)hipEventDestroy(ev_[i]);   // released by the runtime once the recorded work has completed
 }
 
+// After a synchronisation of the handle's stream: a KB_SRIF batch that ran the dense Update kernel learns here whether any
+// filter failed in it (Batch::srif_leftover); if none did, the steady-state kernel runs alone again.
+void after_sync(Batch &b) {
+    if (b.srif_leftover && b.h_srif_fail && *b.h_srif_fail == 0u) b.srif_leftover = 0;
+}
+
 int use_device(const Batch &b) {
     KB_HIP(hipSetDevice(b.device));
     return KB_OK;
@@ -218,6 +224,7 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p; a.srif_tri = b.srif_tri;
+    a.srif_leftover = b.srif_leftover; a.srif_dense_fail = b.d_srif_fail;
     a.ekf = b.ekf; a.snc = b.snc; a.predict = (b.kind == KB_VANILLA_PREDICT);
     a.noise_kind = b.noise_kind; a.seed = b.seed; a.epoch = b.epoch; a.step0 = b.step; a.first_filter = 0;
     a.bn_proc = b.d_bn_proc; a.bn_meas = b.d_bn_meas; a.bn_p = b.bn_p;
@@ -322,6 +329,11 @@ int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, i
     KB_TRY(hipMemsetAsync(b->d_state0, 0, b->block_bytes(b->L.st_elems), b->stream));
     KB_TRY(hipMemsetAsync(b->d_model, 0, b->block_bytes(b->L.mo_elems), b->stream));
     KB_TRY(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
+    if (kind == KB_SRIF) {
+        KB_TRY(hipHostMalloc((void **)&b->h_srif_fail, sizeof(uint32_t), hipHostMallocMapped));
+        *b->h_srif_fail = 0u;
+        KB_TRY(hipHostGetDevicePointer((void **)&b->d_srif_fail, b->h_srif_fail, 0));
+    }
     if (flags & KB_FLAG_FULL_ESTIMATE) {
         KB_TRY(hipMalloc(&b->d_est, b->block_bytes(b->L.es_elems)));
         KB_TRY(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
@@ -342,6 +354,7 @@ void kb_destroy(kb_batch *b) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_lag) (void)hipHostFree(b->h_lag);
+    if (b->h_srif_fail) (void)hipHostFree(b->h_srif_fail);
     if (b->h_pin) (void)hipHostFree(b->h_pin);
     for (hipEvent_t e : b->ev_heavy)
         if (e) (void)hipEventDestroy(e);
@@ -462,7 +475,8 @@ int kb_reset(kb_batch *b) {
     b->step = 0;   // vanilla.go:123
     b->calls++;
     b->epoch++;  // AWGN.Reset re-seeds (noise.go:145-146)
-    if (is_nldkf(b->kind)) { b->locked = 1; b->snc = 0; b->srif_tri = 1; }
+    if (is_nldkf(b->kind)) { b->locked = 1; b->snc = 0; b->srif_tri = 1; b->srif_leftover = 0; }
+    if (b->h_srif_fail) *b->h_srif_fail = 0u;
     return KB_OK;
 }
 

@@ -78,7 +78,14 @@ static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
             a.ext_phi = a.ext_h = nullptr;
         }
     }
+    if (b->kind == KB_SRIF && !predict) {
+        // Batch::srif_leftover: once the stream has drained, the pinned word tells whether a filter failed in the dense kernel
+        if (b->srif_leftover && hipStreamQuery(b->stream) == hipSuccess) after_sync(*b);
+        a.srif_leftover = b->srif_leftover;
+        if (!b->srif_tri) KB_HIP(hipMemsetAsync(b->d_srif_fail, 0, sizeof(uint32_t), b->stream));   // a whole-batch dense Update: failures are counted afresh
+    }
     if ((rc = launch_nl(b, a))) return rc;
+    if (b->kind == KB_SRIF && !predict && !b->srif_tri) b->srif_leftover = 1;   // until a drained stream shows that nobody failed in it
     b->step++;
     b->calls++;
     b->srif_tri = predict ? 0 : 1;  // Predict() leaves the full RBar in R (srif.go:134-141), an Update a triangular R_k

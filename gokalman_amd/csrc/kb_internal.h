@@ -66,6 +66,11 @@ struct Batch {
     bool have[8] = {false, false, false, false, false, false, false, false};  // KB_X..KB_R staged
     int need_ctrl = 0;
     int64_t step = 0;          // step calls since construction / Reset (kf.step of a filter that never failed)
+    // KB_SRIF: some filter may hold a dense R although srif_tri is set (it failed the Update that followed a Predict()); the dense
+    // kernel raises *h_srif_fail (pinned, device-mapped) when that happens, and the flag is dropped at the next host synchronisation
+    // that finds the word at zero (kb_srif_pair.h)
+    int srif_leftover = 0;
+    uint32_t *h_srif_fail = nullptr, *d_srif_fail = nullptr;
     int srif_tri = 1;      // KB_SRIF: R is upper triangular (constructor / measurement update wrote it; Predict() stores the full RBar)
     int rinv_p = 0;        // KB_INFORMATION: dimension R^-1 was computed for (stale-Rinv quirk)
     int sqrt_p = 0;        // KB_SQUAREROOT: dimension of chol(R)
@@ -109,6 +114,7 @@ struct StepArgs {
     int need_ctrl;
     int rinv_p, sqrt_p;
     int srif_tri;                               // KB_SRIF: R is upper triangular (last writer: constructor or a measurement update)
+    int srif_leftover; uint32_t *srif_dense_fail;   // KB_SRIF: see Batch::srif_leftover
     int ekf, snc, predict;
     int noise_kind; uint64_t seed; int64_t epoch; int64_t step0; int64_t first_filter;
     const void *bn_proc, *bn_meas; int bn_p;     // BatchNoise: [step][n], [step][bn_p]
@@ -168,6 +174,7 @@ int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int nco
 int mc_repl();
 // shared host helpers (kb_api.hip)
 int use_device(const Batch &b);
+void after_sync(Batch &b);   // call after every hipStreamSynchronize of the handle's stream in a host-facing entry point
 int ensure_stage(Batch &b, size_t bytes);
 int ensure_xp(Batch &b);  // allocates Batch::d_xp on first use
 int stage_host_vec(Batch &b, const double *host, int rows, void **dblock, int slot, const void **tile);  // *tile: the AoSoA tile(s) the step kernel reads

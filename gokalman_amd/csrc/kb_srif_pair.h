@@ -130,7 +130,9 @@ struct Panel {
 // One half-tile (32 filters) of the SRIF Update.  DENSE: R may be a full matrix for some filter of this half-tile (the
 // Update right after a Predict(), or a filter that skipped such an Update): all of R is read, State(prev) is a pivoted LU
 // solve, and the finished factor's lower triangle is zeroed in memory.  DENSE = false is the steady state (R upper
-// triangular, structural zeros skipped at compile time).
+// triangular, structural zeros skipped at compile time).  The two variants are separate KERNELS (srif_pair_kernel,
+// srif_pair_dense_kernel): inside one kernel the dense variant's 144-register copy of R set the allocation of both (104 B of
+// scratch per lane in the code object although the steady-state path never touched it).
 template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE>
 __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, int half, int lane, T *lds_lu) {
     static_assert(NS % 2 == 0 && NM % 2 == 0, "rows are split by parity");
@@ -331,7 +333,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         err = elo | ehi;
     }
     const bool ok = inb && err == 0;   // failed: (b, R) stay as they are, srif.go:111-114 returns before any assignment
-    if (err && inb && !is_hi) fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
+    if (err && inb && !is_hi) {
+        fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
+        // a filter that fails HERE keeps a dense R: the host must keep sending its half-tile to this kernel (kb_internal.h srif_leftover)
+        if constexpr (DENSE) __hip_atomic_store(a.srif_dense_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- whitened measurement rows (srif.go:146-148): [L Htilde | L y].  Each half forms ALL rows of L Htilde for ITS
@@ -594,6 +600,9 @@ constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 *
 #define KB_PAIR_WPB 1   // waves per workgroup.  They share nothing; with 4 per workgroup a finished wave's slot and LDS stay
                         // reserved until its three companions are done: 89.8 us against 86.7 us (fp32, 256k filters)
 #endif
+// Steady state: every R of the batch is upper triangular (Batch::srif_tri).  With a.srif_leftover the batch may still hold filters
+// with a dense R (they failed the Update that followed a Predict()); those carry a non-zero status word, and their half-tiles are
+// left to srif_pair_dense_kernel, which the host launches right behind this kernel for as long as that can be the case.
 template <typename T, int NS, int NM, bool FULL, bool EXT>
 __global__ void __launch_bounds__(64 * KB_PAIR_WPB, (srif_pair_waves_per_simd<T, NS>())) srif_pair_kernel(const StepArgs a) {
     __shared__ T lds[KB_PAIR_WPB * NS * NS * 32];
@@ -604,12 +613,30 @@ __global__ void __launch_bounds__(64 * KB_PAIR_WPB, (srif_pair_waves_per_simd<T,
     const int half = (int)(gw & 1);
     const int64_t first = tile * KB_TILE + half * 32;
     if (first >= a.N) return;
-    const int64_t fi = first + (lane & 31);
-    // a non-zero status word: that filter may hold a dense R (it skipped the Update after a Predict(), whose kernel stores the full RBar)
-    const bool flagged = fi < a.N && a.status[fi] != 0u;
-    T *lds_lu = lds + wv * (NS * NS * 32);
-    if (!a.srif_tri || __any(flagged)) srif_pair_tile<T, NS, NM, FULL, EXT, true>(a, tile, half, lane, lds_lu);
-    else srif_pair_tile<T, NS, NM, FULL, EXT, false>(a, tile, half, lane, lds_lu);
+    if (a.srif_leftover) {
+        const int64_t fi = first + (lane & 31);
+        if (__any(fi < a.N && a.status[fi] != 0u)) return;
+    }
+    srif_pair_tile<T, NS, NM, FULL, EXT, false>(a, tile, half, lane, lds + wv * (NS * NS * 32));
+}
+
+// The Update right after a Predict() (a.srif_tri == 0: every R is the dense RBar the Predict() kernel stored), or the half-tiles
+// the steady-state kernel skipped (a.srif_tri != 0: only half-tiles with a non-zero status word).  One wave per SIMD: the
+// register-resident copy of R needs the 512-register budget.
+template <typename T, int NS, int NM, bool FULL, bool EXT>
+__global__ void __launch_bounds__(64, 1) srif_pair_dense_kernel(const StepArgs a) {
+    __shared__ T lds[NS * NS * 32];
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = blockIdx.x;
+    const int64_t tile = gw >> 1;
+    const int half = (int)(gw & 1);
+    const int64_t first = tile * KB_TILE + half * 32;
+    if (first >= a.N) return;
+    if (a.srif_tri) {
+        const int64_t fi = first + (lane & 31);
+        if (!__any(fi < a.N && a.status[fi] != 0u)) return;
+    }
+    srif_pair_tile<T, NS, NM, FULL, EXT, true>(a, tile, half, lane, lds);
 }
 
 template <typename T, int NS, int NM>
@@ -618,7 +645,12 @@ static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
     if (a.ext_phi && a.ext_ld >= (int64_t(1) << 28)) return false;   // the upper half's Phi offset (+ ld elements) is a 32-bit byte offset
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
     const dim3 grid((unsigned)((2 * a.ntiles + KB_PAIR_WPB - 1) / KB_PAIR_WPB)), block(64 * KB_PAIR_WPB);
-#define KB_P(F_, E_) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a)
+    const dim3 dgrid((unsigned)(2 * a.ntiles)), dblock(64);
+#define KB_P(F_, E_)                                                                                                                         \
+    do {                                                                                                                                     \
+        if (a.srif_tri) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a);                             \
+        if (!a.srif_tri || a.srif_leftover) hipLaunchKernelGGL((srif_pair_dense_kernel<T, NS, NM, F_, E_>), dgrid, dblock, 0, b.stream, a); \
+    } while (0)
     if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
     else      { if (ext) KB_P(false, true); else KB_P(false, false); }
 #undef KB_P
