@@ -53,8 +53,8 @@ static Layout make_layout(int kind, int n, int pmax, int m, unsigned flags) {
     L.mo_LR = o; o += tri(pmax);
     if (kind == KB_INFORMATION) {
         L.mo_Finv = o; o += n * n;
-        L.mo_Qinv = o; o += n * n;
-        L.mo_Rinv = o; o += pmax * pmax;
+        L.mo_Qinv = o; o += tri(n);      // Q^-1 and R^-1 are inverses of symmetric matrices: stored packed (upper triangle of the
+        L.mo_Rinv = o; o += tri(pmax);   // computed inverse, mirrored on use), 8 (n(n-1) + p(p-1)) / 2 bytes per filter-step less
     }
     L.mo_elems = o;
     return L;
@@ -222,6 +222,7 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     memset(&a, 0, sizeof(a));
     a.state = b.d_state; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status; a.lag = b.d_lag;
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
+    a.stream_state = b.block_bytes(b.L.st_elems) > KB_MALL_BYTES ? 1 : 0;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p; a.srif_tri = b.srif_tri;
     a.srif_leftover = b.srif_leftover; a.srif_dense_fail = b.d_srif_fail;

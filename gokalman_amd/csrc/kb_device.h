@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #define KB_TILE 64
 
 namespace kb {
@@ -33,6 +35,31 @@ __device__ __forceinline__ void stt(T *p, int e, T v) { p[(int64_t)e * KB_TILE] 
 // not push the state block out of the Infinity Cache
 template <typename T>
 __device__ __forceinline__ void stnt(T *p, int e, T v) { __builtin_nontemporal_store(v, p + (int64_t)e * KB_TILE); }
+
+// State-block accesses with the cache policy as a compile-time flag: the kernels pick it per batch through a wave-uniform branch
+// (StepArgs::stream_state; the policy and its measurements: kb_vanilla_reg.h)
+template <bool NT, typename T>
+__device__ __forceinline__ T ldp(const T *p, int e) {
+    if constexpr (NT) return ldnt(p, e);
+    else return ldt(p, e);
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stp(T *p, int e, T v) {
+    if constexpr (NT) stnt(p, e, v);
+    else stt(p, e, v);
+}
+// (the empty asm statements keep the two arms apart: without them LLVM merges the otherwise identical loads / stores of both
+// arms into one copy and drops the non-temporal hint, which is metadata -- measured: no effect at all until they were added)
+#define KB_WITH_STATE_POLICY(a, fn)                                    \
+    do {                                                               \
+        if ((a).stream_state) {                                        \
+            asm volatile("; state block: streaming policy" ::: "memory"); \
+            fn(std::true_type{});                                      \
+            asm volatile("; end of streaming arm" ::: "memory");      \
+        } else {                                                       \
+            fn(std::false_type{});                                     \
+        }                                                              \
+    } while (0)
 
 // pin(v): an empty asm that "modifies" v.  The value must exist in a VGPR at this point of the program, so LLVM can neither
 // sink the computation that produces it into a later basic block (machine sinking does that across the data-dependent

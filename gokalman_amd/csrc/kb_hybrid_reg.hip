@@ -46,10 +46,14 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
             yv[r] = real[r] - cv;
         }
     }
+    auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
+        constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = ldt(st, i);
+        for (int i = 0; i < NS; i++) x[i] = ldp<nt>(st, i);
 #pragma unroll
-    for (int e = 0; e < TR; e++) P[e] = ldt(st, NS + e);
+        for (int e = 0; e < TR; e++) P[e] = ldp<nt>(st, NS + e);
+    };
+    KB_WITH_STATE_POLICY(a, load_state);
     __builtin_amdgcn_sched_barrier(0);
     // :114-116 PBar = Phi P Phi^T (upper triangle)
     T Pm[TR];
@@ -240,10 +244,14 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
     }
     if (chk != chk) err |= KB_ST_NONFINITE;
     if (active && !err) {
+        auto store_state = [&](auto NT) {
+            constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-        for (int i = 0; i < NS; i++) stt(st, i, xn[i]);
+            for (int i = 0; i < NS; i++) stp<nt>(st, i, xn[i]);
 #pragma unroll
-        for (int e = 0; e < TR; e++) stt(st, NS + e, Pn[e]);
+            for (int e = 0; e < TR; e++) stp<nt>(st, NS + e, Pn[e]);
+        };
+        KB_WITH_STATE_POLICY(a, store_state);
         if constexpr (FULL) {
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll

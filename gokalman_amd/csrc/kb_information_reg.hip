@@ -2,8 +2,8 @@
 // for the benchmark shape (n = 6, p = 3, fp64) and the padded family up to 6 / 4 / 2.  FULL (KB_FLAG_FULL_ESTIMATE) also
 // writes I- and yhat = H State(prev) [+ Measurement(k) for an AWGN batch, information.go:192-194], which costs one more
 // n x n inverse per step (State() inverts I on every call, information.go:257-293); the stale-1x1-Rinv quirk is a template flag.
-// Per filter-step it reads i[n], I (packed), F^-1 [n^2], Q^-1 [n^2], H [p n], R^-1 [p^2], y[p] and
-// writes i, I.  The (M + Q^-1)^-1 inverse is the LU-pivoted register inverse (kb_device.h).
+// Per filter-step it reads i[n], I (packed), F^-1 [n^2], Q^-1 and R^-1 (packed: the upper triangle of the computed
+// inverse, mirrored), H [p n], y[p] and writes i, I.  The (M + Q^-1)^-1 inverse is the LU-pivoted register inverse (kb_device.h).
 #include "kb_internal.h"
 #include "kb_static.h"
 #include "kb_vanilla_reg.h"   // draw_normals / chol_times / TilePtr (the AWGN draw of the register kernels)
@@ -44,12 +44,16 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_Finv + i * rn + j) : T(0);
+    auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
+        constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-    for (int i = 0; i < NS; i++) iv[i] = (i < rn) ? ldt(st, i) : T(0);
+        for (int i = 0; i < NS; i++) iv[i] = (i < rn) ? ldp<nt>(st, i) : T(0);
 #pragma unroll
-    for (int j = 0; j < NS; j++)
+        for (int j = 0; j < NS; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) I[symi(i, j)] = (j < rn) ? ldt(st, rn + symi(i, j)) : T(0);
+            for (int i = 0; i <= j; i++) I[symi(i, j)] = (j < rn) ? ldp<nt>(st, rn + symi(i, j)) : T(0);
+    };
+    KB_WITH_STATE_POLICY(a, load_state);
     __builtin_amdgcn_sched_barrier(0);
     // :163-165 zk = Finv^T (I Finv), one column at a time: column j of I Finv lives only until column j of zk is formed
     // (the whole intermediate product would put 3 n^2 + n(n+1)/2 doubles in registers at once)
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            zqT[j * NS + i] = zk[i * NS + j] + ((i < rn && j < rn) ? ldnt(mo, a.L.mo_Qinv + i * rn + j) : (i == j ? T(1) : T(0)));
+            zqT[j * NS + i] = zk[i * NS + j] + ((i < rn && j < rn) ? ldnt(mo, a.L.mo_Qinv + symi(i, j)) : (i == j ? T(1) : T(0)));
             X[j * NS + i] = zk[i * NS + j];
         }
 #pragma unroll
@@ -198,7 +202,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
 #pragma unroll
         for (int l = 0; l < NM; l++)
 #pragma unroll
-            for (int j = 0; j < NM; j++) Ri[l * NM + j] = (l < rp && j < rp) ? ldnt(mo, a.L.mo_Rinv + l * rp + j) : T(0);
+            for (int j = 0; j < NM; j++) Ri[l * NM + j] = (l < rp && j < rp) ? ldnt(mo, a.L.mo_Rinv + symi(l, j)) : T(0);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -255,14 +259,18 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         __builtin_amdgcn_sched_barrier(0);
     }
     if (active && ok) {
+        auto store_state = [&](auto NT) {
+            constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-        for (int i = 0; i < NS; i++)
-            if (i < rn) stt(st, i, ip[i]);
+            for (int i = 0; i < NS; i++)
+                if (i < rn) stp<nt>(st, i, ip[i]);
 #pragma unroll
-        for (int j = 0; j < NS; j++)
+            for (int j = 0; j < NS; j++)
 #pragma unroll
-            for (int i = 0; i <= j; i++)
-                if (j < rn) stt(st, rn + symi(i, j), Ip[symi(i, j)]);
+                for (int i = 0; i <= j; i++)
+                    if (j < rn) stp<nt>(st, rn + symi(i, j), Ip[symi(i, j)]);
+        };
+        KB_WITH_STATE_POLICY(a, store_state);
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
     if constexpr (FULL) {

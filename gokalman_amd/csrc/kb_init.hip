@@ -16,8 +16,8 @@ enum DeriveOp {
     OP_CHOL_Q = 2,     // model Q -> mo_LQ
     OP_CHOL_R = 3,     // model R (dim rp) -> mo_LR
     OP_INV_F = 4,      // model F -> mo_Finv
-    OP_INV_Q = 5,      // model Q -> mo_Qinv (full)
-    OP_INV_R = 6,      // model R (dim rp) -> mo_Rinv (full, leading dim rp)
+    OP_INV_Q = 5,      // model Q -> mo_Qinv (packed: the upper triangle of the computed inverse)
+    OP_INV_R = 6,      // model R (dim rp) -> mo_Rinv (packed)
     OP_INFO_FROM_STATE = 7,
     OP_SRIF_INIT = 8
 };
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64) derive_kernel(void *state_, void *model_, 
             for (int j = 0; j < n; j++) A[i * LD + j] = ldt(mo, L.mo_Q + symi(i, j));
         inverse_lu_rt<T, LD>(n, A, B);
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) stt(mo, L.mo_Qinv + i * n + j, B[i * LD + j]);
+            for (int j = i; j < n; j++) stt(mo, L.mo_Qinv + symi(i, j), B[i * LD + j]);
         break;
     }
     case OP_INV_R: {
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64) derive_kernel(void *state_, void *model_, 
             for (int j = 0; j < rp; j++) A[i * LD + j] = ldt(mo, L.mo_R + symi(i, j));
         inverse_lu_rt<T, LD>(rp, A, B);
         for (int i = 0; i < rp; i++)
-            for (int j = 0; j < rp; j++) stt(mo, L.mo_Rinv + i * rp + j, B[i * LD + j]);
+            for (int j = i; j < rp; j++) stt(mo, L.mo_Rinv + symi(i, j), B[i * LD + j]);
         break;
     }
     case OP_INFO_FROM_STATE: {  // information.go:65-81

@@ -27,7 +27,7 @@ struct Layout {
     int mo_F = 0, mo_H = 0, mo_Q = 0, mo_R = 0, mo_G = 0;
     // derived (constructor / SetNoise / SetStateTransition products)
     int mo_LQ = 0, mo_LR = 0;                   // chol_L(Q) packed [tri(n)], chol_L(R) packed [tri(pmax)]  (AWGN, SQUAREROOT, SRIF)
-    int mo_Finv = 0, mo_Qinv = 0, mo_Rinv = 0;  // INFORMATION: full n*n, n*n, pmax*pmax
+    int mo_Finv = 0, mo_Qinv = 0, mo_Rinv = 0;  // INFORMATION: F^-1 full n*n; Q^-1, R^-1 packed symmetric [tri(n)], [tri(pmax)]
     int nq = 0;                                  // HYBRID: dimension of the SNC noise (Q is q x q, Gamma n x q)
     int mo_elems = 0;
 };
@@ -108,6 +108,7 @@ struct StepArgs {
     const void *ext_phi, *ext_h; int64_t ext_ld;   // NLDKF zero-copy model (planar, element e of filter i at ptr[e*ld + i])
     int64_t N, ntiles;
     int nsteps;
+    int stream_state;                            // the state block cannot stay in the Infinity Cache: read / write it non-temporally (kb_vanilla_reg.h)
     int n, p, m, pmax;
     Layout L;
     unsigned flags;
@@ -203,6 +204,7 @@ struct HeavyScope {
     hipEvent_t ev_[2] = {nullptr, nullptr};
     bool heavy_ = false, owned_ = false;
 };
+constexpr size_t KB_MALL_BYTES = (size_t)256 << 20;   // Infinity Cache (MALL) of one MI355X
 constexpr int KB_HEAVY_LD = 16;   // leading dimension from which a generic kernel counts as scratch-heavy
 
 inline dim3 tile_grid(int64_t ntiles) { return dim3((unsigned)((ntiles + 3) / 4)); }

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
         mm_tn<T, LD, LD, LD>(n, n, n, Fi, t1, zk);
         // :169-174 Z = -zk (zk + Qinv)^-1
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) zq[i * LD + j] = zk[i * LD + j] + ldt(mo, a.L.mo_Qinv + i * n + j);
+            for (int j = 0; j < n; j++) zq[i * LD + j] = zk[i * LD + j] + ldt(mo, a.L.mo_Qinv + symi(i, j));
         inverse_lu_rt<T, LD>(n, zq, zqi);
         mm_nn<T, LD, LD, LD>(n, n, n, zk, zqi, Z);
         for (int i = 0; i < n; i++)
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(64) information_gen_kernel(const StepArgs a) {
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < p; j++) {
                     T s = T(0);
-                    for (int l = 0; l < p; l++) s += H[l * LD + i] * ldt(mo, a.L.mo_Rinv + l * rp + j);
+                    for (int l = 0; l < p; l++) s += H[l * LD + i] * ldt(mo, a.L.mo_Rinv + symi(l, j));
                     HTR[i * LD + j] = s;
                 }
         }

@@ -55,12 +55,16 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_F + i * rn + j) : T(0);
+    auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
+        constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldt(st, i) : T(0);
+        for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldp<nt>(st, i) : T(0);
 #pragma unroll
-    for (int i = 0; i < NS; i++)
+        for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int k2 = 0; k2 <= i; k2++) S[symi(k2, i)] = (i < rn) ? ldt(st, rn + symi(k2, i)) : T(0);  // S[i][k], k <= i, at symi(k, i)
+            for (int k2 = 0; k2 <= i; k2++) S[symi(k2, i)] = (i < rn) ? ldp<nt>(st, rn + symi(k2, i)) : T(0);  // S[i][k], k <= i, at symi(k, i)
+    };
+    KB_WITH_STATE_POLICY(a, load_state);
     __builtin_amdgcn_sched_barrier(0);
 
     // :139-147 x- = F x [+ G u]
@@ -253,14 +257,18 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
         for (int j = 0; j <= i; j++) chk += D[(NM + j) * DD + (NM + i)] * T(0);
     const bool ok = !(chk != chk);
     if (active && ok) {
+        auto store_state = [&](auto NT) {
+            constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-        for (int i = 0; i < NS; i++)
-            if (i < rn) stt(st, i, xn[i]);
+            for (int i = 0; i < NS; i++)
+                if (i < rn) stp<nt>(st, i, xn[i]);
 #pragma unroll
-        for (int i = 0; i < NS; i++)
+            for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int j = 0; j <= i; j++)
-                if (i < rn) stt(st, rn + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
+                for (int j = 0; j <= i; j++)
+                    if (i < rn) stp<nt>(st, rn + symi(j, i), D[(NM + j) * DD + (NM + i)]);  // S+[i][j] = UD[p+j][p+i]
+        };
+        KB_WITH_STATE_POLICY(a, store_state);
         if constexpr (FULL) {
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
 #pragma unroll

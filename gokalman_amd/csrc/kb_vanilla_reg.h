@@ -3,15 +3,14 @@
 // (kb_vanilla.hip: the benchmark shapes in fp64 and fp32 incl. the time-fused variant;
 //  kb_vanilla_shapes.hip: the shapes of the reference's own examples and tests, fp64).
 #pragma once
+#include <type_traits>
+
 #include "kb_internal.h"
 
 namespace kb {
 
 // waves (= tiles) per workgroup of the register kernel: 2 measured 1-1.5 % faster than 4 or 1 and 10 % faster than 8
 // at 1M filters (smaller groups retire and refill more evenly)
-#ifndef KB_VANILLA_ORDER
-#define KB_VANILLA_ORDER 2   // request order: 0 = x, P, F | Q, H, R, y;  1 = F, x, P | Q, H, R, y;  2 = F | Q, H, R, y, then x, P
-#endif
 #ifndef KB_VANILLA_WPB
 #define KB_VANILLA_WPB 2
 #endif
@@ -142,26 +141,10 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 
     // ---- state + transition model
     T x[NS], P[TR], F[NS * NS];
-#if KB_VANILLA_ORDER >= 1
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(moF, i * rn + j) : T(0);
-#endif
-#if KB_VANILLA_ORDER != 2
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldt(st, i) : T(0);
-#pragma unroll
-    for (int j = 0; j < NS; j++)
-#pragma unroll
-        for (int i = 0; i <= j; i++) P[symi(i, j)] = (j < rn) ? ldt(st, rn + symi(i, j)) : T(0);   // packed index does not depend on n
-#endif
-#if KB_VANILLA_ORDER == 0
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(moF, i * rn + j) : T(0);
-#endif
     // Issue order is pinned with scheduling barriers, and it is "slowest first": the model and the measurement are HBM
     // streams (non-temporal), x and P are Infinity-Cache hits.  With F, Q, H, R, y requested before x and P every HBM request
     // of the wave is in flight as early as possible and the cache hits arrive right behind them: 163.5 us per 1M-filter step
@@ -190,14 +173,21 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
         for (int r = 0; r < NM; r++) y0[r] = (active && r < rp) ? ldnt_at(yp + (int64_t)r * a.y_es) : T(0);
     }
-#if KB_VANILLA_ORDER == 2
+    // Cache policy of the state block (wave-uniform, chosen per batch at launch: StepArgs::stream_state).  A state block that fits the
+    // 256 MiB Infinity Cache is read and written with the default policy and stays resident from step to step (with the model
+    // streamed non-temporally around it); one that cannot fit anyway -- 4M filters: 906 MB -- is streamed non-temporally as well:
+    // 740 us against 848 us per 4M-filter step, i.e. 6.26 TB/s = 0.995 of what a copy kernel achieves, where the resident policy
+    // on a non-resident block thrashes (and the streaming policy at 1M filters costs 12 %: 189 against 168 us).
+    auto load_state = [&](auto NT) {
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = (i < rn) ? ldt(st, i) : T(0);
+        for (int i = 0; i < NS; i++) x[i] = (i < rn) ? (decltype(NT)::value ? st.ldnt(i) : st.ld(i)) : T(0);
 #pragma unroll
-    for (int j = 0; j < NS; j++)
+        for (int j = 0; j < NS; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) P[symi(i, j)] = (j < rn) ? ldt(st, rn + symi(i, j)) : T(0);   // packed index does not depend on n
-#endif
+            for (int i = 0; i <= j; i++)   // packed index does not depend on n
+                P[symi(i, j)] = (j < rn) ? (decltype(NT)::value ? st.ldnt(rn + symi(i, j)) : st.ld(rn + symi(i, j))) : T(0);
+    };
+    KB_WITH_STATE_POLICY(a, load_state);
     __builtin_amdgcn_sched_barrier(0);
 
     unsigned err_acc = 0, nfail = 0;
@@ -481,14 +471,17 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
             for (int e = 0; e < TR; e++) P[e] = ok ? Pn[e] : P[e];
         } else {
             if (active && ok) {
+                auto store_state = [&](auto NT) {
 #pragma unroll
-                for (int i = 0; i < NS; i++)
-                    if (i < rn) stt(st, i, xn[i]);
+                    for (int i = 0; i < NS; i++)
+                        if (i < rn) { if constexpr (decltype(NT)::value) st.stnt(i, xn[i]); else st.st(i, xn[i]); }
 #pragma unroll
-                for (int j = 0; j < NS; j++)
+                    for (int j = 0; j < NS; j++)
 #pragma unroll
-                    for (int i = 0; i <= j; i++)
-                        if (j < rn) stt(st, rn + symi(i, j), Pn[symi(i, j)]);
+                        for (int i = 0; i <= j; i++)
+                            if (j < rn) { if constexpr (decltype(NT)::value) st.stnt(rn + symi(i, j), Pn[symi(i, j)]); else st.st(rn + symi(i, j), Pn[symi(i, j)]); }
+                };
+                KB_WITH_STATE_POLICY(a, store_state);
             }
         }
     }

@@ -52,8 +52,8 @@ def moved_bytes(kind, n, p, w=8):
         return w * (n + t + n * n + p * n + t + tp + p + n + t) + 4
     if kind == "squareroot":    # x, S, F, H, chol Q, chol R, y -> x, S
         return w * (n + t + n * n + p * n + t + tp + p + n + t)
-    if kind == "information":   # i, I, F^-1, Q^-1 (full), H, R^-1 (full), y -> i, I
-        return w * (n + t + n * n + n * n + p * n + p * p + p + n + t)
+    if kind == "information":   # i, I, F^-1, Q^-1 (packed), H, R^-1 (packed), y -> i, I
+        return w * (n + t + n * n + t + p * n + tp + p + n + t)
     if kind == "hybrid":        # x, P, Phi, Htilde, R, real, computed -> x, P
         return w * (n + t + n * n + p * n + tp + 2 * p + n + t)
     if kind == "srif":          # b, R upper, Phi, Htilde, chol R, real, computed -> b, R upper (fused Update)
