@@ -71,6 +71,16 @@ def test_two_ranks_self_launched_over_gloo_on_one_gpu():
     assert two["extra"]["squareroot"]["filters_total"] == 2 * 16384 and two["extra"]["squareroot"]["filters_with_error_status"] == 0
     assert two["extra"]["srif_fp32"]["filters_total"] == 2 * 8192 and two["extra"]["srif_fp32"]["filters_with_error_status"] == 0
     assert two["roofline"]["frac"] <= 1.0 and one["roofline"]["frac"] <= 1.0
+    # strong scaling (GPU g owns [g N / G, (g + 1) N / G)): the same 65536 filters split over the two ranks
+    assert two["strong_scaling"]["filters_per_gpu"] == [32768, 32768] and two["strong_scaling"]["filters_total"] == 65536
+    assert len(two["strong_scaling"]["per_rank_ms_per_step"]) == 2 and two["strong_scaling"]["value"] > 0
+    assert one["strong_scaling"]["filters_per_gpu"] == [65536]
+    # the chi-square sums are all-reduced like the Monte-Carlo means
+    assert two["extra"]["chisq"]["runs_total"] == 2 * one["extra"]["chisq"]["runs_total"] and 0.5 < two["extra"]["chisq"]["nis_mean"] < 5.0
+    # parity against the oracle travels in the line (rank 0), and so does the repetition of the timed block
+    assert one["parity"]["ok"] and two["parity"]["ok"] and one["parity"]["filters"] == 4096
+    assert one["repetitions"]["blocks"] == 5 and len(one["repetitions"]["ms_per_step_blocks"]) == 5
+    assert one["host_path"]["value"] < one["value"]
 
 
 @pytest.mark.gpu
@@ -85,6 +95,7 @@ def test_bench_line_roofline_is_physical():
     assert roof["bytes_convention"]["algorithmic_bytes_per_filter_step"] == 1488
     assert roof["bytes_convention"]["moved_bytes_per_filter_step"] == 1104
     assert "traffic_source" in roof
+    assert 0.0 < roof["dram_frac_lower_bound"] < roof["frac"] and "Infinity-Cache" in roof["side"]
 
 
 @pytest.mark.gpu
