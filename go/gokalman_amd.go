@@ -819,6 +819,128 @@ func (kf *BatchLDKF) FilterStep(filter int64) (int64, error) {
 	return int64(st), err
 }
 
+// ShardedBatch is N LDKF filters split into contiguous shards over the GPUs of the node from this ONE process (kb_sharded_*,
+// SURVEY section 8e): GPU g owns the filters [g N / G, (g + 1) N / G), one handle + host thread + stream per device.  Update has
+// no collective; MonteCarlo / ChiSquare combine the per-shard sums with ONE ncclAllReduce over RCCL (host sum when shards share a
+// device).  devices = nil uses every visible GPU.
+type ShardedBatch struct {
+	s       *C.kb_sharded
+	n, p, m int
+	N       int64
+}
+
+func NewShardedBatch(kind C.int, N int64, devices []int, x0 *mat64.Vector, P0 mat64.Symmetric, F, G, H mat64.Matrix, noise gokalman.Noise) (*ShardedBatch, error) {
+	n, _ := x0.Dims()
+	p, _ := H.Dims()
+	_, m := G.Dims()
+	sb := &ShardedBatch{n: n, p: p, m: m, N: N}
+	if len(devices) == 0 {
+		for g := 0; g < int(C.kb_device_count()); g++ {
+			devices = append(devices, g)
+		}
+	}
+	devs := make([]C.int, len(devices))
+	for i, d := range devices {
+		devs[i] = C.int(d)
+	}
+	if err := kbCall(func() C.int {
+		return C.kb_sharded_create(&sb.s, kind, C.int(n), C.int(p), C.int(m), C.int64_t(N), C.KB_F64, &devs[0], C.int(len(devs)), 0)
+	}); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(sb, func(b *ShardedBatch) { C.kb_sharded_destroy(b.s) })
+	for _, f := range []struct {
+		f C.int
+		m mat64.Matrix
+		p int
+	}{{C.KB_X, x0, 0}, {C.KB_P, P0, 0}, {C.KB_F, F, 0}, {C.KB_G, G, 0}, {C.KB_H, H, p},
+		{C.KB_Q, noise.ProcessMatrix(), 0}, {C.KB_R, noise.MeasurementMatrix(), p}} {
+		v := rowMajor(f.m)
+		if len(v) == 0 {
+			continue
+		}
+		if err := kbCall(func() C.int { return C.kb_sharded_set(sb.s, f.f, ptr(v), 1, 1, C.int(f.p), C.int64_t(len(v))) }); err != nil {
+			return nil, err
+		}
+	}
+	if _, isAWGN := noise.(*gokalman.AWGN); isAWGN {
+		if err := kbCall(func() C.int { return C.kb_sharded_set_noise_kind(sb.s, C.KB_NOISE_AWGN, C.uint64_t(time.Now().UnixNano())) }); err != nil {
+			return nil, err
+		}
+	}
+	if err := kbCall(func() C.int { return C.kb_sharded_init(sb.s) }); err != nil {
+		return nil, err
+	}
+	return sb, nil
+}
+
+// SetPerFilter uploads one matrix per filter (values: N matrices of elems doubles back to back); it is cut at the shard boundaries.
+func (sb *ShardedBatch) SetPerFilter(field C.int, values []float64, pRows, elems int) error {
+	return kbCall(func() C.int { return C.kb_sharded_set(sb.s, field, ptr(values), C.int64_t(sb.N), 0, C.int(pRows), C.int64_t(elems)) })
+}
+
+// Update runs LDKF.Update on every filter, the shards in parallel: measurements [N][p], controls [N][m] or nil.
+func (sb *ShardedBatch) Update(measurements, controls []float64) error {
+	var up *C.double
+	m := 0
+	if len(controls) > 0 {
+		up, m = ptr(controls), len(controls)/int(sb.N)
+	}
+	return kbCall(func() C.int {
+		return C.kb_sharded_update(sb.s, ptr(measurements), C.int(len(measurements)/int(sb.N)), up, C.int(m))
+	})
+}
+
+// States / Covariances of the filters [first, first+count): [count][n] and [count][n][n].
+func (sb *ShardedBatch) States(first, count int64) ([]float64, error) {
+	out := make([]float64, int(count)*sb.n)
+	err := kbCall(func() C.int { return C.kb_sharded_get(sb.s, C.KB_STATE, ptr(out), C.int64_t(first), C.int64_t(count), C.int64_t(sb.n)) })
+	return out, err
+}
+func (sb *ShardedBatch) Covariances(first, count int64) ([]float64, error) {
+	out := make([]float64, int(count)*sb.n*sb.n)
+	err := kbCall(func() C.int {
+		return C.kb_sharded_get(sb.s, C.KB_COVAR, ptr(out), C.int64_t(first), C.int64_t(count), C.int64_t(sb.n*sb.n))
+	})
+	return out, err
+}
+
+// MonteCarlo is NewMonteCarloRuns over the whole node (montecarlo.go:92-119): per-step mean and unbiased standard deviation over
+// all N runs (mean[steps][n], stddev[steps][n]); usedRCCL tells how the shards' sums were combined.
+func (sb *ShardedBatch) MonteCarlo(steps int, controls []*mat64.Vector) (mean, stddev []float64, usedRCCL bool, err error) {
+	ctrl := flattenControls(controls)
+	sums := make([]float64, steps*3*sb.n)
+	if err = kbCall(func() C.int { return C.kb_sharded_mc_run(sb.s, C.int(steps), ptr(ctrl), C.int(len(controls)), ptr(sums), 0) }); err != nil {
+		return
+	}
+	mean, stddev = make([]float64, steps*sb.n), make([]float64, steps*sb.n)
+	err = kbCall(func() C.int { return C.kb_mc_stats(ptr(sums), C.int(steps), C.int(sb.n), C.int64_t(sb.N), ptr(mean), ptr(stddev)) })
+	usedRCCL = C.kb_sharded_used_rccl(sb.s) != 0
+	return
+}
+
+// ChiSquare is NewChiSquare over the whole node (chisquare.go:16-95); sb is the truth (pure predictor, AWGN), kf the filter under test.
+func (sb *ShardedBatch) ChiSquare(kf *ShardedBatch, steps int, controls []*mat64.Vector, replayLastMC, withNEES, withNIS bool) ([]float64, []float64, error) {
+	ctrl := flattenControls(controls)
+	sums := make([]float64, steps*2)
+	b2i := func(v bool) C.int {
+		if v {
+			return 1
+		}
+		return 0
+	}
+	if err := kbCall(func() C.int {
+		return C.kb_sharded_chisquare(sb.s, kf.s, C.int(steps), ptr(ctrl), C.int(len(controls)), b2i(replayLastMC), b2i(withNEES), b2i(withNIS), ptr(sums))
+	}); err != nil {
+		return nil, nil, err
+	}
+	nis, nees := make([]float64, steps), make([]float64, steps)
+	for k := 0; k < steps; k++ {
+		nis[k], nees[k] = sums[2*k]/float64(sb.N), sums[2*k+1]/float64(sb.N)
+	}
+	return nis, nees, nil
+}
+
 // VanLoan computes F and Q from the continuous-time system A, Γ, W and the sampling period Δt
 // (gokalman.VanLoan, c2d.go:13-75) on the GPU.
 func VanLoan(A, Γ, W *mat64.Dense, Δt float64) (*mat64.Dense, *mat64.SymDense, error) {

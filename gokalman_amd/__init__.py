@@ -5,5 +5,6 @@ the host-side binding used by the tests and the benchmark: `batch.FilterBatch` m
 reference's LDKF / NLDKF / Estimate surface over N filters at once.
 """
 from . import _capi as capi  # noqa: F401
-from .batch import FilterBatch, Estimate, StaleEstimateError, MonteCarloRuns, new_monte_carlo_runs, new_chi_square, van_loan  # noqa: F401
+from .batch import (FilterBatch, Estimate, StaleEstimateError, MonteCarloRuns, MonteCarloRun, MonteCarloEstimate, ShardedBatch,  # noqa: F401
+                    new_monte_carlo_runs, new_chi_square, van_loan)
 from ._capi import KalmanError  # noqa: F401

@@ -69,6 +69,23 @@ SIGNATURES = {
     "kb_mc_get_runs": (_i, [_vp, _i64, _i64, _dp, _dp]),
     "kb_chisquare": (_i, [_vp, _vp, _i, _dp, _i, _i64, _i, _i, _i, _dp]),
     "kb_mc_stats": (_i, [_dp, _i, _i, _i64, _dp, _dp]),
+    "kb_sharded_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i64, _i, C.POINTER(_i), _i, C.c_uint]),
+    "kb_sharded_destroy": (None, [_vp]),
+    "kb_sharded_num_shards": (_i, [_vp]),
+    "kb_sharded_shard": (_vp, [_vp, _i]),
+    "kb_sharded_first": (_i64, [_vp, _i]),
+    "kb_sharded_set": (_i, [_vp, _i, _dp, _i64, _i, _i, _i64]),
+    "kb_sharded_set_noise_kind": (_i, [_vp, _i, _u64]),
+    "kb_sharded_init": (_i, [_vp]),
+    "kb_sharded_reset": (_i, [_vp]),
+    "kb_sharded_synchronize": (_i, [_vp]),
+    "kb_sharded_update": (_i, [_vp, _dp, _i, _dp, _i]),
+    "kb_sharded_update_dev": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),
+    "kb_sharded_get": (_i, [_vp, _i, _dp, _i64, _i64, _i64]),
+    "kb_sharded_get_status": (_i, [_vp, C.POINTER(C.c_uint32), _i64, _i64]),
+    "kb_sharded_mc_run": (_i, [_vp, _i, _dp, _i, _dp, C.c_uint]),
+    "kb_sharded_chisquare": (_i, [_vp, _vp, _i, _dp, _i, _i, _i, _i, _dp]),
+    "kb_sharded_used_rccl": (_i, [_vp]),
     "kb_van_loan": (_i, [_i, _i, _i, _i, _i64, _dp, _dp, _dp, _dp, _i, _dp, _dp, C.POINTER(C.c_uint32)]),
     "kb_van_loan_dev": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
 }

@@ -721,3 +721,87 @@ def van_loan(A, Gamma, W, dt, dtype=k.F64, device=0):
     if not any(batched):
         return F[0], Q[0], int(st[0])
     return F, Q, st
+
+
+class ShardedBatch:
+    """kb_sharded_* (include/gokalman_amd.h): N filters in contiguous shards over several devices from ONE process -- one handle,
+    host thread and stream per device, no collective in Update, the Monte-Carlo / chi-square statistics one ncclAllReduce (host
+    sum when shards share a device).  The native counterpart of one-process-per-GPU over torch.distributed (dist.py)."""
+
+    def __init__(self, kind, x0, P0, F, G, H, Q, R, nfilters, devices=None, flags=0, noise=k.NOISE_NOISELESS, seed=0):
+        x0, P0, F, H, Q, R = [_f64(v) for v in (x0, P0, F, H, Q, R)]
+        self.n, self.p = x0.shape[-1], H.shape[-2]
+        Gm = None if G is None else _f64(G).reshape(_f64(G).shape[:-2] + (self.n, -1))
+        self.m = 0 if Gm is None else Gm.shape[-1]
+        self.N, self.kind = int(nfilters), kind
+        if devices is None:
+            devices = list(range(k.lib().kb_device_count()))
+        devs = (C.c_int * len(devices))(*devices)
+        self._s = C.c_void_p()
+        k.check(k.lib().kb_sharded_create(C.byref(self._s), kind, self.n, self.p, self.m, self.N, k.F64, devs, len(devices), flags))
+        for field, arr, item_ndim, p_rows in ((k.X, x0, 1, 0), (k.P, P0, 2, 0), (k.F, F, 2, 0), (k.G, Gm, 2, 0), (k.H, H, 2, self.p),
+                                              (k.Q, Q, 2, 0), (k.R, R, 2, self.p)):
+            if arr is None:
+                continue
+            shared = arr.ndim == item_ndim
+            per = int(np.prod(arr.shape[-item_ndim:]))
+            k.check(k.lib().kb_sharded_set(self._s, field, _ptr(arr), 1 if shared else self.N, 1 if shared else 0, p_rows, per))
+        if noise != k.NOISE_NOISELESS:
+            k.check(k.lib().kb_sharded_set_noise_kind(self._s, noise, seed))
+        k.check(k.lib().kb_sharded_init(self._s))
+
+    def close(self):
+        s = getattr(self, "_s", None)
+        if s is not None and s.value:
+            k.lib().kb_sharded_destroy(s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shards(self):
+        return int(k.lib().kb_sharded_num_shards(self._s))
+
+    def first(self, g):
+        return int(k.lib().kb_sharded_first(self._s, g))
+
+    def update(self, measurement, control=None):
+        y = _f64(measurement)
+        if y.ndim == 1:
+            y = _f64(np.broadcast_to(y, (self.N, y.shape[0])))
+        u = None
+        if control is not None:
+            u = _f64(control)
+            if u.ndim == 1:
+                u = _f64(np.broadcast_to(u, (self.N, u.shape[0])))
+        k.check(k.lib().kb_sharded_update(self._s, _ptr(y), y.shape[1], None if u is None else _ptr(u), 0 if u is None else u.shape[1]))
+
+    def get(self, field, shape):
+        out = np.zeros((self.N,) + tuple(shape))
+        k.check(k.lib().kb_sharded_get(self._s, field, _ptr(out), 0, self.N, int(np.prod(shape))))
+        return out
+
+    def status(self):
+        out = np.zeros(self.N, dtype=np.uint32)
+        k.check(k.lib().kb_sharded_get_status(self._s, out.ctypes.data_as(C.POINTER(C.c_uint32)), 0, self.N))
+        return out
+
+    def monte_carlo(self, steps, controls):
+        """NewMonteCarloRuns over every shard: MonteCarloRuns (mean / stddev per step over ALL N runs)."""
+        controls = _controls_arg(controls, steps, self.m)
+        sums = np.zeros((steps, 3, self.n))
+        k.check(k.lib().kb_sharded_mc_run(self._s, steps, _ptr(controls), controls.shape[0], _ptr(sums), 0))
+        return MonteCarloRuns(self.N, steps, self.n, sums)
+
+    def chi_square(self, kf, steps, controls, replay_last_mc=True, with_nees=True, with_nis=True):
+        controls = _controls_arg(controls, steps, self.m)
+        sums = np.zeros((steps, 2))
+        k.check(k.lib().kb_sharded_chisquare(self._s, kf._s, steps, _ptr(controls), controls.shape[0], int(replay_last_mc),
+                                             int(with_nees), int(with_nis), _ptr(sums)))
+        return sums[:, 0] / self.N, sums[:, 1] / self.N
+
+    def used_rccl(self):
+        return bool(k.lib().kb_sharded_used_rccl(self._s))

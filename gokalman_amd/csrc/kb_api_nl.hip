@@ -252,6 +252,27 @@ int kb_mc_run(kb_batch *b, int steps, const double *controls, int ncontrols, int
 
 int kb_mc_run_ex(kb_batch *b, int steps, const double *controls, int ncontrols, int64_t first_run, double *sums, unsigned mc_flags) {
     if (!b || !sums) { set_error("null argument"); return KB_ERR_INVALID; }
+    double *d_folded = nullptr, *d_shift = nullptr;
+    int rc = mc_run_device(*b, steps, controls, ncontrols, first_run, mc_flags, &d_folded, &d_shift);
+    if (rc) return rc;
+    const int n = b->n;
+    std::vector<double> host((size_t)steps * 3 * n);   // shift [steps][n] | folded [steps][2][n]: adjacent in Batch::d_mc
+    KB_HIP(hipMemcpyAsync(host.data(), d_shift, host.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    KB_HIP(hipStreamSynchronize(b->stream));
+    const double *shift = host.data(), *folded = host.data() + (size_t)steps * n;
+    for (int t = 0; t < steps; t++)
+        for (int i = 0; i < n; i++) {   // sums[steps][3][n]: sum(d), sum(d^2), shift c
+            sums[((size_t)t * 3 + 0) * n + i] = folded[((size_t)t * 2 + 0) * n + i];
+            sums[((size_t)t * 3 + 1) * n + i] = folded[((size_t)t * 2 + 1) * n + i];
+            sums[((size_t)t * 3 + 2) * n + i] = shift[(size_t)t * n + i];
+        }
+    return KB_OK;
+}
+
+}  // extern "C"
+
+int kb::mc_run_device(Batch &bb, int steps, const double *controls, int ncontrols, int64_t first_run, unsigned mc_flags, double **folded, double **shift) {
+    kb_batch *b = static_cast<kb_batch *>(&bb);
     if (mc_flags & ~(unsigned)KB_MC_KEEP_RUNS) { set_error("unknown Monte-Carlo flags 0x%x", mc_flags); return KB_ERR_INVALID; }
     if (!b->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
     if (b->kind != KB_VANILLA_PREDICT) {  // montecarlo.go:93-95 (a panic there)
@@ -289,7 +310,8 @@ int kb_mc_run_ex(kb_batch *b, int steps, const double *controls, int ncontrols, 
         }
     }
     const int repl = mc_repl();
-    const size_t ndbl = (size_t)repl * steps * 2 * n + (size_t)steps * n;
+    const size_t nrep = (size_t)repl * steps * 2 * n;   // [repl][steps][2][n] | shift [steps][n] | folded [steps][2][n]
+    const size_t ndbl = nrep + (size_t)steps * n + (size_t)steps * 2 * n;
     if (b->mc_bytes < ndbl * sizeof(double)) {
         if (b->d_mc) KB_HIP(hipFree(b->d_mc));
         b->d_mc = nullptr; b->mc_bytes = 0;
@@ -324,25 +346,14 @@ int kb_mc_run_ex(kb_batch *b, int steps, const double *controls, int ncontrols, 
     a.step0 = 0;
     if ((rc = launch_mc(*b, a, b->d_ctrl, ncontrols, b->d_mc, traj, traj_ld))) return rc;
     if (traj) { b->mc_steps = steps; b->mc_p = b->p; b->mc_ld = traj_ld; b->mc_first_run = first_run; b->mc_epoch = b->epoch; }
-    std::vector<double> host(ndbl);
-    KB_HIP(hipMemcpyAsync(host.data(), b->d_mc, ndbl * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    KB_HIP(hipStreamSynchronize(b->stream));
-    // sums[steps][3][n]: sum(d), sum(d^2), shift c
-    const double *shift = host.data() + (size_t)repl * steps * 2 * n;
-    for (int t = 0; t < steps; t++)
-        for (int i = 0; i < n; i++) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int r = 0; r < repl; r++) {
-                s1 += host[(((size_t)r * steps + t) * 2 + 0) * n + i];
-                s2 += host[(((size_t)r * steps + t) * 2 + 1) * n + i];
-            }
-            sums[((size_t)t * 3 + 0) * n + i] = s1;
-            sums[((size_t)t * 3 + 1) * n + i] = s2;
-            sums[((size_t)t * 3 + 2) * n + i] = shift[(size_t)t * n + i];
-        }
+    *shift = b->d_mc + nrep;
+    *folded = b->d_mc + nrep + (size_t)steps * n;
+    if ((rc = launch_fold(b->stream, b->d_mc, repl, (int64_t)steps * 2 * n, *folded))) return rc;
     b->epoch++;  // kf.Reset() after the sample (montecarlo.go:116): state untouched, noise re-seeded
     return KB_OK;
 }
+
+extern "C" {
 
 // MonteCarloRuns.Runs[first + k].Estimates[t].State() / .Measurement() of the last kb_mc_run_ex(..., KB_MC_KEEP_RUNS)
 int kb_mc_get_runs(kb_batch *b, int64_t first, int64_t count, double *states, double *measurements) {

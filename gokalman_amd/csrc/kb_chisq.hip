@@ -349,6 +349,17 @@ using namespace kb;
 extern "C" int kb_chisquare(kb_batch *truth, kb_batch *kf, int steps, const double *controls, int ncontrols, int64_t first_run,
                             int replay_last_mc, int with_nees, int with_nis, double *sums) {
     if (!truth || !kf || !sums) { set_error("null argument"); return KB_ERR_INVALID; }
+    double *d_folded = nullptr;
+    int rc = chisq_run_device(*truth, *kf, steps, controls, ncontrols, first_run, replay_last_mc, with_nees, with_nis, &d_folded);
+    if (rc) return rc;
+    KB_HIP(hipMemcpyAsync(sums, d_folded, (size_t)steps * 2 * sizeof(double), hipMemcpyDeviceToHost, truth->stream));   // [steps][2]: sum NIS, sum NEES
+    KB_HIP(hipStreamSynchronize(truth->stream));
+    return KB_OK;
+}
+
+int kb::chisq_run_device(Batch &tb, Batch &kb_, int steps, const double *controls, int ncontrols, int64_t first_run, int replay_last_mc,
+                         int with_nees, int with_nis, double **folded) {
+    Batch *truth = &tb, *kf = &kb_;
     if (!with_nees && !with_nis) { set_error("Chi Square requires either NEES or NIS or both"); return KB_ERR_INVALID; }  // chisquare.go:17-19
     if (!truth->initialized || !kf->initialized) { set_error("kb_init has not been called"); return KB_ERR_INVALID; }
     if (truth->kind != KB_VANILLA_PREDICT || truth->noise_kind != KB_NOISE_AWGN) {
@@ -381,7 +392,7 @@ extern "C" int kb_chisquare(kb_batch *truth, kb_batch *kf, int steps, const doub
         KB_HIP(hipMemcpy(truth->d_ctrl, controls, bytes, hipMemcpyHostToDevice));  // fp64 only (see launch_chisq)
     }
     const int repl = chi_repl();
-    const size_t ndbl = (size_t)repl * steps * 2;
+    const size_t nrep = (size_t)repl * steps * 2, ndbl = nrep + (size_t)steps * 2;   // [repl][steps][2] | folded [steps][2]
     if (truth->mc_bytes < ndbl * sizeof(double)) {
         if (truth->d_mc) KB_HIP(hipFree(truth->d_mc));
         truth->d_mc = nullptr; truth->mc_bytes = 0;
@@ -400,15 +411,8 @@ extern "C" int kb_chisquare(kb_batch *truth, kb_batch *kf, int steps, const doub
     a.nsteps = steps; a.ncontrols = ncontrols; a.need_ctrl = truth->need_ctrl; a.with_nees = with_nees; a.with_nis = with_nis;
     a.controls = truth->d_ctrl; a.sums = truth->d_mc;
     if ((rc = launch_chisq(*truth, a, truth->n, truth->p, truth->need_ctrl ? m : 0))) return rc;
-    std::vector<double> host(ndbl);
-    KB_HIP(hipMemcpyAsync(host.data(), truth->d_mc, ndbl * sizeof(double), hipMemcpyDeviceToHost, truth->stream));
-    KB_HIP(hipStreamSynchronize(truth->stream));
-    for (int t = 0; t < steps; t++) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < repl; r++) { s1 += host[((size_t)r * steps + t) * 2 + 0]; s2 += host[((size_t)r * steps + t) * 2 + 1]; }
-        sums[(size_t)t * 2 + 0] = s1;
-        sums[(size_t)t * 2 + 1] = s2;
-    }
+    *folded = truth->d_mc + nrep;
+    if ((rc = launch_fold(truth->stream, truth->d_mc, repl, (int64_t)steps * 2, *folded))) return rc;
     if (!replay_last_mc) truth->epoch++;
     return KB_OK;
 }

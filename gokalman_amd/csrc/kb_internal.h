@@ -173,6 +173,12 @@ bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair6
 // traj != nullptr: keep every run's State() and Measurement() per step (Batch::d_traj layout)
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, void *traj, int64_t traj_ld);
 int mc_repl();
+int launch_fold(hipStream_t stream, const double *src, int repl, int64_t per, double *out);
+// The device half of kb_mc_run_ex / kb_chisquare: everything up to the folded per-step sums in Batch::d_mc (asynchronous on the
+// handle's stream); *folded = [steps][2][n] (MC) or [steps][2] (chi-square) doubles on the device, *shift = [steps][n] (MC only).
+int mc_run_device(Batch &b, int steps, const double *controls, int ncontrols, int64_t first_run, unsigned mc_flags, double **folded, double **shift);
+int chisq_run_device(Batch &truth, Batch &kf, int steps, const double *controls, int ncontrols, int64_t first_run, int replay_last_mc,
+                     int with_nees, int with_nis, double **folded);
 // shared host helpers (kb_api.hip)
 int use_device(const Batch &b);
 void after_sync(Batch &b);   // call after every hipStreamSynchronize of the handle's stream in a host-facing entry point

@@ -182,4 +182,20 @@ int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int nco
 
 int mc_repl() { return MC_REPL; }
 
+// out[i] = sum over the replicas r of src[r * per + i] (replica order, so the result does not depend on who asks): the partial sums
+// of a launch folded on the device, where a multi-device driver can all-reduce them in place (kb_sharded.hip)
+__global__ void fold_replicas_kernel(const double *__restrict__ src, int repl, int64_t per, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per) return;
+    double s = 0.0;
+    for (int r = 0; r < repl; r++) s += src[(int64_t)r * per + i];
+    out[i] = s;
+}
+
+int launch_fold(hipStream_t stream, const double *src, int repl, int64_t per, double *out) {
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream, src, repl, per, out);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
 }  // namespace kb

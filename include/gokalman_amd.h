@@ -334,6 +334,43 @@ int kb_van_loan_dev(int dtype, int n, int q, int64_t N, const void *A, const voi
 int kb_chisquare(kb_batch *truth, kb_batch *kf, int steps, const double *controls, int ncontrols,
                  int64_t first_run, int replay_last_mc, int with_nees, int with_nis, double *sums);
 
+/* ---- one process, every GPU of the node ----------------------------------- */
+/* A batch of N filters split into contiguous shards over `ndev` devices -- shard g owns the filters [g N / G, (g + 1) N / G)
+ * -- with one kb_batch, one host thread and one HIP stream per shard.  Filters share nothing (vanilla.go:216-218), so the
+ * update path has no collective; the one exchange, the Monte-Carlo / chi-square statistics (montecarlo.go:18-59,
+ * chisquare.go:85-94), is ONE ncclAllReduce(sum) of steps x 2n (resp. steps x 2) doubles over RCCL / xGMI, from this single
+ * process (ncclCommInitAll; librccl is loaded on first use).  Shards that share a device, or a box without librccl, add the
+ * shards on the host instead (kb_sharded_used_rccl tells which).  devices = NULL means 0 .. ndev-1.  Every call below fans
+ * out to the shards' threads and returns when all are done; kb_sharded_shard(s, g) hands out a shard's own handle for
+ * everything not wrapped here (device-resident setters, getters, the NLDKF calls, ...). */
+typedef struct kb_sharded kb_sharded;
+int kb_sharded_create(kb_sharded **out, int kind, int n, int p, int m, int64_t nfilters, int dtype, const int *devices,
+                      int ndev, unsigned flags);
+void kb_sharded_destroy(kb_sharded *s);
+int kb_sharded_num_shards(const kb_sharded *s);
+kb_batch *kb_sharded_shard(kb_sharded *s, int g);
+int64_t kb_sharded_first(const kb_sharded *s, int g); /* global index of shard g's first filter; g = num_shards: N */
+/* kb_set: a per-filter array [N][elems_per_filter] is cut at the shard boundaries, a shared one (broadcast) goes to all */
+int kb_sharded_set(kb_sharded *s, int field, const double *host, int64_t count, int broadcast, int p_rows,
+                   int64_t elems_per_filter);
+int kb_sharded_set_noise_kind(kb_sharded *s, int noise_kind, uint64_t seed);
+int kb_sharded_init(kb_sharded *s);
+int kb_sharded_reset(kb_sharded *s);
+int kb_sharded_synchronize(kb_sharded *s);
+/* LDKF.Update on every shard in parallel: host measurements [N][meas_rows] (kb_update), or every shard's measurements
+ * already in ITS device's memory, meas[g] planar with leading dimension ld_meas[g] (kb_update_dev; asynchronous) */
+int kb_sharded_update(kb_sharded *s, const double *meas, int meas_rows, const double *ctrl, int ctrl_rows);
+int kb_sharded_update_dev(kb_sharded *s, const void *const *meas, const int64_t *ld_meas, const void *const *ctrl,
+                          const int64_t *ld_ctrl);
+int kb_sharded_get(kb_sharded *s, int field, double *host, int64_t first, int64_t count, int64_t elems_per_filter);
+int kb_sharded_get_status(kb_sharded *s, uint32_t *host, int64_t first, int64_t count);
+/* NewMonteCarloRuns / NewChiSquare over the whole node: one ensemble, shard g runs the runs [first(g), first(g + 1)) (a run's
+ * noise depends only on its global index); sums as kb_mc_run / kb_chisquare, over ALL runs. */
+int kb_sharded_mc_run(kb_sharded *s, int steps, const double *controls, int ncontrols, double *sums, unsigned mc_flags);
+int kb_sharded_chisquare(kb_sharded *truth, kb_sharded *kf, int steps, const double *controls, int ncontrols,
+                         int replay_last_mc, int with_nees, int with_nis, double *sums);
+int kb_sharded_used_rccl(const kb_sharded *s); /* 1: the last statistics reduction went through ncclAllReduce, 0: host sum */
+
 #ifdef __cplusplus
 }
 #endif

@@ -667,6 +667,92 @@ inline std::pair<std::vector<double>, std::vector<double>> NewChiSquare(LDKF &kf
     return {nis, nees};
 }
 
+// ---- one process, every GPU of the node (kb_sharded_* in gokalman_amd.h) ---------------------------
+// N LDKF filters split into contiguous shards over the visible devices -- GPU g owns [g N / G, (g + 1) N / G) -- one handle, host
+// thread and stream per device; Update has no collective, the Monte-Carlo / chi-square statistics are ONE ncclAllReduce over RCCL
+// (host sum when the shards share a device).  Matrices as everywhere: one shared (rows x cols) or N of them back to back.
+class ShardedBatch {
+   public:
+    ShardedBatch(int kind, const Vector &x0, const Matrix &P0, const Matrix &F, const Matrix &G, const Matrix &H, const Noise &noise,
+                 int64_t N, std::vector<int> devices = {}, unsigned flags = 0)
+        : n_(x0.rows), p_(H.rows), m_(G.cols), N_(N) {
+        if (devices.empty())
+            for (int g = 0; g < kb_device_count(); g++) devices.push_back(g);
+        check(kb_sharded_create(&s_, kind, n_, p_, m_, N, KB_F64, devices.data(), (int)devices.size(), flags));
+        auto set = [&](int field, const Matrix &mtx, int p_rows) {
+            if (mtx.data.empty()) return;
+            const int64_t per = (int64_t)mtx.rows * mtx.cols;
+            check(kb_sharded_set(s_, field, mtx.data.data(), mtx.shared() ? 1 : N, mtx.shared() ? 1 : 0, p_rows, per));
+        };
+        set(KB_X, x0, 0); set(KB_P, P0, 0); set(KB_F, F, 0);
+        if (m_ > 0) set(KB_G, G, 0);
+        set(KB_H, H, H.rows); set(KB_Q, noise.Q, 0); set(KB_R, noise.R, noise.R.rows);
+        if (noise.kind != KB_NOISE_NOISELESS) check(kb_sharded_set_noise_kind(s_, noise.kind, noise.seed));
+        check(kb_sharded_init(s_));
+    }
+    ~ShardedBatch() { kb_sharded_destroy(s_); }
+    ShardedBatch(const ShardedBatch &) = delete;
+    ShardedBatch &operator=(const ShardedBatch &) = delete;
+    kb_sharded *handle() const { return s_; }
+    int Shards() const { return kb_sharded_num_shards(s_); }
+    int64_t First(int g) const { return kb_sharded_first(s_, g); }
+    int64_t N() const { return N_; }
+    // LDKF.Update(measurement, control) on every filter, the shards in parallel: measurements [N][p] (or one vector for all)
+    void Update(const Vector &measurement, const Vector &control = Vector()) {
+        const std::vector<double> y = expand(measurement), u = expand(control);
+        check(kb_sharded_update(s_, y.data(), measurement.rows, control.rows ? u.data() : nullptr, control.rows));
+    }
+    void Reset() { check(kb_sharded_reset(s_)); }
+    Matrix State() const { return get(KB_STATE, n_, 1); }
+    Matrix Covariance() const { return get(KB_COVAR, n_, n_); }
+    std::vector<uint32_t> Status() const {
+        std::vector<uint32_t> st((size_t)N_);
+        check(kb_sharded_get_status(s_, st.data(), 0, N_));
+        return st;
+    }
+    // NewMonteCarloRuns over the whole node (montecarlo.go:92-119): mean / stddev per step over ALL runs; usedRccl = how they were reduced
+    struct Stats { int steps, n; std::vector<double> mean, stddev; bool usedRccl; };
+    Stats MonteCarlo(int steps, const std::vector<Vector> &controls) {
+        std::vector<double> ctrl;
+        for (const auto &c : controls) ctrl.insert(ctrl.end(), c.data.begin(), c.data.end());
+        std::vector<double> sums((size_t)steps * 3 * n_);
+        check(kb_sharded_mc_run(s_, steps, ctrl.data(), (int)controls.size(), sums.data(), 0u));
+        Stats st{steps, n_, std::vector<double>((size_t)steps * n_), std::vector<double>((size_t)steps * n_), kb_sharded_used_rccl(s_) != 0};
+        check(kb_mc_stats(sums.data(), steps, n_, N_, st.mean.data(), st.stddev.data()));
+        return st;
+    }
+    // NewChiSquare over the whole node (chisquare.go:16-95): (NISmeans, NEESmeans); `*this` is the truth (pure predictor, AWGN)
+    std::pair<std::vector<double>, std::vector<double>> ChiSquare(ShardedBatch &kf, int steps, const std::vector<Vector> &controls, bool replayLastMC,
+                                                                   bool withNEES = true, bool withNIS = true) {
+        std::vector<double> ctrl;
+        for (const auto &c : controls) ctrl.insert(ctrl.end(), c.data.begin(), c.data.end());
+        std::vector<double> sums((size_t)steps * 2);
+        check(kb_sharded_chisquare(s_, kf.s_, steps, ctrl.data(), (int)controls.size(), replayLastMC, withNEES, withNIS, sums.data()));
+        std::vector<double> nis((size_t)steps), nees((size_t)steps);
+        for (int t = 0; t < steps; t++) { nis[(size_t)t] = sums[(size_t)t * 2] / (double)N_; nees[(size_t)t] = sums[(size_t)t * 2 + 1] / (double)N_; }
+        return {nis, nees};
+    }
+
+   private:
+    Matrix get(int field, int rows, int cols) const {
+        Matrix out(rows, cols);
+        out.data.assign((size_t)N_ * rows * cols, 0.0);
+        check(kb_sharded_get(s_, field, out.data.data(), 0, N_, (int64_t)rows * cols));
+        return out;
+    }
+    std::vector<double> expand(const Vector &v) const {
+        if (v.rows == 0) return {};
+        if (!v.shared()) return v.data;
+        std::vector<double> out;
+        out.reserve((size_t)N_ * v.rows);
+        for (int64_t i = 0; i < N_; i++) out.insert(out.end(), v.data.begin(), v.data.end());
+        return out;
+    }
+    kb_sharded *s_ = nullptr;
+    int n_, p_, m_;
+    int64_t N_;
+};
+
 // VanLoan(A, Gamma, W, dt) (F, Q, error)   c2d.go:13-75.  The reference returns its Nyquist error NEXT to valid F and Q;
 // here `nyquist` carries it ("gokalman: Nyquist sampling criterion not fulfilled with dt=...").
 struct VanLoanResult { Matrix F, Q; bool nyquist = false; };
