@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgokalman_oracle.so")
+# GOKALMAN_ORACLE_SO: another build of the same sources (tests/test_sanitizers_cpu.py points it at the ASan / UBSan build)
+_SO = os.environ.get("GOKALMAN_ORACLE_SO") or os.path.join(_HERE, "libgokalman_oracle.so")
 _SRC = [os.path.join(_HERE, f) for f in ("gokalman_oracle.c", "vanloan_oracle.c", "gokalman_oracle.h")]
 
 VANILLA, VANILLA_PREDICT, SQUAREROOT, INFORMATION, SRIF, HYBRID, BATCH_LS = 1, 2, 3, 4, 5, 6, 7
@@ -24,8 +25,7 @@ def build(force=False):
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRC)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libgokalman_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     return _SO
 
 
