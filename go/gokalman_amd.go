@@ -25,6 +25,18 @@ static int kbgo_get_estimate(kb_batch *b, int64_t first, int64_t count, double *
     v.innovation = innovation; v.measurement = measurement; v.status = status; v.clear_status = clear_status;
     return kb_get_estimate(b, first, count, &v);
 }
+// The step and the estimate it returns in ONE call and one synchronisation (kb_update_estimate & co.); which = 0: LDKF.Update,
+// 1: NLDKF.Update, 2: NLDKF.Predict
+static int kbgo_step_estimate(kb_batch *b, int which, const double *a, int arows, const double *c, int crows, double *state,
+                              double *covariance, double *pred_covariance, double *gain, double *innovation,
+                              double *measurement, uint32_t *status) {
+    kb_estimate_view v;
+    v.state = state; v.covariance = covariance; v.pred_covariance = pred_covariance; v.gain = gain;
+    v.innovation = innovation; v.measurement = measurement; v.status = status; v.clear_status = 1;
+    if (which == 0) return kb_update_estimate(b, a, arows, c, crows, 0, 1, &v);
+    if (which == 1) return kb_update_nl_estimate(b, a, arows, c, crows, 0, 1, &v);
+    return kb_predict_nl_estimate(b, 0, 1, &v);
+}
 // kb_last_error() is thread-local: copy it out in the same C call frame's thread (see kbCall)
 static void kbgo_last_error(char *dst, size_t n) {
     strncpy(dst, kb_last_error(), n - 1);
@@ -123,7 +135,11 @@ type Estimate struct {
 
 // snapshot downloads the current estimate of filter 0 of b and reads-and-clears its status word, so that one failed
 // Update does not poison the next call (vanilla.go:164-167 returns an error and leaves prevEst alone).
-func snapshot(b *batch, kind C.int) (*Estimate, error) {
+func snapshot(b *batch, kind C.int) (*Estimate, error) { return stepSnapshot(b, kind, -1, nil, nil) }
+
+// stepSnapshot runs one step (which = 0 LDKF.Update(a, c), 1 NLDKF.Update(a, c), 2 NLDKF.Predict(); -1: no step) and snapshots the
+// estimate it produced, with ONE device synchronisation for both.
+func stepSnapshot(b *batch, kind C.int, which int, a, c []float64) (*Estimate, error) {
 	n, p := b.n, int(C.kb_meas_dim(b.h))
 	info := kind == C.KB_INFORMATION || kind == C.KB_SRIF
 	lazy := info || kind == C.KB_SQUAREROOT
@@ -139,9 +155,13 @@ func snapshot(b *batch, kind C.int) (*Estimate, error) {
 	var st C.uint32_t
 	// every slice pointer is a direct cgo argument (pinned for the call); the view struct itself lives in C (see the preamble)
 	if err := kbCall(func() C.int {
-		return C.kbgo_get_estimate(b.h, 0, 1, ptr(e.state), ptr(e.covar), ptr(e.predCovar), ptr(e.gain), ptr(e.innov), ptr(e.meas), &st, 1)
+		if which < 0 {
+			return C.kbgo_get_estimate(b.h, 0, 1, ptr(e.state), ptr(e.covar), ptr(e.predCovar), ptr(e.gain), ptr(e.innov), ptr(e.meas), &st, 1)
+		}
+		return C.kbgo_step_estimate(b.h, C.int(which), ptr(a), C.int(len(a)), ptr(c), C.int(len(c)), ptr(e.state), ptr(e.covar),
+			ptr(e.predCovar), ptr(e.gain), ptr(e.innov), ptr(e.meas), &st)
 	}); err != nil {
-		return nil, err
+		return nil, err // "dimensions must agree: ...", "kf is locked (call Prepare() first)"
 	}
 	e.status = uint32(st)
 	return e, nil
@@ -225,19 +245,13 @@ func (kf *ldkf) handle() *batch { return kf.b }
 // step kernel, then one snapshot.
 func (kf *ldkf) Update(measurement, control *mat64.Vector) (gokalman.Estimate, error) {
 	y := rowMajor(measurement)
-	var up *C.double
-	nu := 0
+	var u []float64
 	if control != nil {
-		if u := rowMajor(control); len(u) > 0 {
-			up, nu = ptr(u), len(u)
-		}
+		u = rowMajor(control)
 	}
-	if err := kbCall(func() C.int { return C.kb_update(kf.b.h, ptr(y), C.int(len(y)), up, C.int(nu)) }); err != nil {
-		return nil, err // "dimensions must agree: ..." (vanilla.go:129-135)
-	}
-	est, err := snapshot(kf.b, kf.kind)
+	est, err := stepSnapshot(kf.b, kf.kind, 0, y, u) // kb_update_estimate: the step and its estimate, one synchronisation
 	if err != nil {
-		return nil, err
+		return nil, err // "dimensions must agree: ..." (vanilla.go:129-135)
 	}
 	if err := stepError(est.status, "`H*P_kp1_minus*H' + R`", false, 0); err != nil {
 		return nil, err // the filter kept its previous estimate and its kf.step; the next Update runs normally
@@ -436,10 +450,10 @@ func (kf *nldkf) whatFailed() string {
 	}
 	return "`H*P_kp1_minus*H' + R`" // hybrid.go:151
 }
-func (kf *nldkf) stepEstimate() (gokalman.Estimate, error) {
-	est, err := snapshot(kf.b, kf.kind)
+func (kf *nldkf) stepEstimate(which int, a, c []float64) (gokalman.Estimate, error) {
+	est, err := stepSnapshot(kf.b, kf.kind, which, a, c)
 	if err != nil {
-		return nil, err
+		return nil, err // "kf is locked (call Prepare() first)", "dimensions must agree: ..."
 	}
 	// kb_step is kf.step: the failed call did not advance it, so it is the k srif.go:113 / hybrid.go:151 print
 	if err := stepError(est.status, kf.whatFailed(), true, int64(C.kb_step(kf.b.h))); err != nil {
@@ -448,17 +462,10 @@ func (kf *nldkf) stepEstimate() (gokalman.Estimate, error) {
 	return est, nil
 }
 func (kf *nldkf) Update(realObservation, computedObservation *mat64.Vector) (gokalman.Estimate, error) { // srif.go:90, hybrid.go:93
-	r, c := rowMajor(realObservation), rowMajor(computedObservation)
-	if err := kbCall(func() C.int { return C.kb_update_nl(kf.b.h, ptr(r), C.int(len(r)), ptr(c), C.int(len(c))) }); err != nil {
-		return nil, err // "kf is locked (call Prepare() first)", "dimensions must agree: ..."
-	}
-	return kf.stepEstimate()
+	return kf.stepEstimate(1, rowMajor(realObservation), rowMajor(computedObservation))
 }
 func (kf *nldkf) Predict() (gokalman.Estimate, error) { // srif.go:96, hybrid.go:99
-	if err := kbCall(func() C.int { return C.kb_predict_nl(kf.b.h) }); err != nil {
-		return nil, err
-	}
-	return kf.stepEstimate()
+	return kf.stepEstimate(2, nil, nil)
 }
 func (kf *nldkf) EKFEnabled() bool { return C.kb_ekf_enabled(kf.b.h) != 0 }
 func (kf *nldkf) EnableEKF()       { C.kb_set_ekf(kf.b.h, 1) }

@@ -48,6 +48,9 @@ SIGNATURES = {
     "kb_get": (_i, [_vp, _i, _dp, _i64, _i64]),
     "kb_get_dev": (_i, [_vp, _i, _vp, _i64]),
     "kb_get_estimate": (_i, [_vp, _i64, _i64, _vp]),
+    "kb_update_estimate": (_i, [_vp, _dp, _i, _dp, _i, _i64, _i64, _vp]),
+    "kb_update_nl_estimate": (_i, [_vp, _dp, _i, _dp, _i, _i64, _i64, _vp]),
+    "kb_predict_nl_estimate": (_i, [_vp, _i64, _i64, _vp]),
     "kb_get_status": (_i, [_vp, C.POINTER(C.c_uint32), _i64, _i64]),
     "kb_clear_status": (_i, [_vp]),
     "kb_is_within_nsigma": (_i, [_vp, C.c_double, C.POINTER(C.c_uint8), _i64, _i64]),

@@ -40,18 +40,20 @@ class Estimate:
     cheap form for batches too large to copy every step: getters download on demand, and raise StaleEstimateError once
     the batch has advanced (never a silent read of a later step); `freeze()` turns it into an owning snapshot."""
 
-    def __init__(self, batch, snapshot=False, first=0, count=None, clear_status=False):
+    def __init__(self, batch, snapshot=False, first=0, count=None, clear_status=False, via=None):
+        """via(view, first, count): a C-ABI call that runs a step AND fills the view (kb_update_estimate & co.: one synchronisation
+        for the step and its estimate); without it an owning estimate is a kb_get_estimate of the batch's current state."""
         self._b = batch
         self._first = first
         self._count = batch.N - first if count is None else count
+        self._own = None
+        if snapshot or via is not None:
+            self._download(clear_status, via)
         self._step = batch.step()
         self._calls = batch.calls()
-        self._own = None
-        if snapshot:
-            self._download(clear_status)
 
     # ---- owning form -------------------------------------------------------------------
-    def _download(self, clear_status=False):
+    def _download(self, clear_status=False, via=None):
         b = self._b
         n, p, cnt = b.n, b.meas_dim(), self._count
         info = b.kind in (k.INFORMATION, k.SRIF)
@@ -71,7 +73,10 @@ class Estimate:
                 setattr(v, name, _ptr(own[name]))
         v.status = own["status"].ctypes.data_as(C.POINTER(C.c_uint32))
         v.clear_status = 1 if clear_status else 0
-        k.check(k.lib().kb_get_estimate(b._h, self._first, cnt, C.byref(v)))
+        if via is not None:
+            k.check(via(C.byref(v), self._first, cnt))
+        else:
+            k.check(k.lib().kb_get_estimate(b._h, self._first, cnt, C.byref(v)))
         self._own = own
 
     def freeze(self):
@@ -309,10 +314,13 @@ class FilterBatch:
                                 % (rows_name, self.N, tuple(np.shape(v))))
         return _f64(v)
 
-    def _estimate(self, snapshot):
+    def _wants_snapshot(self, snapshot):
         if snapshot is None:   # BatchKF has no per-step estimate: Solve() (kb_get) is an explicit call there (batch.go:64-79)
             snapshot = self.N <= SNAPSHOT_MAX_FILTERS and self.kind != k.BATCH_LS
-        return Estimate(self, snapshot=snapshot)
+        return snapshot
+
+    def _estimate(self, snapshot):
+        return Estimate(self, snapshot=self._wants_snapshot(snapshot))
 
     def update(self, measurement, control=None, snapshot=None):
         """LDKF.Update(measurement, control) for every filter; returns the batch Estimate of this step: an owning
@@ -323,8 +331,11 @@ class FilterBatch:
         if control is not None:
             u = self._per_filter(control, "control (u)")
             urows = u.shape[1]
-        k.check(k.lib().kb_update(self._h, _ptr(y), y.shape[1], None if u is None else _ptr(u), urows))
-        return self._estimate(snapshot)
+        up = None if u is None else _ptr(u)
+        if self._wants_snapshot(snapshot):   # the step and its estimate in ONE call and one synchronisation
+            return Estimate(self, via=lambda view, first, cnt: k.lib().kb_update_estimate(self._h, _ptr(y), y.shape[1], up, urows, first, cnt, view))
+        k.check(k.lib().kb_update(self._h, _ptr(y), y.shape[1], up, urows))
+        return Estimate(self, snapshot=False)
 
     def update_dev(self, meas_ptr, ld_meas, ctrl_ptr=None, ld_ctrl=0):
         k.check(k.lib().kb_update_dev(self._h, C.c_void_p(meas_ptr), ld_meas,
@@ -364,12 +375,16 @@ class FilterBatch:
     def update_nl(self, real_obs, computed_obs, snapshot=None):
         r = self._per_filter(real_obs, "real observation")
         c = self._per_filter(computed_obs, "computed observation")
+        if self._wants_snapshot(snapshot):
+            return Estimate(self, via=lambda view, first, cnt: k.lib().kb_update_nl_estimate(self._h, _ptr(r), r.shape[1], _ptr(c), c.shape[1], first, cnt, view))
         k.check(k.lib().kb_update_nl(self._h, _ptr(r), r.shape[1], _ptr(c), c.shape[1]))
-        return self._estimate(snapshot)
+        return Estimate(self, snapshot=False)
 
     def predict_nl(self, snapshot=None):
+        if self._wants_snapshot(snapshot):
+            return Estimate(self, via=lambda view, first, cnt: k.lib().kb_predict_nl_estimate(self._h, first, cnt, view))
         k.check(k.lib().kb_predict_nl(self._h))
-        return self._estimate(snapshot)
+        return Estimate(self, snapshot=False)
 
     # ---- results -----------------------------------------------------------------------
     def _shape(self, field):

@@ -102,7 +102,8 @@ static void nl_after_sync(kb_batch *b, uint32_t lag_before, int snc_before) {
 }
 
 // Update(realObservation, computedObservation): srif.go:90-92, hybrid.go:93-95
-int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs, int computed_rows) {
+static int update_nl_host(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs, int computed_rows,
+                          int64_t first, int64_t count, kb_estimate_view *view) {
     int rc = ready_nl(b);
     if (rc) return rc;
     if (b->locked) { set_error("kf is locked (call Prepare() first)"); return KB_ERR_LOCKED; }
@@ -125,9 +126,19 @@ int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const doubl
     const uint32_t lag_before = b->h_lag ? b->h_lag[0] : 0u;
     const int snc_before = b->snc;
     if ((rc = nl_common(b, a, false))) return rc;
-    KB_HIP(hipStreamSynchronize(b->stream));
+    if (view) rc = kb_get_estimate(b, first, count, view);   // synchronises once, for the step and the snapshot
+    if (!view || rc) KB_HIP(hipStreamSynchronize(b->stream));
     nl_after_sync(b, lag_before, snc_before);
-    return KB_OK;
+    return rc;
+}
+
+int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs, int computed_rows) {
+    return update_nl_host(b, real_obs, real_rows, computed_obs, computed_rows, 0, 0, nullptr);
+}
+int kb_update_nl_estimate(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs, int computed_rows,
+                          int64_t first, int64_t count, kb_estimate_view *view) {
+    if (!view) { set_error("null argument"); return KB_ERR_INVALID; }
+    return update_nl_host(b, real_obs, real_rows, computed_obs, computed_rows, first, count, view);
 }
 
 int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs, int64_t ld) {
@@ -143,7 +154,7 @@ int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs
 }
 
 // Predict(): srif.go:96-98, hybrid.go:99-101
-int kb_predict_nl(kb_batch *b) {
+static int predict_nl_host(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *view) {
     int rc = ready_nl(b);
     if (rc) return rc;
     if (b->kind == KB_BATCH_LS) { set_error("BatchKF has no Predict()"); return KB_ERR_UNSUPPORTED; }
@@ -152,9 +163,16 @@ int kb_predict_nl(kb_batch *b) {
     const uint32_t lag_before = b->h_lag ? b->h_lag[0] : 0u;
     const int snc_before = b->snc;
     if ((rc = nl_common(b, a, true))) return rc;
-    KB_HIP(hipStreamSynchronize(b->stream));
+    if (view) rc = kb_get_estimate(b, first, count, view);
+    if (!view || rc) KB_HIP(hipStreamSynchronize(b->stream));
     nl_after_sync(b, lag_before, snc_before);
-    return KB_OK;
+    return rc;
+}
+
+int kb_predict_nl(kb_batch *b) { return predict_nl_host(b, 0, 0, nullptr); }
+int kb_predict_nl_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *view) {
+    if (!view) { set_error("null argument"); return KB_ERR_INVALID; }
+    return predict_nl_host(b, first, count, view);
 }
 
 // SmoothAll(estimates) (hybrid.go:209-238, srif.go:165-192; estimates without SNC)

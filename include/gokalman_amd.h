@@ -224,6 +224,14 @@ typedef struct kb_estimate_view {
     int clear_status;
 } kb_estimate_view;
 int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *view);
+/* The reference's `est, err := kf.Update(y, u)` in ONE call and ONE synchronisation: the step (kb_update / kb_update_nl /
+ * kb_predict_nl) and the snapshot of the estimate it produced are enqueued back to back.  This is what the host shims call for
+ * every Update of a drop-in filter (one filter: 22 us per step against 32 us for kb_update + kb_get_estimate). */
+int kb_update_estimate(kb_batch *b, const double *meas, int meas_rows, const double *ctrl, int ctrl_rows, int64_t first,
+                       int64_t count, kb_estimate_view *view);
+int kb_update_nl_estimate(kb_batch *b, const double *real_obs, int real_rows, const double *computed_obs,
+                          int computed_rows, int64_t first, int64_t count, kb_estimate_view *view);
+int kb_predict_nl_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *view);
 /* Planar device-side variant: writes element e of filter i to dst[e*ld + i] in the batch dtype. */
 int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld);
 int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count);

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -192,12 +193,22 @@ class Estimate {
     };
     Estimate() = default;
     // snapshot == true: download now (clear_status: read-and-clear the status words, the per-call error semantics)
-    Estimate(std::shared_ptr<Batch> b, bool snapshot, bool clear_status = false) : b_(std::move(b)), step_(kb_step(b_->handle())), calls_(kb_calls(b_->handle())) {
-        if (snapshot) snap_ = download(*b_, clear_status);
+    Estimate(std::shared_ptr<Batch> b, bool snapshot, bool clear_status = false) : b_(std::move(b)) {
+        if (snapshot) snap_ = download(*b_, clear_status, nullptr);
+        step_ = kb_step(b_->handle());
+        calls_ = kb_calls(b_->handle());
+    }
+    // The estimate of a step that `step_call` runs: kb_update_estimate & co. enqueue the step and the snapshot back to back and the
+    // host waits ONCE (the reference's `est, err := kf.Update(y, u)`)
+    using StepCall = std::function<int(int64_t first, int64_t count, kb_estimate_view *view)>;
+    Estimate(std::shared_ptr<Batch> b, const StepCall &step_call, bool clear_status) : b_(std::move(b)) {
+        snap_ = download(*b_, clear_status, &step_call);
+        step_ = kb_step(b_->handle());
+        calls_ = kb_calls(b_->handle());
     }
     bool Owning() const { return snap_ != nullptr; }
     Estimate &Freeze() {
-        if (!snap_) { live(); snap_ = download(*b_, false); }
+        if (!snap_) { live(); snap_ = download(*b_, false, nullptr); }
         return *this;
     }
     Vector State() const { return snap_ ? snap_->state : (live(), b_->get(KB_STATE, b_->n(), 1)); }
@@ -266,7 +277,7 @@ class Estimate {
     }
 
    private:
-    static std::shared_ptr<const Snapshot> download(Batch &b, bool clear_status) {
+    static std::shared_ptr<const Snapshot> download(Batch &b, bool clear_status, const StepCall *step_call) {
         auto s = std::make_shared<Snapshot>();
         const int n = b.n(), p = kb_meas_dim(b.handle());
         const int64_t N = b.N();
@@ -286,7 +297,7 @@ class Estimate {
         s->status.assign((size_t)N, 0u);
         v.status = s->status.data();
         v.clear_status = clear_status ? 1 : 0;
-        check(kb_get_estimate(b.handle(), 0, N, &v));
+        check(step_call ? (*step_call)(0, N, &v) : kb_get_estimate(b.handle(), 0, N, &v));
         return s;
     }
     void live() const {
@@ -306,9 +317,10 @@ class Estimate {
 // The estimate of the step that just ran, with the reference's per-call error behaviour.  at_k: srif.go:113 and hybrid.go:151
 // print the step ("... at k=%d: ..."), vanilla.go:166 does not.  kf.step is not advanced by the failed call (kb_step), so it
 // still is the k of the step that failed.
-inline Estimate step_estimate(const std::shared_ptr<Batch> &b, const char *what_failed, bool at_k) {
-    if (b->N() > kSnapshotMaxFilters) return Estimate(b, false);
-    Estimate est(b, true, /*clear_status=*/true);
+inline Estimate step_estimate(const std::shared_ptr<Batch> &b, const char *what_failed, bool at_k, const Estimate::StepCall &step_call,
+                              const std::function<int()> &step_only) {
+    if (b->N() > kSnapshotMaxFilters) { check(step_only()); return Estimate(b, false); }
+    Estimate est(b, step_call, /*clear_status=*/true);
     if (b->N() == 1) {
         const uint32_t st = est.Status()[0];
         if (st & KB_ST_SINGULAR)
@@ -327,8 +339,11 @@ class LDKF {
     // Update(measurement, control *mat64.Vector) (Estimate, error)
     Estimate Update(const Vector &measurement, const Vector &control) {
         const std::vector<double> y = expand(measurement), u = expand(control);
-        check(kb_update(b_->handle(), y.data(), measurement.rows, control.rows ? u.data() : nullptr, control.rows));
-        return step_estimate(b_, "`H*P_kp1_minus*H' + R`", false);   // vanilla.go:166
+        const double *up = control.rows ? u.data() : nullptr;
+        kb_batch *h = b_->handle();
+        return step_estimate(b_, "`H*P_kp1_minus*H' + R`", false,   // vanilla.go:166
+                             [&](int64_t first, int64_t count, kb_estimate_view *v) { return kb_update_estimate(h, y.data(), measurement.rows, up, control.rows, first, count, v); },
+                             [&] { return kb_update(h, y.data(), measurement.rows, up, control.rows); });
     }
     const Noise &GetNoise() const { return noise_; }
     const Matrix &GetStateTransition() const { return F_; }
@@ -436,11 +451,19 @@ class NLDKF {
     void Prepare(const Matrix &Phi, const Matrix &Htilde) {
         check(kb_prepare(b_->handle(), Phi.data.data(), Htilde.data.data(), Phi.shared() ? 1 : b_->N(), Phi.shared() ? 1 : 0));
     }
-    Estimate Predict() { check(kb_predict_nl(b_->handle())); return step_estimate(b_, what_failed(), true); }
+    Estimate Predict() {
+        kb_batch *h = b_->handle();
+        return step_estimate(b_, what_failed(), true, [&](int64_t first, int64_t count, kb_estimate_view *v) { return kb_predict_nl_estimate(h, first, count, v); },
+                             [&] { return kb_predict_nl(h); });
+    }
     Estimate Update(const Vector &realObservation, const Vector &computedObservation) {
         const std::vector<double> r = expand(realObservation), c = expand(computedObservation);
-        check(kb_update_nl(b_->handle(), r.data(), realObservation.rows, c.data(), computedObservation.rows));
-        return step_estimate(b_, what_failed(), true);
+        kb_batch *h = b_->handle();
+        return step_estimate(b_, what_failed(), true,
+                             [&](int64_t first, int64_t count, kb_estimate_view *v) {
+                                 return kb_update_nl_estimate(h, r.data(), realObservation.rows, c.data(), computedObservation.rows, first, count, v);
+                             },
+                             [&] { return kb_update_nl(h, r.data(), realObservation.rows, c.data(), computedObservation.rows); });
     }
     int64_t Step() const { return kb_step(b_->handle()); }
     bool EKFEnabled() const { return kb_ekf_enabled(b_->handle()) != 0; }

@@ -40,6 +40,11 @@ int main() {
         v.innovation = in.data(); v.measurement = yh.data(); v.status = &st; v.clear_status = 1;
         kb_get_estimate(b, 0, 1, &v);
     });
+    timeit("kb_update_estimate(all six members, status): ONE synchronisation", [&] {
+        kb_estimate_view v{}; v.state = xs.data(); v.covariance = Pc.data(); v.pred_covariance = Pp.data(); v.gain = K.data();
+        v.innovation = in.data(); v.measurement = yh.data(); v.status = &st; v.clear_status = 1;
+        kb_update_estimate(b, y.data(), p, nullptr, 0, 0, 1, &v);
+    });
     timeit("kb_update + kb_get(STATE) + kb_get(COVAR) + kb_get_status  (round 1)", [&] {
         kb_update(b, y.data(), p, nullptr, 0);
         kb_get(b, KB_STATE, xs.data(), 0, 1); kb_get(b, KB_COVAR, Pc.data(), 0, 1); kb_get_status(b, &st, 0, 1);
