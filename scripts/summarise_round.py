@@ -55,7 +55,7 @@ def jsonl(path):
     return out
 
 
-WARMER = "vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false>"   # warm_clocks() of bench_kinds.py / bench_chisq.py
+WARMER = "vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, false>"   # warm_clocks() of bench_kinds.py / bench_chisq.py
 
 
 def main():
@@ -84,7 +84,8 @@ def main():
     traffic = []
     md.append("\n## HBM-side traffic per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; KiB counters -> bytes)\n")
     md.append("| kernel | launches | read B | written B | total B | per filter |\n|---|---|---|---|---|---|")
-    filters = {"vanilla_reg_kernel<double, 6, 3, 0": 1 << 20, "squareroot_reg_kernel<double, 6, 3": 1 << 20, "information_reg_kernel<double, 6, 3": 1 << 20,
+    filters = {"vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, true": 1 << 20,   # AWGN (bench_kinds vnoise)
+               "vanilla_reg_kernel<double, 6, 3, 0": 1 << 20, "squareroot_reg_kernel<double, 6, 3": 1 << 20, "information_reg_kernel<double, 6, 3": 1 << 20,
                "hybrid_reg_kernel<double, 6, 2": 1 << 20, "srif_pair_kernel<float, 12, 6": 1 << 18, "srif_pair_kernel<double, 12, 6": 1 << 18}
     for fkey, wkey in (("bench_fetch", "bench_write"), ("kinds_fetch", "kinds_write")):
         fe, wr = c["pmc"].get(fkey, {}), c["pmc"].get(wkey, {})
@@ -123,9 +124,9 @@ def main():
         if "vanilla_reg_kernel<double, 6, 3, 0, false, false, true" in kn:
             named["vanilla_fused"] = dict(v, kernel=kn, steps_per_launch=16, valu_insts_per_wave_per_step=v["valu_insts_per_wave"] / 16.0)
         if "mc_kernel<double, 4, 2" in kn:
-            named["mc"] = dict(v, kernel=kn)
+            named["mc"] = dict(v, kernel=kn, steps_per_launch=1086)
         if "chisq_kernel" in kn:
-            named["chisq"] = dict(v, kernel=kn)
+            named["chisq"] = dict(v, kernel=kn, steps_per_launch=1086)
         if "srif_pair_kernel<float, 12, 6, false, true" in kn:
             named["srif_pair_f32"] = dict(v, kernel=kn)
         if "srif_pair_kernel<double, 12, 6, false, true" in kn:
