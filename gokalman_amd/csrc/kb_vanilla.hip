@@ -248,6 +248,8 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
     bool done = false;
     if (!(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind != KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_noise(b, a) || launch_vanilla_noise_padded(b, a);   // AWGN / BatchNoise on the register kernels
+    if ((a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
+        done = launch_vanilla_strict(b, a);
     if (special) {
         done = try_reg<T, 6, 3, 0>(b, a, fused) || try_reg<T, 4, 2, 0>(b, a, fused);
         if (!done && b.dtype == KB_F64) done = launch_vanilla_extra_shapes(b, a, fused);

@@ -544,5 +544,7 @@ bool launch_vanilla_padded8(const Batch &b, const StepArgs &a);
 // AWGN / BatchNoise batches (kb_vanilla_noise.hip, kb_vanilla_noise_pad.hip): every shape up to n = 8, p = 4, m = 2, fp64
 bool launch_vanilla_noise(const Batch &b, const StepArgs &a);
 bool launch_vanilla_noise_padded(const Batch &b, const StepArgs &a);
+// KB_FLAG_STRICT_SYMCHECK batches (kb_vanilla_strict.hip): both triangles, AsSymDense's test, the oracle's rounding; n <= 6, p <= 4, m <= 2
+bool launch_vanilla_strict(const Batch &b, const StepArgs &a);
 
 }  // namespace kb

@@ -124,3 +124,60 @@ def test_overflowing_covariance_fails_the_step_on_both_kernels_as_in_the_oracle(
     for i in huge:
         f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], P0[i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i])
         assert f.update(d["y"][0, i]) == orc.ERR_SINGULAR
+
+
+@pytest.mark.parametrize("n,p,m", [(3, 1, 0), (4, 2, 0), (4, 2, 1), (6, 3, 0), (5, 3, 2), (6, 4, 2), (2, 1, 0)])
+@pytest.mark.parametrize("full", [False, True])
+def test_strict_register_kernel_is_bit_identical_to_the_statement_kernel(n, p, m, full):
+    """KB_FLAG_STRICT_SYMCHECK batches up to 6 / 4 / 2 run kb_vanilla_strict.hip (registers, compile-time sizes, zero padding);
+    kb_update_steps_dev still takes vanilla_gen_kernel.  Same operand order, no contraction, same pivots: every bit agrees --
+    states, covariances, the FULL outputs and the status words, including filters that fail the symmetry test, singular ones
+    and non-finite ones."""
+    import torch
+    N, steps = 300, 4
+    rng = np.random.default_rng(100 * n + 10 * p + m)
+    d = synth.linear_batch(N, 8, 4, steps, seed=7)
+    F = d["F"][:, :n, :n].copy(); P0 = d["P0"][:, :n, :n].copy(); Q = d["Q"][:, :n, :n].copy()
+    H = d["H"][:, :p, :n].copy(); R = d["R"][:, :p, :p].copy(); x0 = d["x0"][:, :n].copy()
+    if n >= 3:      # a third of the filters trip AsSymDense by cancellation, as in the test above
+        Fc, Pc = _cancelling_models(N, seed=3)
+        F[1::3, :3, :3] = Fc[1::3]; F[1::3, 3:, :3] = 0; F[1::3, :3, 3:] = 0
+        P0[1::3] = 0; P0[1::3, :3, :3] = Pc[1::3]
+        for i in range(3, n):
+            P0[1::3, i, i] = 1.0
+    H[5] = 0.0; R[5] = 0.0                      # singular innovation covariance
+    with np.errstate(over="ignore"):
+        P0[8] = np.full((n, n), 1e308)           # overflows in F P F^T
+    G = rng.standard_normal((N, n, m)) if m else None
+    y = torch.from_numpy(np.ascontiguousarray(d["y"][:, :, :p].transpose(0, 2, 1))).cuda()          # [T][p][N]
+    u = torch.from_numpy(np.ascontiguousarray(rng.standard_normal((steps, m, N)))).cuda() if m else None
+    flags = k.FLAG_STRICT_SYMCHECK | (k.FLAG_FULL_ESTIMATE if full else 0)
+    out = []
+    for reg in (True, False):
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, flags=flags)
+        per_step = []
+        for t in range(steps):
+            up = (u[t].data_ptr(), N) if m else (None, 0)
+            if reg:
+                b.update_dev(y[t].data_ptr(), N, *up)
+            else:
+                b.update_steps_dev(y[t].data_ptr(), N, 1, *up)
+            b.synchronize()
+            fields = [k.STATE, k.COVAR] + ([k.PRED_COVAR, k.GAIN, k.INNOVATION, k.MEASUREMENT] if full else [])
+            per_step.append([b.get(f).copy() for f in fields] + [b.status().copy()])
+        out.append(per_step)
+    nbad = 0
+    for t in range(steps):
+        st = out[0][t][-1]
+        assert np.array_equal(st, out[1][t][-1])
+        good = st == 0
+        for a_, b_ in zip(out[0][t][:-1], out[1][t][:-1]):
+            # failed filters keep their previous estimate (bitwise too); FULL outputs of a failed step are not written
+            assert np.array_equal(a_[good].view(np.uint64), b_[good].view(np.uint64))
+        assert np.array_equal(out[0][t][0].view(np.uint64), out[1][t][0].view(np.uint64))
+        assert np.array_equal(out[0][t][1].view(np.uint64), out[1][t][1].view(np.uint64))
+        nbad = max(nbad, int(np.count_nonzero(st)))
+    st = out[0][0][-1]
+    assert st[5] & k.ST_SINGULAR and st[8] != 0
+    if n >= 3:
+        assert np.count_nonzero(st & k.ST_ASYMMETRIC) >= 20
