@@ -377,6 +377,7 @@ def main():
         if e:   # VALU-issue roofline of mc_kernel (the reduction's host side and the all-reduce are in `seconds`, not in the floor)
             per_step = e["valu_insts_per_wave"] / float(e.get("steps_per_launch", 1086))
             extra["mc"]["roofline"] = rl.valu_roofline(mc_s * 1e3, (args.mc_runs + 63) // 64, per_step * args.mc_steps, vsrc)
+            extra["mc"]["roofline"]["kernel_ms_is"] = "the whole NewMonteCarloRuns call (mc_kernel + fold + D2H of the sums + host object), not the kernel alone"
         # ---- chi-square on the same ensemble (chisquare.go:16-95): NIS / NEES sums all-reduced like the means ----
         if args.chisq_runs > 0:
             R = min(args.chisq_runs, args.mc_runs)
@@ -398,6 +399,7 @@ def main():
             if e:
                 per_step = e["valu_insts_per_wave"] / float(e.get("steps_per_launch", 1086))
                 extra["chisq"]["roofline"] = rl.valu_roofline(c_s * 1e3, (R + 63) // 64, per_step * args.mc_steps, vsrc)
+                extra["chisq"]["roofline"]["kernel_ms_is"] = "the whole NewChiSquare call (replicate kf, chisq_kernel, fold, D2H), not the kernel alone"
             del ckf
         del kf
     # ---- extra: config D(ii), Hybrid EKF ensemble sharded the same way ---------------------------------------------
