@@ -214,8 +214,12 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     // fp64 (one wave per SIMD, nothing else hides its latency): the largest HBM stream, Phi, is requested first -- 3.5 % faster
     // than with it last; in fp32 the other order is 1 % ahead (b and R, the Infinity-Cache hits State(prev) starts from, arrive earlier)
     constexpr bool PHI_FIRST = sizeof(T) == 8 && !DENSE;
+    // fp64 steady state: the measurement operands (63 values = 126 registers) are requested only when Phi's registers are free (its
+    // factors are in LDS) and whitened after the RBar solves, whose ~25 us hide that second latency: 1143 -> 986 AGPR copies in the
+    // code, 200 -> 191 us per 256k-filter step (profiles/NOTES.md).  In fp32 (two waves per SIMD, no AGPRs) the same order gains nothing.
+    constexpr bool MEAS_LATE = sizeof(T) == 8 && !DENSE;
     if constexpr (PHI_FIRST) load_phi();
-    load_meas();
+    if constexpr (!MEAS_LATE) load_meas();
     [[maybe_unused]] T bown[HS];   // b of the own rows
     if constexpr (DENSE) {
 #pragma unroll
@@ -340,9 +344,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     }
 
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MEAS_LATE) { load_meas(); __builtin_amdgcn_sched_barrier(0); }
     // ---- whitened measurement rows (srif.go:146-148): [L Htilde | L y].  Each half forms ALL rows of L Htilde for ITS
     // columns (Htilde is held column-split like Phi: half the registers, half the loads), then one exchange per pair of
     // values turns columns-of-all-rows into all-columns-of-the-own-rows.
+    auto whiten = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < HM; t++) {
 #pragma unroll
@@ -364,8 +370,10 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         A.set(HS + t, NS, is_hi ? s1 : s0);
         if constexpr (FULL) yown[t] = is_hi ? yreal[2 * t + 1] : yreal[2 * t];
     }
+    };
+    if constexpr (!MEAS_LATE) whiten();
 
-    __builtin_amdgcn_sched_barrier(0);   // the measurement operands are dead from here on
+    __builtin_amdgcn_sched_barrier(0);   // (!MEAS_LATE) the measurement operands are dead from here on
     // ---- RBar = R Phi^-1 (srif.go:115) for the own rows: z Phi = R[i,:], i.e. w U = r, v L = w, z[perm_k] = v_k --------
     // A[s][0..NS) is z for row 2 s + l; columns < 2 s are structural zeros (skipped) unless DENSE
     // two columns (2 c, 2 c + 1) at a time: the pair subtracts A[s][k2] (U[k2][2 c], U[k2][2 c + 1]) in one packed FMA
@@ -473,6 +481,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             A.set(s, NS, bb);
         }
     }
+    if constexpr (MEAS_LATE) { __builtin_amdgcn_sched_barrier(0); whiten(); }
     if constexpr (FULL) {
         if (ok) {
 #pragma unroll
