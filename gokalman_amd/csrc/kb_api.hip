@@ -8,6 +8,8 @@
 #include <mutex>
 #include <vector>
 
+#include <chrono>
+
 #include "kb_internal.h"
 
 namespace kb {
@@ -71,7 +73,9 @@ int ensure_stage(Batch &b, size_t bytes) {
 
 int ensure_pin(Batch &b) {
     if (b.h_pin) return KB_OK;
-    KB_HIP(hipHostMalloc(&b.h_pin, 3 * KB_PIN_TILE_BYTES + KB_PIN_OUT_BYTES, hipHostMallocMapped));
+    KB_HIP(hipHostMalloc(&b.h_pin, KB_PIN_FLAG_OFF + 64, hipHostMallocMapped));
+    *(volatile uint32_t *)((char *)b.h_pin + KB_PIN_FLAG_OFF) = 0;
+    b.pin_seq = 0;
     if (hipHostGetDevicePointer(&b.d_pin, b.h_pin, 0) != hipSuccess) {
         (void)hipHostFree(b.h_pin);
         b.h_pin = b.d_pin = nullptr;
@@ -737,6 +741,20 @@ int kb_get_dev(kb_batch *b, int field, void *dst, int64_t ld) {
 
 // One snapshot of the Estimate of filters [first, first+count): every requested member is unpacked into ONE staging
 // area (the pinned, device-mapped buffer when it fits: no copy at all) and handed over after ONE stream synchronisation.
+// Completion of a flagged snapshot without the runtime: the kernel's last store is the sequence number, to pinned host memory; the
+// host polls that word.  hipStreamSynchronize costs 11.5 us for an empty kernel on this stack, the polled word 7.5
+// (scripts/diag_launch_latency.hip): 3-4 us per one-filter Update-with-estimate.  Bounded: after 200 us (a busy stream, or a launch
+// that never ran) the caller falls back to hipStreamSynchronize, which also reports an asynchronous error.
+static bool wait_snapshot(const Batch &b) {
+    const uint32_t *flag = (const uint32_t *)((const char *)b.h_pin + KB_PIN_FLAG_OFF);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == b.pin_seq) return true;
+        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) return false;
+        __builtin_ia32_pause();
+    }
+}
+
 int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *v) {
     if (!b || !v) { set_error("null argument"); return KB_ERR_INVALID; }
     int rc = use_device(*b);
@@ -774,6 +792,10 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
     // batch without KB_FLAG_FULL_ESTIMATE, a launch error) fails the call before anything has been cleared.
     const int status_pass = (lazy && v->pred_covariance) ? 1 : 0;
     bool cleared = false;
+    // which pass is the last one that launches anything (status travels with status_pass; pass 1 only exists for lazy pred_covariance)
+    const int last_pass = (lazy && v->pred_covariance) ? 1 : 0;
+    const bool flagged = pinned && count <= KB_SNAP_FLAG_MAX;
+    bool flag_armed = false;
     // after the clear nothing may fail silently: the SRIF Update finds filters that may hold a dense R through their status
     // words (kb_srif_pair.h), so a lost word sends the next Update down the dense path
     auto after_clear = [&](int code) { if (code && cleared && b->kind == KB_SRIF) b->srif_tri = 0; return code; };
@@ -793,13 +815,17 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
         }
         const bool with_status = v->status && pass == status_pass;
         if (sa.nmembers == 0 && !with_status) continue;
-        if ((rc = launch_snapshot(*b, sa, first, count, d_area, with_status ? b->d_status : nullptr, (int64_t)st_off, v->clear_status ? 1 : 0))) return rc;
+        // the LAST launch of a small snapshot raises a completion word in the pinned block (see wait_snapshot)
+        uint32_t *done = nullptr;
+        if (flagged && pass == last_pass) { done = (uint32_t *)((char *)b->d_pin + KB_PIN_FLAG_OFF); ++b->pin_seq; }
+        if ((rc = launch_snapshot(*b, sa, first, count, d_area, with_status ? b->d_status : nullptr, (int64_t)st_off, v->clear_status ? 1 : 0, done, b->pin_seq))) return rc;
+        if (done) flag_armed = true;
         if (with_status && v->clear_status) cleared = true;
     }
 #undef KB_HIP
 #define KB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return after_clear(::kb::hip_fail(e__, #call)); } while (0)
     if (pinned) {
-        KB_HIP(hipStreamSynchronize(b->stream));
+        if (!(flag_armed && wait_snapshot(*b))) KB_HIP(hipStreamSynchronize(b->stream));
         for (int i = 0; i < 6; i++)
             if (want[i].dst) memcpy(want[i].dst, h_area + want[i].off, want[i].bytes);
         if (v->status) memcpy(v->status, h_area + st_off, (size_t)count * sizeof(uint32_t));

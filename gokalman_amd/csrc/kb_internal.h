@@ -55,6 +55,7 @@ struct Batch {
     // Batches of at most one tile (the reference's own use: one filter) skip the staging copies: the host writes / reads a
     // pinned, device-mapped buffer the kernels access directly (3 input tiles + one read-back area).
     void *h_pin = nullptr, *d_pin = nullptr;
+    uint32_t pin_seq = 0;   // sequence number of the last flagged snapshot (the word at KB_PIN_FLAG_OFF of the pinned block)
     void *d_y2 = nullptr;
     void *d_xp = nullptr;      // cached getter scratch: materialised State() | Covariance() (x[n] | P packed) per filter
     uint8_t *d_flags = nullptr;  // cached IsWithinNsigma output
@@ -136,7 +137,9 @@ struct SnapArgs {   // kernel argument of the one-launch Estimate snapshot (kb_g
     int16_t map[6][KB_MAX_DIM * KB_MAX_DIM];
     int nmembers;
 };
-int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t count, void *area, uint32_t *status, int64_t status_off, int clear);
+// done != nullptr (count <= KB_SNAP_FLAG_MAX): one block copies every filter, then stores `seq` to *done (pinned host memory, system scope)
+int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t count, void *area, uint32_t *status, int64_t status_off, int clear,
+                    uint32_t *done = nullptr, uint32_t seq = 0);
 int launch_pack(const Batch &b, const void *src_aos, int src_elems, int64_t count, bool broadcast,
                 void *dst_block, int dst_elems, const int16_t *map /* [src_elems] -> dst elem or -1 */);
 int launch_unpack(const Batch &b, const void *src_block, int src_elems, const int16_t *map /* [dst_elems] -> src elem or -1 (0.0) */,
@@ -188,6 +191,8 @@ int stage_host_vec(Batch &b, const double *host, int rows, void **dblock, int sl
 int ensure_pin(Batch &b);
 constexpr size_t KB_PIN_TILE_BYTES = (size_t)KB_MAX_DIM * KB_TILE * sizeof(double);
 constexpr size_t KB_PIN_OUT_BYTES = (size_t)KB_TILE * KB_MAX_DIM * KB_MAX_DIM * sizeof(double);
+constexpr size_t KB_PIN_FLAG_OFF = 3 * KB_PIN_TILE_BYTES + KB_PIN_OUT_BYTES;   // completion word of a small snapshot, then padding to a cache line
+constexpr int KB_SNAP_FLAG_MAX = 16;   // snapshots of up to this many filters run as ONE block that raises the completion word itself
 void fill_step_args(const Batch &b, StepArgs &a);
 int upload_field(Batch &b, int field, const double *host, int64_t count, int broadcast, int p_rows);
 

@@ -53,9 +53,9 @@ __global__ void unpack_planar_kernel(const T *__restrict__ src, int src_elems, i
 // destination is pinned HOST memory written across PCIe, where 64 lanes storing neighbouring doubles make a few large
 // transactions instead of a hundred 8-byte ones.
 template <typename T>
-__global__ void __launch_bounds__(64) snapshot_kernel(SnapArgs sa, int64_t first, int64_t count, char *area, uint32_t *status, int64_t status_off, int clear) {
-    const int64_t k = blockIdx.x;
-    if (k >= count) return;
+__global__ void __launch_bounds__(64) snapshot_kernel(SnapArgs sa, int64_t first, int64_t count, char *area, uint32_t *status, int64_t status_off, int clear,
+                                                      uint32_t *done, uint32_t seq) {
+  for (int64_t k = blockIdx.x; k < count; k += gridDim.x) {
     const int64_t i = first + k;
     for (int m = 0; m < sa.nmembers; m++) {
         const T *s = (const T *)sa.block[m] + (i / KB_TILE) * ((int64_t)KB_TILE * sa.block_elems[m]) + (i % KB_TILE);
@@ -69,14 +69,22 @@ __global__ void __launch_bounds__(64) snapshot_kernel(SnapArgs sa, int64_t first
         const uint32_t v = clear ? atomicExch(status + i, 0u) : status[i];
         ((uint32_t *)(area + status_off))[k] = v;
     }
+  }
+    if (done) {   // one block (launch_snapshot): everything above is in pinned host memory before the host sees the new sequence number
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
-int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t count, void *area, uint32_t *status, int64_t status_off, int clear) {
+int launch_snapshot(const Batch &b, const SnapArgs &sa, int64_t first, int64_t count, void *area, uint32_t *status, int64_t status_off, int clear,
+                    uint32_t *done, uint32_t seq) {
     if (count <= 0) return KB_OK;
+    const dim3 grid(done ? 1u : (unsigned)count);
     if (b.dtype == KB_F64)
-        hipLaunchKernelGGL(snapshot_kernel<double>, dim3((unsigned)count), dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear);
+        hipLaunchKernelGGL(snapshot_kernel<double>, grid, dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear, done, seq);
     else
-        hipLaunchKernelGGL(snapshot_kernel<float>, dim3((unsigned)count), dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear);
+        hipLaunchKernelGGL(snapshot_kernel<float>, grid, dim3(64), 0, b.stream, sa, first, count, (char *)area, status, status_off, clear, done, seq);
     KB_HIP(hipGetLastError());
     return KB_OK;
 }

@@ -1,10 +1,12 @@
 // Per-call latency of the drop-in path (one filter, host vectors) through the C ABI, without any binding overhead:
 //   kb_update alone; kb_update + kb_get_estimate(state, covariance, status); kb_update + kb_get_estimate(every member);
 //   kb_update + the round-1 pattern of separate kb_get calls.
-// g++ -std=c++17 -O2 -Iinclude scripts/latency_n1.cpp -Lgokalman_amd -lgokalman_amd -Wl,-rpath,$PWD/gokalman_amd -o /tmp/latency_n1
+// hipcc -std=c++17 -O2 -Iinclude scripts/latency_n1.cpp -Lgokalman_amd -lgokalman_amd -Wl,-rpath,$PWD/gokalman_amd -o scripts/latency_n1
 #include <chrono>
 #include <cstdio>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "gokalman_amd.h"
 
@@ -28,6 +30,20 @@ int main() {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
         std::printf("%-70s %7.1f us per call\n", name, us);
     };
+    {   // where the time goes: enqueue cost of the step alone (device-resident y, no wait) and the snapshot alone
+        void *dy = nullptr;
+        hipMalloc(&dy, 64 * p * sizeof(double));
+        hipMemset(dy, 0, 64 * p * sizeof(double));
+        timeit("kb_update_dev x 1 (enqueue only; one kb_synchronize per 5000)", [&] { kb_update_dev(b, dy, 64, nullptr, 0); });
+        kb_synchronize(b);
+        timeit("kb_update_dev + kb_synchronize", [&] { kb_update_dev(b, dy, 64, nullptr, 0); kb_synchronize(b); });
+        timeit("kb_get_estimate(all six members, status) alone", [&] {
+            kb_estimate_view v{}; v.state = xs.data(); v.covariance = Pc.data(); v.pred_covariance = Pp.data(); v.gain = K.data();
+            v.innovation = in.data(); v.measurement = yh.data(); v.status = &st; v.clear_status = 1;
+            kb_get_estimate(b, 0, 1, &v);
+        });
+        hipFree(dy);
+    }
     timeit("kb_update", [&] { kb_update(b, y.data(), p, nullptr, 0); });
     timeit("kb_update + kb_get_estimate(state, covariance, status)", [&] {
         kb_update(b, y.data(), p, nullptr, 0);
