@@ -219,7 +219,7 @@ int kb_set_noise_kind(kb_batch *b, int noise_kind, uint64_t seed) {
 // BatchNoise (noise.go:67-106)
 int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const double *measurement, int nmeas) {
     if (!b || !process || !measurement || nproc < 1 || nmeas < 1) { set_error("bad argument"); return KB_ERR_INVALID; }
-    if (b->kind != KB_VANILLA && b->kind != KB_VANILLA_PREDICT) { set_error("BatchNoise is wired into the Vanilla kinds"); return KB_ERR_UNSUPPORTED; }
+    if (b->kind != KB_VANILLA && b->kind != KB_VANILLA_PREDICT) { set_error("BatchNoise needs a Vanilla filter: its noise matrices are zero (noise.go:88-98), which SquareRoot cannot factorise and Information cannot invert"); return KB_ERR_UNSUPPORTED; }
     int rc = use_device(*b);
     if (rc) return rc;
     const int n = b->n, p = b->p;

@@ -322,3 +322,70 @@ def test_baseline_size_1m_hybrid_ekf_properties():
     tail_P = big.get(k.COVAR, N - small, small)
     assert np.array_equal(tail_P, ref.get(k.COVAR)) and np.array_equal(big.get(k.STATE, N - small, small), ref.get(k.STATE))
     assert np.all(np.isfinite(tail_P)) and np.all(np.diagonal(tail_P, axis1=1, axis2=2) > 0)
+
+
+def test_baseline_size_1m_vanilla_awgn_sampled_oracle_replay():
+    """Config B's size with the reference's usual Noise object (AWGN): 1M filters on the NOISE register kernel, 3 steps.
+    Beyond a full oracle replay, so (a) 200 filters spread over the batch (first / last tile, tile borders) are replayed
+    through the oracle with the device's own draws (kb_noise_sample, keyed by the GLOBAL filter index), (b) every filter is
+    status-clean and finite, (c) identical rows given different filter indices end in DIFFERENT states (independent noise
+    streams) while the covariances -- which the noise vectors never enter (vanilla.go:152, :197-205) -- are bit-equal."""
+    N, small, steps = 1 << 20, 4096, 3
+    base = synth.linear_batch(small, 6, 3, steps)
+    rep = N // small
+    big = {kk: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if kk != "y" else np.tile(v, (1, rep, 1))) for kk, v in base.items()}
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, big["x0"], big["P0"], big["F"], None, big["H"], big["Q"], big["R"], noise=k.NOISE_AWGN, seed=31)
+    for t in range(steps):
+        b.update(big["y"][t], snapshot=False)
+    assert not b.status().any() and b.step() == steps
+    idx = np.unique(np.concatenate([np.arange(0, 70), np.arange(N - 70, N), np.random.default_rng(5).integers(0, N, 60)]))
+    X = np.concatenate([b.get(k.STATE, int(i), 1) for i in idx]); P = np.concatenate([b.get(k.COVAR, int(i), 1) for i in idx])
+    xs, Ps = [], []
+    for i in idx:
+        r = int(i) % small
+        LQ, LR = orc.cholesky_lower(base["Q"][r])[1], orc.cholesky_lower(base["R"][r])[1]
+        f = orc.Filter.ldkf(orc.VANILLA, base["x0"][r], base["P0"][r], base["F"][r], None, base["H"][r], base["Q"][r], base["R"][r])
+        for t in range(steps):
+            draws = [b.noise_sample(int(i), 0, t, w, 6 if w != 1 else 3) for w in range(3)]
+            assert f.update(base["y"][t, r], None, w_pred=LQ @ draws[0], v_meas=LR @ draws[1], w_post=LQ @ draws[2]) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance())
+    assert synth.rel_frobenius(X, np.array(xs)) <= 1e-9 and synth.rel_frobenius(P, np.array(Ps)) <= 1e-9
+    head_x, tail_x = b.get(k.STATE, 0, small), b.get(k.STATE, N - small, small)
+    head_P, tail_P = b.get(k.COVAR, 0, small), b.get(k.COVAR, N - small, small)
+    assert np.isfinite(tail_x).all() and np.isfinite(tail_P).all()
+    assert np.array_equal(head_P, tail_P) and not np.any(np.all(head_x == tail_x, axis=1))
+    # the noise has the right size: (x_noisy - x_noiseless) has per-component spread of the order of sqrt(Q_ii) after 3 steps
+    s = ga.FilterBatch.new_ldkf(k.VANILLA, base["x0"], base["P0"], base["F"], None, base["H"], base["Q"], base["R"])
+    for t in range(steps):
+        s.update(base["y"][t], snapshot=False)
+    dev = tail_x - s.get(k.STATE)
+    ratio = dev.std(axis=0) / np.sqrt(np.diagonal(base["Q"], axis1=1, axis2=2).mean(axis=0))
+    assert np.all(ratio > 0.05) and np.all(ratio < 20.0), ratio
+
+
+def test_baseline_size_1m_vanilla_strict_symcheck_register_kernel():
+    """Config B's size under KB_FLAG_STRICT_SYMCHECK (kb_vanilla_strict.hip): shard invariance against the 4096-filter batch
+    of the same rows, bit for bit, and against the oracle on that small batch at 1e-9; a filter made to trip AsSymDense in the
+    middle of the batch is the only one flagged and keeps its estimate."""
+    N, small, steps = 1 << 20, 4096, 2
+    base = synth.linear_batch(small, 6, 3, steps)
+    rep = N // small
+    big = {kk: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if kk != "y" else np.tile(v, (1, rep, 1))) for kk, v in base.items()}
+    bad = 117 * small + 33
+    p1, p2 = 2.2e20, 5.5e20          # (F P0 F^T)_01 cancels; _01 and _10 keep different multiples of ulp(1e20): tests/test_symcheck_gpu.py
+    Fc = np.eye(6); Fc[:2, :2] = [[0.7, -0.7 * 1.3 * p1 / (0.9 * p2)], [1.3, 0.9]]
+    Hc = np.zeros((3, 6)); Hc[0, 2] = Hc[1, 3] = Hc[2, 4] = 1.0     # measures the well-scaled states only
+    big["F"][bad] = Fc; big["P0"][bad] = np.diag([p1, p2, 1, 1, 1, 1.0]); big["H"][bad] = Hc
+    f = orc.Filter.ldkf(orc.VANILLA, big["x0"][bad], big["P0"][bad], big["F"][bad], None, big["H"][bad], big["Q"][bad], big["R"][bad])
+    assert f.update(big["y"][0, bad]) == orc.ERR_ASYMMETRIC          # the oracle takes AsSymDense's failure branch for it
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, big["x0"], big["P0"], big["F"], None, big["H"], big["Q"], big["R"], flags=k.FLAG_STRICT_SYMCHECK)
+    s = ga.FilterBatch.new_ldkf(k.VANILLA, base["x0"], base["P0"], base["F"], None, base["H"], base["Q"], base["R"], flags=k.FLAG_STRICT_SYMCHECK)
+    b.update(big["y"][0], snapshot=False); s.update(base["y"][0], snapshot=False)
+    st = b.status()
+    assert st[bad] & k.ST_ASYMMETRIC and np.count_nonzero(st) == 1
+    assert np.array_equal(b.get(k.STATE, bad, 1)[0], big["x0"][bad]) and np.array_equal(b.get(k.COVAR, bad, 1)[0], big["P0"][bad])
+    b.update(big["y"][1], snapshot=False); s.update(base["y"][1], snapshot=False)
+    tail_P, tail_x = b.get(k.COVAR, N - small, small), b.get(k.STATE, N - small, small)
+    assert np.array_equal(tail_P, s.get(k.COVAR)) and np.array_equal(tail_x, s.get(k.STATE))
+    xo, Po, _ = orc.ldkf_batch(orc.VANILLA, base["x0"], base["P0"], base["F"], base["H"], base["Q"], base["R"], base["y"][:steps])
+    assert synth.rel_frobenius(tail_x, xo) <= 1e-9 and synth.rel_frobenius(tail_P, Po) <= 1e-9
