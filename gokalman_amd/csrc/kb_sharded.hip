@@ -146,6 +146,13 @@ int on_all(kb_sharded *s, const std::function<int(int)> &fn) {
     return rc;
 }
 
+// reduce_sum / kb_sharded_mc_run touch several devices from the CALLER's thread: its current device is put back on return
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 bool distinct_devices(const kb_sharded *s) {
     for (size_t i = 0; i < s->device.size(); i++)
         for (size_t j = i + 1; j < s->device.size(); j++)
@@ -171,6 +178,7 @@ bool ensure_rccl(kb_sharded *s) {
 // shard), then shard 0's copy goes to the host; or on the host, in shard order.
 int reduce_sum(kb_sharded *s, const std::vector<double *> &d_buf, size_t count, double *host_out) {
     const int G = (int)s->shard.size();
+    const DeviceGuard guard;
     if (ensure_rccl(s)) {
         Rccl &r = Rccl::get();
         int nrc = r.group_start();
@@ -319,6 +327,7 @@ int kb_sharded_mc_run(kb_sharded *s, int steps, const double *controls, int ncon
     if (rc) return rc;
     std::vector<double> tot((size_t)steps * 2 * n), sh((size_t)steps * n);
     if ((rc = reduce_sum(s, folded, tot.size(), tot.data()))) return rc;
+    const DeviceGuard guard;
     KB_HIP(hipSetDevice(s->device[0]));
     KB_HIP(hipMemcpyAsync(sh.data(), shift[0], sh.size() * sizeof(double), hipMemcpyDeviceToHost, s->shard[0]->stream));   // identical on every shard
     KB_HIP(hipStreamSynchronize(s->shard[0]->stream));
