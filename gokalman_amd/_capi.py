@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgokalman_amd.so")
 # enums (kb_kind, kb_dtype, flags, kb_status, status bits, kb_field, kb_noise_kind)
 VANILLA, VANILLA_PREDICT, SQUAREROOT, INFORMATION, SRIF, HYBRID, BATCH_LS = 1, 2, 3, 4, 5, 6, 7
 F64, F32 = 0, 1
-FLAG_FULL_ESTIMATE, FLAG_STRICT_SYMCHECK, FLAG_INFO_FROM_STATE, FLAG_SRIF_NON_TRI_R = 1, 2, 4, 8
+FLAG_FULL_ESTIMATE, FLAG_STRICT_SYMCHECK, FLAG_INFO_FROM_STATE, FLAG_SRIF_NON_TRI_R, FLAG_STATEMENT_KERNELS = 1, 2, 4, 8, 16
 OK, ERR_INVALID, ERR_DIMS, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_LOCKED, ERR_NOT_PD = 0, -1, -2, -3, -4, -5, -6, -7
 ST_SINGULAR, ST_ASYMMETRIC, ST_NONFINITE, ST_INFO_NOT_INVERTIBLE, ST_NYQUIST = 1, 2, 4, 8, 16
 X, P, F, G, H, Q, R = range(7)

@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_r
 }
 
 static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {
+    if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     return a.n == NS && a.p == NM && (!a.snc || a.L.nq <= 3) && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
 }
 
@@ -294,6 +295,7 @@ bool hybrid_reg_ok(const Batch &b, const StepArgs &a) {
 int launch_hybrid(const Batch &b, const StepArgs &a) {
     bool done = false;
     if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a) || hybrid_try<double, 6, 1>(b, a);
+    if (!done && (a.flags & KB_FLAG_STRICT_SYMCHECK) && !(a.flags & KB_FLAG_STATEMENT_KERNELS)) done = launch_hybrid_strict(b, a);   // kb_hybrid_strict.hip
     if (!done) return launch_hybrid_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -356,6 +356,7 @@ static bool info_try_pad(const Batch &b, const StepArgs &a) {
 }
 
 int launch_information(const Batch &b, const StepArgs &a) {
+    if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_information_gen(b, a);
     bool done = false;
     if (b.dtype == KB_F64)
         done = info_try<double, 6, 3>(b, a) || info_try<double, 4, 2>(b, a) ||

@@ -170,6 +170,7 @@ int launch_srif(const Batch &b, const StepArgs &a);
 int launch_hybrid(const Batch &b, const StepArgs &a);
 int launch_batch_ls(const Batch &b, const StepArgs &a);
 bool hybrid_reg_ok(const Batch &b, const StepArgs &a);
+bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_strict.hip: KB_FLAG_STRICT_SYMCHECK on registers (6 / 1..3, fp64)
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip

@@ -307,6 +307,7 @@ static bool sqrt_try_pad(const Batch &b, const StepArgs &a) {
 }
 
 int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
+    if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_squareroot_gen(b, a);
     bool done = false;
     if (b.dtype == KB_F64)
         done = sqrt_try<double, 6, 3>(b, a) || sqrt_try<double, 4, 2>(b, a) ||

@@ -199,11 +199,13 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
 
 // zero-copy Phi / Htilde (kb_prepare_dev) need one of the kernels that read the caller's planar arrays
 bool srif_reg_ok(const Batch &, const StepArgs &a) {
+    if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
     return srif_shape_ok(a, 12, 6) || srif_shape_ok(a, 6, 2);
 }
 
 int launch_srif(const Batch &b, const StepArgs &a) {
+    if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_srif_gen(b, a);
     bool done = false;
     if (!a.predict) done = b.dtype == KB_F32 ? launch_srif_pair_f32(b, a) : launch_srif_pair_f64(b, a);   // kb_srif_pair.h
     else if (b.dtype == KB_F32) done = srif_try_predict<float, 12, 6>(b, a) || srif_try_predict<float, 6, 2>(b, a);

@@ -244,11 +244,12 @@ __global__ void __launch_bounds__(64) vanilla_gen_kernel(const StepArgs a) {
 // ---------------------------------------------------------------------------------
 template <typename T>
 static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
-    const bool special = !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS;
+    const bool reg = !(a.flags & KB_FLAG_STATEMENT_KERNELS);
+    const bool special = reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS;
     bool done = false;
-    if (!(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind != KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
+    if (reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind != KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_noise(b, a) || launch_vanilla_noise_padded(b, a);   // AWGN / BatchNoise on the register kernels
-    if ((a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
+    if (reg && (a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_strict(b, a);
     if (special) {
         done = try_reg<T, 6, 3, 0>(b, a, fused) || try_reg<T, 4, 2, 0>(b, a, fused);

@@ -65,6 +65,7 @@ typedef enum { KB_F64 = 0, KB_F32 = 1 } kb_dtype;
 #define KB_FLAG_FULL_ESTIMATE 0x1u /* materialise every Estimate member each step (P-, K, innovation, yhat); off = state-only outputs (x+, P+) */
 #define KB_FLAG_STRICT_SYMCHECK 0x2u /* compute both triangles and run AsSymDense's |M_ij-M_ji| test (helper.go:75) instead of the non-finite test */
 #define KB_FLAG_INFO_FROM_STATE 0x4u /* KB_INFORMATION: X/P given to kb_set are (x0,P0) as in NewInformationFromState, not (i0,I0) */
+#define KB_FLAG_STATEMENT_KERNELS 0x10u /* run the run-time-dimension, statement-order kernels (csrc/kb_kinds.hip) even where a register kernel exists: the library's own slow GPU reference path, for validation (tests compare the two) */
 #define KB_FLAG_SRIF_NON_TRI_R 0x8u  /* NewSRIF(nonTriR = true) (srif.go:13); both settings run the same arithmetic, see srif.go:121-132 */
 
 typedef enum {

@@ -162,6 +162,27 @@ if "hybrid" in which:
     report("D(ii): Hybrid EKF 6/2 f64 (prepare_dev + update_nl_dev)", N, ms, 1120, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("hybrid", 6, 2))
     del b
 
+if "hstrict" in which:
+    # Hybrid CKF under KB_FLAG_STRICT_SYMCHECK: kb_hybrid_strict.hip (registers) against hybrid_gen_kernel (KB_FLAG_STATEMENT_KERNELS);
+    # the model block is resident (kb_prepare_dev packs Phi / Htilde there for strict batches), bit-identical results
+    N = Nopt or (1 << 20)
+    n, p = 6, 2
+    rng = np.random.default_rng(6)
+    x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10, 10, 10, 1, 1, 1]
+    Phi = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=torch.float64, device="cuda")).contiguous()
+    Ht = torch.randn(p * n, N, dtype=torch.float64, device="cuda")
+    real = torch.randn(p, N, dtype=torch.float64, device="cuda"); comp = real + 1e-2 * torch.randn(p, N, dtype=torch.float64, device="cuda")
+    for nm, fl in (("register kernel", k.FLAG_STRICT_SYMCHECK), ("statement kernel", k.FLAG_STRICT_SYMCHECK | k.FLAG_STATEMENT_KERNELS)):
+        b = ga.FilterBatch(k.HYBRID, n, p, 0, N, flags=fl)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, np.diag([1e-2, 1e-2]), 2, p_rows=p); b.init()
+        def step():
+            k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
+            k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
+        ms = timed(b, step, K=5, warm=2)
+        report("D(ii) strict: Hybrid CKF 6/2 f64, STRICT_SYMCHECK, %s (prepare_dev packs + update_nl_dev)" % nm, N, ms, 1120,
+               {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("hybrid", 6, 2))
+        del b
+
 if "mc" in which:
     s = dict(  # examples/statOD5044/main.go:36-57
         F=np.array([[1, 0.1, 0, 7.726e-2], [4.015e-7, 1, 0, 1.545], [-2.319e-16, -1.732e-9, 1, 0.1], [-6.956e-15, -3.465e-8, 0, 1]]),

@@ -130,7 +130,7 @@ def test_overflowing_covariance_fails_the_step_on_both_kernels_as_in_the_oracle(
 @pytest.mark.parametrize("full", [False, True])
 def test_strict_register_kernel_is_bit_identical_to_the_statement_kernel(n, p, m, full):
     """KB_FLAG_STRICT_SYMCHECK batches up to 6 / 4 / 2 run kb_vanilla_strict.hip (registers, compile-time sizes, zero padding);
-    kb_update_steps_dev still takes vanilla_gen_kernel.  Same operand order, no contraction, same pivots: every bit agrees --
+    KB_FLAG_STATEMENT_KERNELS keeps a batch on vanilla_gen_kernel.  Same operand order, no contraction, same pivots: every bit agrees --
     states, covariances, the FULL outputs and the status words, including filters that fail the symmetry test, singular ones
     and non-finite ones."""
     import torch
@@ -154,14 +154,14 @@ def test_strict_register_kernel_is_bit_identical_to_the_statement_kernel(n, p, m
     flags = k.FLAG_STRICT_SYMCHECK | (k.FLAG_FULL_ESTIMATE if full else 0)
     out = []
     for reg in (True, False):
-        b = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, flags=flags)
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, flags=flags | (0 if reg else k.FLAG_STATEMENT_KERNELS))
         per_step = []
         for t in range(steps):
             up = (u[t].data_ptr(), N) if m else (None, 0)
-            if reg:
+            if reg or t % 2:
                 b.update_dev(y[t].data_ptr(), N, *up)
             else:
-                b.update_steps_dev(y[t].data_ptr(), N, 1, *up)
+                b.update_steps_dev(y[t].data_ptr(), N, 1, *up)   # the fused entry point of a strict batch is the statement kernel too
             b.synchronize()
             fields = [k.STATE, k.COVAR] + ([k.PRED_COVAR, k.GAIN, k.INNOVATION, k.MEASUREMENT] if full else [])
             per_step.append([b.get(f).copy() for f in fields] + [b.status().copy()])
@@ -181,3 +181,53 @@ def test_strict_register_kernel_is_bit_identical_to_the_statement_kernel(n, p, m
     assert st[5] & k.ST_SINGULAR and st[8] != 0
     if n >= 3:
         assert np.count_nonzero(st & k.ST_ASYMMETRIC) >= 20
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("ekf,full", [(False, False), (True, True), (False, True)])
+def test_hybrid_strict_register_kernel_is_bit_identical_to_the_statement_kernel(p, ekf, full):
+    """kb_hybrid_strict.hip against hybrid_gen_kernel (KB_FLAG_STATEMENT_KERNELS) over a sequence that takes every branch:
+    Update, PreparePNT + Update (SNC, q = 3), Predict(), Update -- CKF and EKF, with filters that trip AsSymDense, one singular
+    innovation covariance and one overflow.  Every bit of state, covariance, the FULL members and the status words agrees."""
+    N, n, q = 200, 6, 3
+    rng = np.random.default_rng(40 + 3 * p + ekf)
+    Phi3, P3 = _cancelling_models(N, seed=11)
+    Phi = np.tile(np.eye(n), (N, 1, 1)) + 1e-2 * rng.standard_normal((N, n, n))
+    P0 = np.tile(np.diag([10.0, 10, 10, 1, 1, 1]), (N, 1, 1))
+    Phi[1::3] = np.eye(n); Phi[1::3, :3, :3] = Phi3[1::3]
+    P0[1::3] = np.eye(n); P0[1::3, :3, :3] = P3[1::3]
+    Ht = np.zeros((N, p, n)); Ht[:, :, 2] = 0.3
+    for r in range(p):
+        Ht[:, r, 3 + r] = 1.0
+    R = np.diag([1e-2] * p)
+    Ht[7] = 0.0                                     # with R = 0 below for every filter? no: a zero Htilde row set makes S = R only
+    with np.errstate(over="ignore"):
+        P0[9] = np.full((n, n), 1e308)              # overflows in Phi P Phi^T
+    x0 = rng.standard_normal((N, n))
+    Gam = rng.standard_normal((N, n, q)); Qs = np.diag([1e-6, 2e-6, 3e-6])
+    obs = [(rng.standard_normal((N, p)), rng.standard_normal((N, p))) for _ in range(3)]
+    flags = k.FLAG_STRICT_SYMCHECK | (k.FLAG_FULL_ESTIMATE if full else 0)
+    outs = []
+    for extra in (0, k.FLAG_STATEMENT_KERNELS):
+        b = ga.FilterBatch(k.HYBRID, n, p, q, N, flags=flags | extra)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.set(k.Q, Qs, 2); b.init()
+        if ekf:
+            b.enable_ekf()
+        seq = []
+
+        def grab():
+            fields = [k.STATE, k.COVAR] + ([k.PRED_COVAR, k.GAIN, k.INNOVATION, k.MEASUREMENT] if full else [])
+            seq.append([b.get(f).copy() for f in fields] + [b.status().copy()])
+        b.prepare(Phi, Ht); b.update_nl(*obs[0], snapshot=False); grab()
+        b.prepare(Phi, Ht); b.prepare_pnt(Gam); b.update_nl(*obs[1], snapshot=False); grab()
+        b.prepare(Phi, Ht); b.predict_nl(snapshot=False); grab()
+        b.prepare(Phi, Ht); b.update_nl(*obs[2], snapshot=False); grab()
+        outs.append(seq)
+    for t, (a_, b_) in enumerate(zip(*outs)):
+        assert np.array_equal(a_[-1], b_[-1]), t
+        good = a_[-1] == 0
+        for u_, v_ in zip(a_[:-1], b_[:-1]):
+            assert np.array_equal(u_[good].view(np.uint64), v_[good].view(np.uint64)), t
+        assert np.array_equal(a_[0].view(np.uint64), b_[0].view(np.uint64)) and np.array_equal(a_[1].view(np.uint64), b_[1].view(np.uint64))
+    st = outs[0][0][-1]
+    assert np.count_nonzero(st & k.ST_ASYMMETRIC) >= 20 and st[9] != 0
