@@ -15,6 +15,8 @@
 
 #include <type_traits>
 
+#include "kb_normal.h"
+
 #define KB_TILE 64
 
 namespace kb {
@@ -266,25 +268,21 @@ struct Philox {
     }
 };
 
-// two standard normals from one Philox block (Box-Muller on two 53-bit... here 32-bit uniforms each
-// widened to (0,1] doubles with 32 bits of resolution per uniform; two u32 per uniform -> 53 bits)
+// two standard normals from one Philox block: Box-Muller on two 53-bit uniforms (two u32 each), u1 in (0, 1], u2 in [0, 1).
+// The logarithm and the sine / cosine are kb_normal.h's (~75 instructions together where log + sincospi of the math library take
+// ~160), written with explicit FMAs only, so kb_noise_sample on the host and the kernels produce the SAME BITS (sqrt and the
+// conversions are correctly rounded on both sides).
 __host__ __device__ inline void box_muller(const uint32_t (&r)[4], double &z0, double &z1) {
     const double two53 = 1.0 / 9007199254740992.0;
     const uint64_t a = (((uint64_t)r[0] << 32) | r[1]) >> 11;
     const uint64_t b = (((uint64_t)r[2] << 32) | r[3]) >> 11;
     const double u1 = ((double)a + 1.0) * two53;  // (0,1]
     const double u2 = (double)b * two53;          // [0,1)
-    const double rad = sqrt(-2.0 * log(u1));
-#if defined(__HIP_DEVICE_COMPILE__)
+    const double rad = sqrt(neg2log(u1));
     double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);   // exact argument reduction, no large-argument path: 20 % faster Monte-Carlo steps than cos / sin of 2 pi u
+    sincos2pi(u2, sn, cs);
     z0 = rad * cs;
     z1 = rad * sn;
-#else   // host replay (kb_noise_draw): agrees with the device to an ulp of the angle
-    const double ang = 6.283185307179586476925286766559 * u2;
-    z0 = rad * cos(ang);
-    z1 = rad * sin(ang);
-#endif
 }
 
 // standard normal number `k` (k = 0,1,2,...) of the vector drawn by filter `filter` at (step, stream)

@@ -271,3 +271,22 @@ def test_vanilla_noise_register_kernel_is_the_one_that_runs():
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     assert not np.array_equal(runs[0][1], runs[2][1])                      # another kernel ...
     assert synth.rel_frobenius(runs[0][0], runs[2][0]) <= 1e-12 and synth.rel_frobenius(runs[0][1], runs[2][1]) <= 1e-12   # ... same filter
+
+
+def test_device_normals_are_bit_identical_to_the_host_replay():
+    """The normals a kernel draws and the ones kb_noise_sample replays on the host come from the same arithmetic
+    (csrc/kb_normal.h: explicit FMAs, correctly rounded division and sqrt): with F = 0, x0 = 0 and Q = I the pure predictor's
+    x- IS the process draw of the step (vanilla.go:146 with chol(I) = I), so the device's bits can be read off and compared."""
+    N, n, p, steps = 4096 + 5, 6, 3, 3
+    Z = np.zeros
+    H = np.tile(np.eye(p, n), (N, 1, 1))
+    b = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, Z((N, n)), np.tile(np.eye(n), (N, 1, 1)), Z((N, n, n)), None, H,
+                                np.tile(np.eye(n), (N, 1, 1)), np.tile(np.eye(p), (N, 1, 1)), noise=k.NOISE_AWGN, seed=20161103)
+    for t in range(steps):
+        b.update(Z((N, p)), snapshot=False)
+        X = b.get(k.STATE)
+        for i in list(range(0, N, 97)) + [N - 1]:
+            want = b.noise_sample(i, 0, t, 0, n)
+            assert np.array_equal(X[i].view(np.uint64), want.view(np.uint64)), (t, i, X[i], want)
+    # and they are standard normals: mean 0, variance 1 over 6 x 4101 draws of the last step
+    assert abs(X.mean()) < 0.03 and abs(X.var() - 1.0) < 0.05 and np.abs(X).max() < 6.5
