@@ -28,6 +28,9 @@ run chisq_plain   python3 scripts/bench_chisq.py
 run chisq_sq      rocprofv3 --pmc $SQ --output-format csv -d $OUT/chisq_sq -- python3 scripts/bench_chisq.py
 hipcc --offload-arch=gfx950 -O3 scripts/diag_stream.hip -o /tmp/diag_stream 2> /dev/null && /tmp/diag_stream > $OUT/diag_stream.out 2>&1
 hipcc --offload-arch=gfx950 -O3 scripts/diag_lanepair.hip -o /tmp/diag_lanepair 2> /dev/null && /tmp/diag_lanepair > $OUT/diag_lanepair.out 2>&1
+hipcc --offload-arch=gfx950 -O3 scripts/diag_lanequad.hip -o /tmp/diag_lanequad 2> /dev/null && /tmp/diag_lanequad > $OUT/diag_lanequad.out 2>&1
+hipcc --offload-arch=gfx950 -O2 scripts/diag_launch_latency.hip -o /tmp/diag_launch_latency 2> /dev/null && timeout 120 /tmp/diag_launch_latency > $OUT/diag_launch_latency.out 2>&1
+hipcc -std=c++17 -O2 -Iinclude scripts/latency_n1.cpp -Lgokalman_amd -lgokalman_amd -Wl,-rpath,$ROOT/gokalman_amd -o /tmp/latency_n1 2> /dev/null && timeout 200 /tmp/latency_n1 > $OUT/latency_n1.out 2>&1
 find $OUT -name "*.csv" | wc -l
 # keep what travels back small: the per-dispatch CSVs are condensed on the box
 python3 scripts/summarise_round.py $TAG --condense

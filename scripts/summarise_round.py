@@ -69,11 +69,12 @@ def main():
         head = json.load(open(os.path.join(DST, "summary.json")))["head"]
     except Exception:
         pass
-    for name in ("bench_plain", "bench_stats", "kinds_plain", "chisq_plain", "diag_stream", "diag_lanepair"):
+    for name in ("bench_plain", "bench_stats", "kinds_plain", "chisq_plain", "diag_stream", "diag_lanepair", "diag_lanequad", "diag_launch_latency", "latency_n1"):
         p = os.path.join(SRC, name + ".out")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(DST, {"bench_plain": "bench.json", "bench_stats": "bench_under_rocprof.json", "kinds_plain": "bench_kinds.jsonl",
-                                             "chisq_plain": "bench_chisq.json", "diag_stream": "diag_stream.txt", "diag_lanepair": "diag_lanepair.txt"}[name]))
+                                             "chisq_plain": "bench_chisq.json", "diag_stream": "diag_stream.txt", "diag_lanepair": "diag_lanepair.txt",
+                                             "diag_lanequad": "diag_lanequad.txt", "diag_launch_latency": "diag_launch_latency.txt", "latency_n1": "latency_n1.txt"}[name]))
     md = ["# rocprofv3 summary %s (head %s)\n" % (tag, head),
           "Collected by `scripts/profile_round.sh %s` on one MI355X through gpurun; every `--pmc` pass is a separate run.\n" % tag]
     # ---- kernel stats
