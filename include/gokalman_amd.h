@@ -275,7 +275,9 @@ int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const doub
 /* The standard normals z behind the AWGN draw of the filter with global index `filter` at
  * (epoch, step, which); the noise vector is chol_L(Q) z (which 0, 2; n values) or
  * chol_L(R) z (which 1; p values).  For tests that replay the device's samples through the
- * oracle.  which: 0 = Process (first call), 1 = Measurement, 2 = Process (second call). */
+ * oracle.  which: 0 = Process (first call), 1 = Measurement, 2 = Process (second call).  The values are the device's bit
+ * for bit: Philox4x32-10 and a Box-Muller transform whose logarithm / sine / cosine (csrc/kb_normal.h) use only operations that
+ * round identically on the host and on the GPU. */
 int kb_noise_sample(kb_batch *b, int64_t filter, int64_t epoch, int64_t step, int which, double *out);
 /* The same generator as a pure host function (no handle, no device): standard normal number k of
  * the vector drawn by global filter index `filter` at (epoch, step, which) under `seed`. */
