@@ -586,7 +586,19 @@ static int update_dev_common(kb_batch *b, const void *meas, int64_t ld_meas, con
     a.nsteps = nsteps;
     a.y = meas; a.y_es = ld_meas; a.y_ts = KB_TILE; a.y_step = (int64_t)b->p * ld_meas;
     if (b->need_ctrl) { a.u = ctrl; a.u_es = ld_ctrl; a.u_ts = KB_TILE; a.u_step = (int64_t)b->m * ld_ctrl; }
-    if ((rc = launch_step(*b, a, fused))) return rc;
+    const bool vanilla = b->kind == KB_VANILLA || b->kind == KB_VANILLA_PREDICT;
+    if (fused && !(b->flags & KB_FLAG_STATEMENT_KERNELS) && !(vanilla && vanilla_fused_ok(*b, a))) {
+        // no time-fused register kernel for this kind / shape / noise: one single-step launch per step, back to back on the stream
+        // (the multi-step statement kernel is 16-30x slower than that)
+        for (int t = 0; t < nsteps; t++) {
+            StepArgs s = a;
+            s.nsteps = 1;
+            s.step0 = a.step0 + t;
+            s.y = meas ? (const char *)meas + (size_t)t * (size_t)a.y_step * b->esize() : nullptr;
+            if (b->need_ctrl) s.u = (const char *)ctrl + (size_t)t * (size_t)a.u_step * b->esize();
+            if ((rc = launch_step(*b, s, false))) return rc;
+        }
+    } else if ((rc = launch_step(*b, a, fused))) return rc;
     b->step += nsteps;
     b->calls++;
     return KB_OK;

@@ -151,6 +151,7 @@ int launch_traj_unpack(const Batch &b, int64_t first, int64_t count, double *d_s
 
 // kb_vanilla.hip
 int launch_vanilla(const Batch &b, const StepArgs &a, bool fused);
+bool vanilla_fused_ok(const Batch &b, const StepArgs &a);   // a time-fused register kernel exists for this batch
 // kb_getters.hip (materialise State/Covariance for the kinds with a lazy getter)
 int launch_materialise(const Batch &b, const void *state_block, bool pred, void *out_block /* x[n] | P packed */);
 int launch_within_nsigma(const Batch &b, const void *xp_block, double nsigma, uint8_t *d_out);

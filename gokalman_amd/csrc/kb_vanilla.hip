@@ -268,6 +268,15 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
     return KB_OK;
 }
 
+// Is there a time-fused register kernel (state carried in registers over a.nsteps steps) for this batch?  Only the benchmark
+// shapes have one (try_reg<.., WITH_FUSED>); for everything else kb_update_steps_dev enqueues one single-step register launch
+// per step (kb_api.hip) rather than dropping to the multi-step statement kernel.
+bool vanilla_fused_ok(const Batch &, const StepArgs &a) {
+    if (a.flags & (KB_FLAG_STRICT_SYMCHECK | KB_FLAG_STATEMENT_KERNELS)) return false;
+    if (a.noise_kind != KB_NOISE_NOISELESS || (a.need_ctrl ? a.m : 0) != 0) return false;
+    return (a.n == 6 && a.p == 3) || (a.n == 4 && a.p == 2);
+}
+
 int launch_vanilla(const Batch &b, const StepArgs &a, bool fused) {
     if (b.dtype == KB_F64) return launch_vanilla_t<double>(b, a, fused);
     return launch_vanilla_t<float>(b, a, fused);

@@ -170,7 +170,9 @@ int kb_update_dev(kb_batch *b, const void *meas, int64_t ld_meas,
                   const void *ctrl, int64_t ld_ctrl);
 /* The caller loop `for k { kf.Update(y_k, u_k) }` fused into one launch:
  * meas is planar [T][p][ld] on the device (step t at meas + t*p*ld elements).
- * x, P and the model stay in registers across the T steps. */
+ * x, P and the model stay in registers across the T steps where a time-fused register kernel exists (Noiseless Vanilla 6/3
+ * and 4/2 without control input); every other kind / shape / noise runs its single-step register kernel T times, back to back
+ * on the stream, from this one call. */
 int kb_update_steps_dev(kb_batch *b, const void *meas, int64_t ld_meas,
                         const void *ctrl, int64_t ld_ctrl, int nsteps);
 

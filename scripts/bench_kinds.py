@@ -87,16 +87,18 @@ if "vbase" in which:   # the headline configuration (bench.py times it too): her
     del b
 
 if "vstrict" in which:
-    # KB_FLAG_STRICT_SYMCHECK: kb_vanilla_strict.hip (registers) through kb_update_dev, vanilla_gen_kernel (scratch arrays) through
-    # kb_update_steps_dev(.., 1) -- bit-identical results (tests/test_symcheck_gpu.py), so the pair times the register kernel's gain
+    # KB_FLAG_STRICT_SYMCHECK: kb_vanilla_strict.hip (registers) against vanilla_gen_kernel (scratch arrays; KB_FLAG_STATEMENT_KERNELS)
+    # -- bit-identical results (tests/test_symcheck_gpu.py), so the pair times the register kernel's gain
     N = Nopt or (1 << 20)
     d = synth.linear_batch(N, 6, 3, 1)
     y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
     b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_STRICT_SYMCHECK)
     ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
     report("B strict: Vanilla 6/3 f64, STRICT_SYMCHECK, register kernel", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("vanilla", 6, 3))
-    ms = timed(b, lambda: b.update_steps_dev(y[0].data_ptr(), N, 1), K=5, warm=1)
-    report("B strict: Vanilla 6/3 f64, STRICT_SYMCHECK, statement kernel (kb_update_steps_dev)", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("vanilla", 6, 3))
+    del b
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_STRICT_SYMCHECK | k.FLAG_STATEMENT_KERNELS)
+    ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N), K=5, warm=1)
+    report("B strict: Vanilla 6/3 f64, STRICT_SYMCHECK, statement kernel (KB_FLAG_STATEMENT_KERNELS)", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("vanilla", 6, 3))
     del b
 
 if "vnoise" in which:

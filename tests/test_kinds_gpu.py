@@ -590,3 +590,35 @@ def test_information_full_estimate_on_the_register_kernels(n, p, m, awgn, from_s
                 assert np.linalg.norm(Pp - Po) <= max(1e-9, 1e-14 * cond) * np.linalg.norm(Po), (i, t, cond)
         cond = np.linalg.cond(f.raw_mat())
         assert synth.rel_frobenius(ests[-1].state()[i], f.state()) <= max(1e-9, 1e-14 * cond), (i, cond)
+
+
+@pytest.mark.parametrize("kind,flags,n,p,noise", [(k.SQUAREROOT, 0, 6, 3, k.NOISE_NOISELESS), (k.INFORMATION, k.FLAG_INFO_FROM_STATE, 6, 3, k.NOISE_NOISELESS),
+                                                 (k.VANILLA, 0, 5, 2, k.NOISE_NOISELESS), (k.VANILLA, 0, 6, 3, k.NOISE_AWGN),
+                                                 (k.VANILLA, k.FLAG_STRICT_SYMCHECK, 6, 3, k.NOISE_NOISELESS), (k.SQUAREROOT, 0, 4, 2, k.NOISE_AWGN)])
+def test_update_steps_dev_without_a_fused_kernel_runs_the_register_kernel_per_step(kind, flags, n, p, noise):
+    """kb_update_steps_dev(T steps) on a kind / shape / noise that has no time-fused register kernel enqueues T single-step
+    register launches (kb_api.hip update_dev_common) instead of the multi-step statement kernel: bit-identical to T calls of
+    kb_update_dev, kf.step advanced by T, and (Noiseless) the oracle's numbers."""
+    import torch
+    N, steps = 1000, 6
+    d = synth.linear_batch(N, 6, 3, steps, seed=77)
+    sl = {kk: v[:, :n, :n] for kk, v in d.items() if kk in ("F", "P0", "Q")}
+    x0, H, R = d["x0"][:, :n], d["H"][:, :p, :n], d["R"][:, :p, :p]
+    y = torch.from_numpy(np.ascontiguousarray(d["y"][:, :, :p].transpose(0, 2, 1))).cuda()     # [T][p][N]
+    res = []
+    for fused in (True, False):
+        b = ga.FilterBatch.new_ldkf(kind, x0, sl["P0"], sl["F"], None, H, sl["Q"], R, flags=flags, noise=noise, seed=5)
+        if fused:
+            b.update_steps_dev(y.data_ptr(), N, steps)
+        else:
+            for t in range(steps):
+                b.update_dev(y[t].data_ptr(), N)
+        b.synchronize()
+        assert b.step() == steps and not b.status().any()
+        res.append((b.get(k.STATE), b.get(k.COVAR)))
+    assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
+    assert np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
+    if noise == k.NOISE_NOISELESS:
+        okind = {k.SQUAREROOT: orc.SQUAREROOT, k.INFORMATION: orc.INFORMATION, k.VANILLA: orc.VANILLA}[kind]
+        xo, Po, _ = orc.ldkf_batch(okind, x0[:64], sl["P0"][:64], sl["F"][:64], H[:64], sl["Q"][:64], R[:64], d["y"][:, :64, :p])
+        assert synth.rel_frobenius(res[0][0][:64], xo) <= 1e-9 and synth.rel_frobenius(res[0][1][:64], Po) <= 1e-9
