@@ -63,7 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--filters", type=int, default=1 << 20, help="filters per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused-steps", type=int, default=16, help="T of the extra time-fused measurement (0 = skip)")
+    ap.add_argument("--fused-steps", type=int, default=100, help="T of the extra time-fused measurement (0 = skip); SURVEY 8d's T = 100 "
+                    "steps per repetition: the per-launch load / store of state and model is amortised over T steps (T = 16: 12.5 G steps/s, T = 100: 20 G)")
     ap.add_argument("--ooc-filters", type=int, default=1 << 22,
                     help="filters of the out-of-Infinity-Cache measurement of the same kernel (0 = skip)")
     ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")

@@ -133,7 +133,13 @@ def main():
     named = {}
     for kn, v in valu.items():
         if "vanilla_reg_kernel<double, 6, 3, 0, false, false, true" in kn:
-            named["vanilla_fused"] = dict(v, kernel=kn, steps_per_launch=16, valu_insts_per_wave_per_step=v["valu_insts_per_wave"] / 16.0)
+            T = 16   # bench.py's --fused-steps of that round (r03b and earlier: 16)
+            try:
+                bj = [json.loads(l) for l in open(os.path.join(DST, "bench_under_rocprof.json")) if l.startswith("{")][-1]
+                T = int(bj["fused"]["steps_per_launch"])
+            except Exception:
+                pass
+            named["vanilla_fused"] = dict(v, kernel=kn, steps_per_launch=T, valu_insts_per_wave_per_step=v["valu_insts_per_wave"] / float(T))
         if "mc_kernel<double, 4, 2" in kn:
             named["mc"] = dict(v, kernel=kn, steps_per_launch=1086)
         if "chisq_kernel" in kn:
