@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")
     ap.add_argument("--mc-steps", type=int, default=1086)
     ap.add_argument("--hybrid-filters", type=int, default=1 << 20, help="Hybrid EKF filters per GPU for extra.hybrid_ekf (0 = skip)")
+    ap.add_argument("--shared-filters", type=int, default=1 << 20, help="Vanilla 6/3 filters per GPU sharing one model for extra.shared_model (0 = skip)")
     ap.add_argument("--sqrt-filters", type=int, default=1 << 20, help="SquareRoot 6/3 filters per GPU for extra.squareroot, config C (0 = skip)")
     ap.add_argument("--srif-filters", type=int, default=1 << 18, help="SRIF 12/6 fp32 filters per GPU for extra.srif_fp32, config E (0 = skip)")
     ap.add_argument("--repeat", type=int, default=5, help="timed blocks of --steps steps (the first one is the contract's `value`)")
@@ -485,6 +486,24 @@ def main():
                                                            *rl.load_traffic(ROOT, "squareroot_reg_kernel<double, 6, 3, 0, false")),
                                "filters_with_error_status": qbad}
         del sq, yq
+    if args.shared_filters > 0:
+        # one model for the whole batch (the reference's own shape of use: ONE filter object; kb_replicate / BatchLDKF / the ensembles):
+        # the kernels read tile 0's model block out of the L2 and only state + measurements move -- NOT the headline config, whose
+        # models are per filter
+        M = args.shared_filters
+        dq = synth.linear_batch(M, n, p, 1, seed=synth.SEED + 2000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)  # [p][M]
+        sh = ga.FilterBatch.new_ldkf(k.VANILLA, dq["x0"], dq["P0"], dq["F"][0], None, dq["H"][0], dq["Q"][0], dq["R"][0], nfilters=M, device=local_rank)
+        K5 = 50
+        h_s, hms, hbad = timed_leg(sh, lambda: sh.update_dev(yq.data_ptr(), M), K5)
+        moved = 8 * (2 * (n + rl.tri(n)) + p)
+        extra["shared_model"] = {"config": "%d Vanilla 6/3 fp64 filters per GPU sharing ONE model (F, H, Q, R uploaded with broadcast = 1)" % M,
+                                 "filters_total": world * M, "steps": K5, "value": world * M * K5 / h_s,
+                                 "unit": "filter-update steps/s (whole job)", "kernel_ms": hms,
+                                 "roofline": rl.hbm_roofline(hms, M, rl.algorithmic_bytes("vanilla", n, p), moved),
+                                 "filters_with_error_status": hbad,
+                                 "note": "the model block (672 B) is read from the L2 by every wave; moved bytes = x, P read and written + y"}
+        del sh, yq
     if args.srif_filters > 0:
         M = args.srif_filters
         sn, sp = 12, 6

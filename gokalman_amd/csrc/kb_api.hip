@@ -226,6 +226,7 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     memset(&a, 0, sizeof(a));
     a.state = b.d_state; a.est = b.d_est; a.model = b.d_model; a.status = b.d_status; a.lag = b.d_lag;
     a.N = b.N; a.ntiles = b.ntiles; a.nsteps = 1;
+    a.mo_ts = b.per_filter_model ? (int64_t)KB_TILE * b.L.mo_elems : 0;
     a.stream_state = b.block_bytes(b.L.st_elems) > KB_MALL_BYTES ? 1 : 0;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p; a.srif_tri = b.srif_tri;
@@ -407,6 +408,9 @@ int kb_set(kb_batch *b, int field, const double *host, int64_t count, int broadc
     if ((rc = ensure_stage(*b, bytes))) return rc;
     KB_HIP(hipMemcpyAsync(b->d_stage, host, bytes, hipMemcpyHostToDevice, b->stream));
     if ((rc = launch_pack(*b, b->d_stage, t.src_elems, count, broadcast != 0, t.block, t.block_elems, t.map))) return rc;
+    if (t.block == b->d_model && field >= 0 && field < 32) {   // does every filter still have the same model? (StepArgs::mo_ts)
+        if (broadcast) b->per_filter_model &= ~(1u << field); else b->per_filter_model |= 1u << field;
+    }
     if ((rc = after_set(b, field, p_rows, host, count * t.src_elems))) { (void)hipStreamSynchronize(b->stream); return rc; }
     KB_HIP(hipStreamSynchronize(b->stream));
     return KB_OK;
@@ -435,6 +439,7 @@ int kb_set_dev(kb_batch *b, int field, const void *src, int64_t ld, int p_rows) 
         hipLaunchKernelGGL(pack_planar_kernel<float>, dim3(blocks), dim3(256), 0, b->stream, (const float *)src, ld,
                            t.src_elems, b->N, (float *)t.block, t.block_elems, (const int16_t *)b->d_stage);
     KB_HIP(hipGetLastError());
+    if (t.block == b->d_model && field >= 0 && field < 32) b->per_filter_model |= 1u << field;   // per-filter by construction (StepArgs::mo_ts)
     if (field == KB_G && !b->initialized) b->need_ctrl = 1;  // device-side G: assumed non-nil
     if ((rc = after_set(b, field, p_rows, nullptr, 0))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));  // the map buffer may be reused by the next call

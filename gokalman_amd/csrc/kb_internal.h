@@ -54,6 +54,7 @@ struct Batch {
     void *d_y = nullptr, *d_u = nullptr;  // AoSoA staging of host measurements / controls
     // Batches of at most one tile (the reference's own use: one filter) skip the staging copies: the host writes / reads a
     // pinned, device-mapped buffer the kernels access directly (3 input tiles + one read-back area).
+    unsigned per_filter_model = 0;   // bit f set: model field f (KB_F .. ) was last uploaded per filter; 0 = one model for the whole batch
     void *h_pin = nullptr, *d_pin = nullptr;
     uint32_t pin_seq = 0;   // sequence number of the last flagged snapshot (the word at KB_PIN_FLAG_OFF of the pinned block)
     void *d_y2 = nullptr;
@@ -103,6 +104,8 @@ struct StepArgs {
     void *state, *est, *model;
     uint32_t *status;
     uint32_t *lag;                               // per-filter failed-step count (Batch::d_lag)
+    int64_t mo_ts;   // elements between the model blocks of consecutive tiles: 64 * L.mo_elems, or 0 when every filter has the SAME model
+                     // (all model fields uploaded with broadcast = 1: every wave reads tile 0's block, which stays in the L2)
     const void *y; int64_t y_es, y_ts, y_step;   // element stride, tile stride, step stride (elements)
     const void *y2; int64_t y2_es, y2_ts;        // NLDKF: computed observation
     const void *u; int64_t u_es, u_ts, u_step;

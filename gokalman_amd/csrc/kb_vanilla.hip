@@ -247,11 +247,13 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
     const bool reg = !(a.flags & KB_FLAG_STATEMENT_KERNELS);
     const bool special = reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS;
     bool done = false;
-    if (reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind != KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
+    if (reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.mo_ts == 0 && b.dtype == KB_F64 && !fused && a.nsteps == 1)
+        done = launch_vanilla_shared(b, a);   // one model for the whole batch: kb_vanilla_shared.hip
+    if (!done && reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind != KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_noise(b, a) || launch_vanilla_noise_padded(b, a);   // AWGN / BatchNoise on the register kernels
     if (reg && (a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_strict(b, a);
-    if (special) {
+    if (special && !done) {
         done = try_reg<T, 6, 3, 0>(b, a, fused) || try_reg<T, 4, 2, 0>(b, a, fused);
         if (!done && b.dtype == KB_F64) done = launch_vanilla_extra_shapes(b, a, fused);
         if (!done && b.dtype == KB_F64 && !fused) done = launch_vanilla_padded(b, a) || launch_vanilla_padded8(b, a);

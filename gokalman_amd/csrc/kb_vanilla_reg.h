@@ -40,6 +40,14 @@ __device__ __forceinline__ void stt(const TilePtr<T> &p, int e, T v) { p.st(e, v
 // MI355X with the arithmetic removed: 0.208 ms -> 0.153 ms per 1M-filter step.
 template <typename T>
 __device__ __forceinline__ T ldnt(const TilePtr<const T> &p, int e) { return p.ldnt(e); }
+// Model operand of a kernel instantiated for SHARED batches (ONE model for every filter: StepArgs::mo_ts == 0, every wave reads
+// tile 0's block): a plain load, so that the 43 KB block stays in the L2 -- the streaming hint makes every wave fetch it again
+// through the fabric (137 us against 105 us per 1M-filter step; per-filter models: 166 us)
+template <bool SHARED, typename T>
+__device__ __forceinline__ T ldm(const TilePtr<const T> &p, int e) {
+    if constexpr (SHARED) return p.ld(e);
+    else return p.ldnt(e);
+}
 template <typename T>
 __device__ __forceinline__ T ldnt_at(const T *p) { return __builtin_nontemporal_load(p); }
 // write-once Estimate extras (P-, K, innovation, yhat) are stored non-temporally for the same reason
@@ -121,7 +129,7 @@ __device__ __forceinline__ void tri_times(const T (&L)[tri(NV)], const T (&z)[NV
     }
 }
 
-template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false, bool NOISE = false>
+template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false, bool NOISE = false, bool SHARED = false>
 __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(T) * (NS * NS + NS * NM) > 8 * 56)) ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
     static_assert(!(NOISE && FUSED), "the time-fused variant is Noiseless");
     constexpr int TR = tri(NS);
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
     const bool active = tile * KB_TILE + lane < a.N;
 
     const TilePtr<T> st{(T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))), lane};
-    const TilePtr<const T> mo{(const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems), lane};
+    const TilePtr<const T> mo{(const T *)a.model + tile * a.mo_ts, lane};
     const TilePtr<const T> moF = mo.field(a.L.mo_F), moH = mo.field(a.L.mo_H), moQ = mo.field(a.L.mo_Q), moR = mo.field(a.L.mo_R),
                            moG = mo.field(a.L.mo_G);
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
@@ -144,7 +152,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(moF, i * rn + j) : T(0);
+        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldm<SHARED>(moF, i * rn + j) : T(0);
     // Issue order is pinned with scheduling barriers, and it is "slowest first": the model and the measurement are HBM
     // streams (non-temporal), x and P are Infinity-Cache hits.  With F, Q, H, R, y requested before x and P every HBM request
     // of the wave is in flight as early as possible and the cache hits arrive right behind them: 163.5 us per 1M-filter step
@@ -154,20 +162,20 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
     for (int j = 0; j < NS; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) Q[symi(i, j)] = (j < rn) ? ldnt(moQ, symi(i, j)) : T(0);
+        for (int i = 0; i <= j; i++) Q[symi(i, j)] = (j < rn) ? ldm<SHARED>(moQ, symi(i, j)) : T(0);
 #pragma unroll
     for (int r = 0; r < NM; r++)
 #pragma unroll
-        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldnt(moH, r * rn + l) : T(0);
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldm<SHARED>(moH, r * rn + l) : T(0);
 #pragma unroll
     for (int c = 0; c < NM; c++)
 #pragma unroll
-        for (int r = 0; r <= c; r++) R[symi(r, c)] = (c < rp) ? ldnt(moR, symi(r, c)) : (r == c ? T(1) : T(0));
+        for (int r = 0; r <= c; r++) R[symi(r, c)] = (c < rp) ? ldm<SHARED>(moR, symi(r, c)) : (r == c ? T(1) : T(0));
     if constexpr (NC > 0) {
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
-            for (int c = 0; c < NC; c++) G[i * NC + c] = (i < rn && c < rm) ? ldnt(moG, i * rm + c) : T(0);
+            for (int c = 0; c < NC; c++) G[i * NC + c] = (i < rn && c < rm) ? ldm<SHARED>(moG, i * rm + c) : T(0);
     }
     if constexpr (!PREDICT) {
 #pragma unroll
@@ -500,15 +508,16 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
     if (active && err_acc) fail_step(a, tile * KB_TILE + lane, err_acc, nfail);
 }
 
-template <typename T, int NS, int NM, int NC, bool WITH_FUSED = true, bool NOISE = false>
+template <typename T, int NS, int NM, int NC, bool WITH_FUSED = true, bool NOISE = false, bool SHARED = false>
 static inline bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
     if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC) return false;
+    if (SHARED && a.mo_ts != 0) return false;   // (the other instantiations are correct for shared batches too, only slower)
     if (fused && !WITH_FUSED) return false;
     if ((a.noise_kind != KB_NOISE_NOISELESS) != NOISE) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
 #define KB_GO(FULL_, PRED_, FUSED_) \
-    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_, false, NOISE>), grid, block, 0, b.stream, a)
+    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_, false, NOISE, SHARED>), grid, block, 0, b.stream, a)
     if constexpr (WITH_FUSED) {
         if (fused) {
             if (a.predict) { if (full) KB_GO(true, true, true); else KB_GO(false, true, true); }
@@ -523,14 +532,15 @@ static inline bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
 }
 
 // Padded launch: any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input), one step per launch.
-template <typename T, int NS, int NM, int NC, bool NOISE = false>
+template <typename T, int NS, int NM, int NC, bool NOISE = false, bool SHARED = false>
 static inline bool try_pad(const Batch &b, const StepArgs &a) {
     const int m = a.need_ctrl ? a.m : 0;
     if (a.n > NS || a.p > NM || m > NC || (NC == 0) != (m == 0)) return false;
+    if (SHARED && a.mo_ts != 0) return false;   // (the other instantiations are correct for shared batches too, only slower)
     if ((a.noise_kind != KB_NOISE_NOISELESS) != NOISE) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
-#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true, NOISE>), grid, block, 0, b.stream, a)
+#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true, NOISE, SHARED>), grid, block, 0, b.stream, a)
     if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
     else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
 #undef KB_GO
@@ -546,5 +556,8 @@ bool launch_vanilla_noise(const Batch &b, const StepArgs &a);
 bool launch_vanilla_noise_padded(const Batch &b, const StepArgs &a);
 // KB_FLAG_STRICT_SYMCHECK batches (kb_vanilla_strict.hip): both triangles, AsSymDense's test, the oracle's rounding; n <= 6, p <= 4, m <= 2
 bool launch_vanilla_strict(const Batch &b, const StepArgs &a);
+// batches whose filters all share ONE model (StepArgs::mo_ts == 0), fp64, one step per launch (kb_vanilla_shared.hip): the SHARED
+// instantiations (model read with the default cache policy) of the exact and padded kernels, Noiseless and AWGN / BatchNoise
+bool launch_vanilla_shared(const Batch &b, const StepArgs &a);
 
 }  // namespace kb

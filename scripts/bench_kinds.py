@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vfull", "vbase", "vnoise", "vstrict", "sqrt", "info", "srif", "hybrid", "hstrict", "mc"]
+which = args or ["vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "srif", "hybrid", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -99,6 +99,18 @@ if "vstrict" in which:
     b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_STRICT_SYMCHECK | k.FLAG_STATEMENT_KERNELS)
     ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N), K=5, warm=1)
     report("B strict: Vanilla 6/3 f64, STRICT_SYMCHECK, statement kernel (KB_FLAG_STATEMENT_KERNELS)", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("vanilla", 6, 3))
+    del b
+
+if "vshared" in which:
+    # ONE model for the whole batch (every model field uploaded with broadcast = 1: the reference's own use -- one filter object, many
+    # runs / targets): the kernels read tile 0's model block, which stays in the L2, so only state and measurements move
+    N = Nopt or (1 << 20)
+    d = synth.linear_batch(N, 6, 3, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"][0], None, d["H"][0], d["Q"][0], d["R"][0], nfilters=N)
+    ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+    sb = 8 * (6 + 21 + 3 + 6 + 21)   # x, P read; y read; x, P written
+    report("B shared model: Vanilla 6/3 f64, one F / H / Q / R for all filters", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=sb)
     del b
 
 if "vnoise" in which:

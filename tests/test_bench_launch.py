@@ -44,7 +44,7 @@ def test_world_size_mismatch_is_refused():
 
 
 SMALL = ["--steps", "30", "--warmup", "5", "--filters", "65536", "--fused-steps", "0", "--ooc-filters", "0",
-         "--mc-runs", "16384", "--mc-steps", "64", "--hybrid-filters", "16384", "--sqrt-filters", "16384", "--srif-filters", "8192",
+         "--mc-runs", "16384", "--mc-steps", "64", "--hybrid-filters", "16384", "--sqrt-filters", "16384", "--srif-filters", "8192", "--shared-filters", "16384",
          "--no-cpu-baseline"]
 
 
@@ -70,6 +70,7 @@ def test_two_ranks_self_launched_over_gloo_on_one_gpu():
     assert two["extra"]["hybrid_ekf"]["filters_total"] == 2 * 16384
     assert two["extra"]["squareroot"]["filters_total"] == 2 * 16384 and two["extra"]["squareroot"]["filters_with_error_status"] == 0
     assert two["extra"]["srif_fp32"]["filters_total"] == 2 * 8192 and two["extra"]["srif_fp32"]["filters_with_error_status"] == 0
+    assert two["extra"]["shared_model"]["filters_total"] == 2 * 16384 and two["extra"]["shared_model"]["filters_with_error_status"] == 0
     assert two["roofline"]["frac"] <= 1.0 and one["roofline"]["frac"] <= 1.0
     # strong scaling (GPU g owns [g N / G, (g + 1) N / G)): the same 65536 filters split over the two ranks
     assert two["strong_scaling"]["filters_per_gpu"] == [32768, 32768] and two["strong_scaling"]["filters_total"] == 65536

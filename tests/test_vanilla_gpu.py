@@ -290,3 +290,41 @@ def test_device_normals_are_bit_identical_to_the_host_replay():
             assert np.array_equal(X[i].view(np.uint64), want.view(np.uint64)), (t, i, X[i], want)
     # and they are standard normals: mean 0, variance 1 over 6 x 4101 draws of the last step
     assert abs(X.mean()) < 0.03 and abs(X.var() - 1.0) < 0.05 and np.abs(X).max() < 6.5
+
+
+@pytest.mark.parametrize("n,p,m,noise,full", [(6, 3, 0, k.NOISE_NOISELESS, False), (6, 3, 0, k.NOISE_AWGN, True), (5, 2, 1, k.NOISE_NOISELESS, True),
+                                              (8, 4, 2, k.NOISE_NOISELESS, False), (4, 2, 0, k.NOISE_NOISELESS, False), (3, 1, 0, k.NOISE_AWGN, False)])
+def test_shared_model_batch_equals_the_per_filter_batch_bit_for_bit(n, p, m, noise, full):
+    """A batch whose model fields were all uploaded with broadcast = 1 runs the SHARED instantiations (kb_vanilla_shared.hip: every
+    wave reads tile 0's model block, default cache policy): the same arithmetic as the per-filter kernels, so the results equal
+    those of a batch given N copies of that model, bit for bit.  Then ONE field becomes per-filter (SetStateTransition with N
+    matrices): the batch leaves the shared path and both batches still agree; back to one F for all: shared again."""
+    N, steps = 4096 + 37, 4
+    rng = np.random.default_rng(7 * n + p + m)
+    F, G, H, Q, R, x0, P0, y, u = _random_model(rng, N, n, p, m, 3 * steps)
+    F1, H1, Q1, R1 = F[0], H[0], Q[0], R[0]
+    G1 = G[0] if m else None
+    flags = k.FLAG_FULL_ESTIMATE if full else 0
+    tile = lambda M: np.broadcast_to(M, (N,) + M.shape).copy()
+    shared = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F1, G1, H1, Q1, R1, nfilters=N, flags=flags, noise=noise, seed=3)
+    perf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, tile(F1), tile(G1) if m else None, tile(H1), tile(Q1), tile(R1), flags=flags, noise=noise, seed=3)
+
+    def run(t0):
+        for t in range(t0, t0 + steps):
+            for b in (shared, perf):
+                b.update(y[t], u[t] if m else None, snapshot=False)
+        for f in [k.STATE, k.COVAR] + ([k.PRED_COVAR, k.GAIN, k.INNOVATION, k.MEASUREMENT] if full else []):
+            assert np.array_equal(shared.get(f).view(np.uint64), perf.get(f).view(np.uint64)), f
+        assert not shared.status().any() and not perf.status().any()
+    run(0)
+    shared.set(k.F, F, 2); perf.set(k.F, F, 2)            # N different transition matrices: no longer one model
+    run(steps)
+    if noise == k.NOISE_NOISELESS and not m:
+        f = orc.Filter.ldkf(orc.VANILLA, x0[5], P0[5], F1, None, H1, Q1, R1)
+        for t in range(2 * steps):
+            if t == steps:
+                f.set_state_transition(F[5])
+            assert f.update(y[t, 5]) == orc.OK
+        assert synth.rel_frobenius(shared.get(k.STATE, 5, 1)[0], f.state()) <= TOL and synth.rel_frobenius(shared.get(k.COVAR, 5, 1)[0], f.covariance()) <= TOL
+    shared.set(k.F, F1, 2); perf.set(k.F, tile(F1), 2)    # one F for all again
+    run(2 * steps)
