@@ -40,12 +40,15 @@ __device__ __forceinline__ void stt(const TilePtr<T> &p, int e, T v) { p.st(e, v
 // MI355X with the arithmetic removed: 0.208 ms -> 0.153 ms per 1M-filter step.
 template <typename T>
 __device__ __forceinline__ T ldnt(const TilePtr<const T> &p, int e) { return p.ldnt(e); }
-// Model operand of a kernel instantiated for SHARED batches (ONE model for every filter: StepArgs::mo_ts == 0, every wave reads
-// tile 0's block): a plain load, so that the 43 KB block stays in the L2 -- the streaming hint makes every wave fetch it again
-// through the fabric (137 us against 105 us per 1M-filter step; per-filter models: 166 us)
+// Model operand of a kernel instantiated for SHARED batches (ONE model for every filter: StepArgs::mo_ts == 0): every lane reads
+// lane 0's copy in tile 0's block.  The address is wave-uniform and nothing is stored before the last of these loads, so the
+// compiler issues them as SCALAR loads (s_load, 92 of them at 6/3) and the model lives in SGPRs -- scalar operands of the FMAs --
+// instead of 168 VGPRs: 238 -> 190 VGPRs, no model traffic beyond the scalar cache.  1M filters x 6/3: 98-100 us per step; as
+// plain vector loads of the lane's own copy (the block stays in the L2) 105-110 us; with the streaming hint of the per-filter
+// kernels 137 us; per-filter models 166 us.  (A third wave per SIMD -- a 168-register cap -- spills 36 registers: 125-140 us.)
 template <bool SHARED, typename T>
 __device__ __forceinline__ T ldm(const TilePtr<const T> &p, int e) {
-    if constexpr (SHARED) return p.ld(e);
+    if constexpr (SHARED) return (p.base + e * KB_TILE)[0];   // lane 0's copy for every lane: a wave-uniform address
     else return p.ldnt(e);
 }
 template <typename T>
