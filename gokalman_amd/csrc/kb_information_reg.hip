@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     if (tile >= a.ntiles) return;
     const bool active = tile * KB_TILE + lane < a.N;
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))) + lane;
-    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
+    // one model for all filters (StepArgs::mo_ts == 0): every lane reads lane 0's copy in tile 0's block -- 8 bytes per load, not a 512-byte row
+    const T *mo = (const T *)a.model + tile * a.mo_ts + (a.mo_ts ? lane : 0);
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
     // request order "slowest first" (kb_vanilla_reg.h): F^-1 is an HBM stream, i and I are Infinity-Cache hits
     T iv[NS], I[TR], Fi[NS * NS];
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
 #pragma unroll
             for (int r = 0; r < NM; r++) pin(yhat[r]);
             __builtin_amdgcn_sched_barrier(0);
-            const TilePtr<const T> mot{(const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems), (unsigned)lane};
+            const TilePtr<const T> mot{(const T *)a.model + tile * a.mo_ts, a.mo_ts ? (unsigned)lane : 0u};
             const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
             T z1[NM], v[NM];

@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
     const bool active = tile * KB_TILE + lane < a.N;
 
     const TilePtr<T> st{(T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))), lane};
-    const TilePtr<const T> mo{(const T *)a.model + tile * a.mo_ts, lane};
+    // (a batch with ONE model for all filters, mo_ts == 0: every lane reads lane 0's copy in tile 0 -- one 8-byte request per load
+    // instead of a 512-byte row; the SHARED instantiations go further and make these scalar loads, see ldm)
+    const TilePtr<const T> mo{(const T *)a.model + tile * a.mo_ts, a.mo_ts ? lane : 0u};
     const TilePtr<const T> moF = mo.field(a.L.mo_F), moH = mo.field(a.L.mo_H), moQ = mo.field(a.L.mo_Q), moR = mo.field(a.L.mo_R),
                            moG = mo.field(a.L.mo_G);
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;

@@ -113,6 +113,16 @@ if "vshared" in which:
     report("B shared model: Vanilla 6/3 f64, one F / H / Q / R for all filters", N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=sb)
     del b
 
+if "sshared" in which:
+    N = Nopt or (1 << 20)
+    d = synth.linear_batch(N, 6, 3, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    for name, kind, fl in (("C shared model: SquareRoot 6/3 f64", k.SQUAREROOT, 0), ("Information 6/3 f64 shared model (from state)", k.INFORMATION, k.FLAG_INFO_FROM_STATE)):
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"][0], None, d["H"][0], d["Q"][0], d["R"][0], nfilters=N, flags=fl)
+        ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+        report(name, N, ms, 1488, {"errors": int(np.count_nonzero(b.status()))}, moved=8 * (6 + 21 + 3 + 6 + 21))
+        del b
+
 if "vnoise" in which:
     # config B with the reference's usual Noise object: AWGN (noise.go:109-164) -- three draws per filter-step (Process, Measurement,
     # Process: vanilla.go:146,157,195) from the device's Philox stream, on the register kernel (kb_vanilla_reg.h, NOISE = true)
