@@ -25,7 +25,9 @@ constexpr bool info_stash() { return INFO_STASH && sizeof(T) == 8 && NS > 4; }
 // PAD: run-time dimensions a.n <= NS, a.p <= NM, a.m <= NC on operands padded with zeros and an identity block in
 // Q^-1 (so that M + Q^-1 stays invertible; Z, I- and i- keep exact zeros in the padding): only loads and stores see
 // the real sizes (cf. kb_vanilla_reg.h).
-template <typename T, int NS, int NM, int NC, bool SCALAR_RINV, bool PAD = false, bool FULL = false, bool NOISE = false>
+// SHARED: one model for all filters (StepArgs::mo_ts == 0), the model operands come from lane 0's copy in tile 0's block with the
+// default cache policy (wave-uniform addresses: scalar loads where no store precedes them; kb_vanilla_reg.h ldm)
+template <typename T, int NS, int NM, int NC, bool SCALAR_RINV, bool PAD = false, bool FULL = false, bool NOISE = false, bool SHARED = false>
 __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_kernel(const StepArgs a) {
     static_assert(FULL || !NOISE, "Information draws Measurement(k) only: nothing but the FULL estimate's yhat sees it");
     constexpr int TR = tri(NS);
@@ -37,14 +39,15 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     const bool active = tile * KB_TILE + lane < a.N;
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))) + lane;
     // one model for all filters (StepArgs::mo_ts == 0): every lane reads lane 0's copy in tile 0's block -- 8 bytes per load, not a 512-byte row
-    const T *mo = (const T *)a.model + tile * a.mo_ts + (a.mo_ts ? lane : 0);
+    const T *mo = SHARED ? (const T *)a.model : (const T *)a.model + tile * a.mo_ts + (a.mo_ts ? lane : 0);
+    auto ldmo = [&](const T *q, int e) __attribute__((always_inline)) { return SHARED ? q[(int64_t)e * KB_TILE] : ldnt(q, e); };
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
     // request order "slowest first" (kb_vanilla_reg.h): F^-1 is an HBM stream, i and I are Infinity-Cache hits
     T iv[NS], I[TR], Fi[NS * NS];
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_Finv + i * rn + j) : T(0);
+        for (int j = 0; j < NS; j++) Fi[i * NS + j] = (i < rn && j < rn) ? ldmo(mo, a.L.mo_Finv + i * rn + j) : T(0);
     auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
         constexpr bool nt = decltype(NT)::value;
 #pragma unroll
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            zqT[j * NS + i] = zk[i * NS + j] + ((i < rn && j < rn) ? ldnt(mo, a.L.mo_Qinv + symi(i, j)) : (i == j ? T(1) : T(0)));
+            zqT[j * NS + i] = zk[i * NS + j] + ((i < rn && j < rn) ? ldmo(mo, a.L.mo_Qinv + symi(i, j)) : (i == j ? T(1) : T(0)));
             X[j * NS + i] = zk[i * NS + j];
         }
 #pragma unroll
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
             T s = T(0);
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                if (i < rn && c < rm) s += ldnt(mo, a.L.mo_G + i * rm + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+                if (i < rn && c < rm) s += ldmo(mo, a.L.mo_G + i * rm + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
             gu[i] = s;
         }
 #pragma unroll
@@ -191,9 +194,9 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
 #pragma unroll
     for (int r = 0; r < NM; r++)
 #pragma unroll
-        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0);
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldmo(mo, a.L.mo_H + r * rn + l) : T(0);
     if constexpr (SCALAR_RINV) {  // QUIRK information.go:198-200: a (stale) 1x1 R^-1 scales H^T whatever p is
-        const T r0 = ldnt(mo, a.L.mo_Rinv);
+        const T r0 = ldmo(mo, a.L.mo_Rinv);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
 #pragma unroll
         for (int l = 0; l < NM; l++)
 #pragma unroll
-            for (int j = 0; j < NM; j++) Ri[l * NM + j] = (l < rp && j < rp) ? ldnt(mo, a.L.mo_Rinv + symi(l, j)) : T(0);
+            for (int j = 0; j < NM; j++) Ri[l * NM + j] = (l < rp && j < rp) ? ldmo(mo, a.L.mo_Rinv + symi(l, j)) : T(0);
 #pragma unroll
         for (int i = 0; i < NS; i++)
 #pragma unroll
@@ -292,7 +295,7 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         for (int r = 0; r < NM; r++) {
             T s = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
+            for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldmo(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
             yhat[r] = s;
         }
         if constexpr (NOISE) {
@@ -327,14 +330,15 @@ static bool info_variant(const StepArgs &a, bool &full, bool &noise) {
 }
 #define KB_INFO_GO(SC_, PAD_)                                                                                                        \
     do {                                                                                                                             \
-        if (!full) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, false, false>), grid, block, 0, b.stream, a); \
-        else if (!noise) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, false>), grid, block, 0, b.stream, a); \
-        else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, true>), grid, block, 0, b.stream, a);      \
+        if (!full) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, false, false, SHARED>), grid, block, 0, b.stream, a); \
+        else if (!noise) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, false, SHARED>), grid, block, 0, b.stream, a); \
+        else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, true, SHARED>), grid, block, 0, b.stream, a);      \
     } while (0)
 
-template <typename T, int NS, int NM, int NC = 0>
+template <typename T, int NS, int NM, int NC = 0, bool SHARED = false>
 static bool info_try(const Batch &b, const StepArgs &a) {
     bool full = false, noise = false;
+    if (SHARED && (a.mo_ts != 0 || (a.flags & KB_FLAG_FULL_ESTIMATE))) return false;   // (the FULL variants stay on the general instantiations)
     if (a.n != NS || a.p != NM || (a.rinv_p != NM && a.rinv_p != 1) || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1 || !info_variant(a, full, noise))
         return false;
     const dim3 grid((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), block(64 * INFO_WPB);
@@ -344,10 +348,11 @@ static bool info_try(const Batch &b, const StepArgs &a) {
 }
 
 // any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input) on the padded instantiation
-template <typename T, int NS, int NM, int NC>
+template <typename T, int NS, int NM, int NC, bool SHARED = false>
 static bool info_try_pad(const Batch &b, const StepArgs &a) {
     const int m = a.need_ctrl ? a.m : 0;
     bool full = false, noise = false;
+    if (SHARED && (a.mo_ts != 0 || (a.flags & KB_FLAG_FULL_ESTIMATE))) return false;
     if (a.n > NS || a.p > NM || (a.rinv_p != a.p && a.rinv_p != 1) || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1 || !info_variant(a, full, noise))
         return false;
     const dim3 grid((unsigned)((a.ntiles + INFO_WPB - 1) / INFO_WPB)), block(64 * INFO_WPB);
@@ -359,7 +364,10 @@ static bool info_try_pad(const Batch &b, const StepArgs &a) {
 int launch_information(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_information_gen(b, a);
     bool done = false;
-    if (b.dtype == KB_F64)
+    if (b.dtype == KB_F64 && a.mo_ts == 0)   // one model for all filters: the SHARED instantiations (state-only outputs)
+        done = info_try<double, 6, 3, 0, true>(b, a) || info_try<double, 4, 2, 0, true>(b, a) || info_try_pad<double, 4, 2, 0, true>(b, a) ||
+               info_try_pad<double, 4, 2, 2, true>(b, a) || info_try_pad<double, 6, 4, 0, true>(b, a) || info_try_pad<double, 6, 4, 2, true>(b, a);
+    if (!done && b.dtype == KB_F64)
         done = info_try<double, 6, 3>(b, a) || info_try<double, 4, 2>(b, a) ||
                info_try<double, 4, 1, 1>(b, a) || info_try<double, 4, 2, 1>(b, a);  // examples/jerkcar
     if (!done && b.dtype == KB_F64)   // shapes without an exact instantiation: padded register kernels up to 6 / 4 / 2

@@ -37,7 +37,10 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 // NOISE: the batch's Noise is AWGN (noise.go:109-164).  SquareRoot.Update draws twice per step (squareroot.go:239, :268):
 // Measurement(k) into yhat -- only a FULL estimate keeps it -- and Process(k) into x+; x- carries no noise (:139-147).  The
 // draws come at the very end, when only x+, S+ (and K) are alive, with the stream indices of the generic kernel (which = 1, 2).
-template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false, bool NOISE = false>
+// SHARED: instantiated for batches with ONE model for all filters (StepArgs::mo_ts == 0): the model operands are read from lane 0's
+// copy in tile 0's block with the default cache policy -- wave-uniform addresses, scalar loads where no store precedes them
+// (kb_vanilla_reg.h ldm)
+template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false, bool NOISE = false, bool SHARED = false>
 __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PAD>())) squareroot_reg_kernel(const StepArgs a) {
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
@@ -47,7 +50,8 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     const bool active = tile * KB_TILE + lane < a.N;
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn))) + lane;
     // one model for all filters (StepArgs::mo_ts == 0): every lane reads lane 0's copy in tile 0's block -- 8 bytes per load, not a 512-byte row
-    const T *mo = (const T *)a.model + tile * a.mo_ts + (a.mo_ts ? lane : 0);
+    const T *mo = SHARED ? (const T *)a.model : (const T *)a.model + tile * a.mo_ts + (a.mo_ts ? lane : 0);
+    auto ldmo = [&](const T *q, int e) __attribute__((always_inline)) { return SHARED ? q[(int64_t)e * KB_TILE] : ldnt(q, e); };
     const T *yp = (const T *)a.y + tile * a.y_ts + lane;
 
     // request order "slowest first" (kb_vanilla_reg.h): F is an HBM stream, x and S are Infinity-Cache hits
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldnt(mo, a.L.mo_F + i * rn + j) : T(0);
+        for (int j = 0; j < NS; j++) F[i * NS + j] = (i < rn && j < rn) ? ldmo(mo, a.L.mo_F + i * rn + j) : T(0);
     auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
         constexpr bool nt = decltype(NT)::value;
 #pragma unroll
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             T s = T(0);
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                if (i < rn && c < rm) s += ldnt(mo, a.L.mo_G + i * rm + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
+                if (i < rn && c < rm) s += ldmo(mo, a.L.mo_G + i * rm + c) * (active ? __builtin_nontemporal_load(up + (int64_t)c * a.u_es) : T(0));
             xm[i] = xm[i] + s;
         }
     }
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i && j < rn) ? ldnt(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
+        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i && j < rn) ? ldmo(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
     sqr_r<T, 2 * NS, NS, ActC<NS>>(C);
     __builtin_amdgcn_sched_barrier(0);  // H, chol(R) loads and the Delta panel stay below the C phase
     // Sm[i][j] = C[i*NS+j], j >= i
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
     for (int r = 0; r < NM; r++)
 #pragma unroll
-        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0);
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldmo(mo, a.L.mo_H + r * rn + l) : T(0);
     // :190-216 Delta = [[sqrtR^T, 0],[S-^T H^T, S-^T]]
     T D[DD * DD];
 #pragma unroll
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             T val;
             if (c < NM) {
                 if (r < NM) {
-                    val = (c >= r) ? (c < rp ? ldnt(mo, a.L.mo_LR + symi(r, c)) : (r == c ? T(1) : T(0))) : T(0);
+                    val = (c >= r) ? (c < rp ? ldmo(mo, a.L.mo_LR + symi(r, c)) : (r == c ? T(1) : T(0))) : T(0);
                 } else {
                     T s = T(0);  // (S-^T H^T)[r-NM][c] = sum_{l <= r-NM} Sm[l][r-NM] H[c][l]
 #pragma unroll
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             for (int r = 0; r < NM; r++) {                               // squareroot.go:237-239 yhat = H x_prev + Measurement(k)
                 T s = T(0);
 #pragma unroll
-                for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldnt(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
+                for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldmo(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
                 yhat[r] = s + v[r];
             }
             T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
@@ -285,35 +289,40 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
 }
 
-template <typename T, int NS, int NM, int NC = 0, bool NOISE = false>
+template <typename T, int NS, int NM, int NC = 0, bool NOISE = false, bool SHARED = false>
 static bool sqrt_try(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || a.sqrt_p != NM || (a.need_ctrl ? a.m : 0) != NC || a.nsteps != 1) return false;
+    if (SHARED && a.mo_ts != 0) return false;
     if (a.noise_kind != (NOISE ? KB_NOISE_AWGN : KB_NOISE_NOISELESS)) return false;
     const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, false, NOISE>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, false, NOISE>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, false, NOISE, SHARED>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, false, NOISE, SHARED>), grid, block, 0, b.stream, a);
     return true;
 }
 
 // any (n, p, m) with n <= NS, p <= NM, m <= NC (NC == 0 iff no control input) on the padded instantiation
-template <typename T, int NS, int NM, int NC, bool NOISE = false>
+template <typename T, int NS, int NM, int NC, bool NOISE = false, bool SHARED = false>
 static bool sqrt_try_pad(const Batch &b, const StepArgs &a) {
     const int m = a.need_ctrl ? a.m : 0;
     if (a.n > NS || a.p > NM || a.sqrt_p != a.p || m > NC || (NC == 0) != (m == 0) || a.nsteps != 1) return false;
+    if (SHARED && a.mo_ts != 0) return false;
     if (a.noise_kind != (NOISE ? KB_NOISE_AWGN : KB_NOISE_NOISELESS)) return false;
     const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, true, NOISE>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, true, NOISE>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, true, NOISE, SHARED>), grid, block, 0, b.stream, a);
+    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, true, NOISE, SHARED>), grid, block, 0, b.stream, a);
     return true;
 }
 
 int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_squareroot_gen(b, a);
     bool done = false;
-    if (b.dtype == KB_F64)
+    if (b.dtype == KB_F64 && a.mo_ts == 0)   // one model for all filters: the SHARED instantiations (Noiseless; the benchmark shapes and the padded families)
+        done = sqrt_try<double, 6, 3, 0, false, true>(b, a) || sqrt_try<double, 4, 2, 0, false, true>(b, a) || sqrt_try_pad<double, 4, 2, 0, false, true>(b, a) ||
+               sqrt_try_pad<double, 4, 2, 2, false, true>(b, a) || sqrt_try_pad<double, 6, 4, 0, false, true>(b, a) || sqrt_try_pad<double, 6, 4, 2, false, true>(b, a);
+    if (!done && b.dtype == KB_F64)
         done = sqrt_try<double, 6, 3>(b, a) || sqrt_try<double, 4, 2>(b, a) ||
                sqrt_try<double, 4, 1, 1>(b, a) || sqrt_try<double, 4, 2, 1>(b, a);  // examples/jerkcar: 1- and 2-row H, one control
-    else done = sqrt_try<float, 6, 3>(b, a);
+    else if (b.dtype != KB_F64) done = sqrt_try<float, 6, 3>(b, a);
     if (!done && b.dtype == KB_F64)   // shapes without an exact instantiation: padded register kernels up to 6 / 4 / 2
         done = sqrt_try_pad<double, 4, 2, 0>(b, a) || sqrt_try_pad<double, 4, 2, 2>(b, a) || sqrt_try_pad<double, 6, 4, 0>(b, a) ||
                sqrt_try_pad<double, 6, 4, 2>(b, a);

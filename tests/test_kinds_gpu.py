@@ -622,3 +622,29 @@ def test_update_steps_dev_without_a_fused_kernel_runs_the_register_kernel_per_st
         okind = {k.SQUAREROOT: orc.SQUAREROOT, k.INFORMATION: orc.INFORMATION, k.VANILLA: orc.VANILLA}[kind]
         xo, Po, _ = orc.ldkf_batch(okind, x0[:64], sl["P0"][:64], sl["F"][:64], H[:64], sl["Q"][:64], R[:64], d["y"][:, :64, :p])
         assert synth.rel_frobenius(res[0][0][:64], xo) <= 1e-9 and synth.rel_frobenius(res[0][1][:64], Po) <= 1e-9
+
+
+@pytest.mark.parametrize("kind,flags", [(k.SQUAREROOT, 0), (k.INFORMATION, k.FLAG_INFO_FROM_STATE), (k.SQUAREROOT, k.FLAG_FULL_ESTIMATE), (k.INFORMATION, k.FLAG_INFO_FROM_STATE | k.FLAG_FULL_ESTIMATE)])
+@pytest.mark.parametrize("n,p", [(6, 3), (5, 2), (4, 2)])
+def test_shared_model_squareroot_and_information_equal_the_per_filter_batch(kind, flags, n, p):
+    """One model for all filters (every model field uploaded with broadcast = 1) on the SquareRoot / Information kernels: SHARED
+    instantiations for the state-only outputs (scalar model loads), uniform-address reads on the others; bit-identical to a batch that
+    was given N copies of the model, before and after one field becomes per-filter."""
+    N, steps = 2048 + 11, 3
+    d = synth.linear_batch(N, 6, 3, 3 * steps, seed=123)
+    x0, P0, F, H, Q, R, y = d["x0"][:, :n], d["P0"][:, :n, :n], d["F"][:, :n, :n], d["H"][:, :p, :n], d["Q"][:, :n, :n], d["R"][:, :p, :p], d["y"][:, :, :p]
+    tile = lambda M: np.broadcast_to(M, (N,) + M.shape).copy()
+    shared = ga.FilterBatch.new_ldkf(kind, x0, P0, F[0], None, H[0], Q[0], R[0], nfilters=N, flags=flags)
+    perf = ga.FilterBatch.new_ldkf(kind, x0, P0, tile(F[0]), None, tile(H[0]), tile(Q[0]), tile(R[0]), flags=flags)
+
+    def run(t0):
+        for t in range(t0, t0 + steps):
+            shared.update(y[t], snapshot=False); perf.update(y[t], snapshot=False)
+        for f in (k.STATE, k.COVAR):
+            assert np.array_equal(shared.get(f).view(np.uint64), perf.get(f).view(np.uint64)), f
+        assert np.array_equal(shared.status(), perf.status())
+    run(0)
+    shared.set(k.H, H, 2, p_rows=p); perf.set(k.H, H, 2, p_rows=p)     # per-filter measurement matrices
+    run(steps)
+    shared.set(k.H, H[0], 2, p_rows=p); perf.set(k.H, tile(H[0]), 2, p_rows=p)
+    run(2 * steps)
