@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "srif", "hybrid", "hstrict", "mc"]
+which = args or ["vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
