@@ -389,3 +389,25 @@ def test_baseline_size_1m_vanilla_strict_symcheck_register_kernel():
     assert np.array_equal(tail_P, s.get(k.COVAR)) and np.array_equal(tail_x, s.get(k.STATE))
     xo, Po, _ = orc.ldkf_batch(orc.VANILLA, base["x0"], base["P0"], base["F"], base["H"], base["Q"], base["R"], base["y"][:steps])
     assert synth.rel_frobenius(tail_x, xo) <= 1e-9 and synth.rel_frobenius(tail_P, Po) <= 1e-9
+
+
+@pytest.mark.parametrize("kind,flags", [(k.VANILLA, 0), (k.SQUAREROOT, 0), (k.INFORMATION, k.FLAG_INFO_FROM_STATE)])
+def test_baseline_size_1m_filters_sharing_one_model(kind, flags):
+    """1M filters built from ONE model (every model field uploaded with broadcast = 1: the SHARED kernels, model in SGPRs): the last
+    4096 filters equal, bit for bit, a 4096-filter batch that was given that model per filter (the oracle-checked path), and the
+    first 64 filters match the oracle at 1e-9."""
+    N, small, steps = 1 << 20, 4096, 3
+    base = synth.linear_batch(small, 6, 3, steps)
+    rep = N // small
+    F1, H1, Q1, R1 = base["F"][7], base["H"][7], base["Q"][7], base["R"][7]
+    tile = lambda M: np.broadcast_to(M, (small,) + M.shape).copy()
+    b = ga.FilterBatch.new_ldkf(kind, np.tile(base["x0"], (rep, 1)), np.tile(base["P0"], (rep, 1, 1)), F1, None, H1, Q1, R1, nfilters=N, flags=flags)
+    s = ga.FilterBatch.new_ldkf(kind, base["x0"], base["P0"], tile(F1), None, tile(H1), tile(Q1), tile(R1), flags=flags)
+    for t in range(steps):
+        b.update(np.tile(base["y"][t], (rep, 1)), snapshot=False); s.update(base["y"][t], snapshot=False)
+    assert not b.status().any()
+    assert np.array_equal(b.get(k.STATE, N - small, small), s.get(k.STATE)) and np.array_equal(b.get(k.COVAR, N - small, small), s.get(k.COVAR))
+    assert np.array_equal(b.get(k.COVAR, 0, small), s.get(k.COVAR))
+    okind = {k.VANILLA: orc.VANILLA, k.SQUAREROOT: orc.SQUAREROOT, k.INFORMATION: orc.INFORMATION}[kind]
+    xo, Po, _ = orc.ldkf_batch(okind, base["x0"][:64], base["P0"][:64], tile(F1)[:64], tile(H1)[:64], tile(Q1)[:64], tile(R1)[:64], base["y"][:steps, :64])
+    assert synth.rel_frobenius(b.get(k.STATE, 0, 64), xo) <= 1e-9 and synth.rel_frobenius(b.get(k.COVAR, 0, 64), Po) <= 1e-9
