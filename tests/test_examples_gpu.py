@@ -61,3 +61,26 @@ def test_statod5044_example_runs_end_to_end(tmp_path):
             worst = max(worst, np.linalg.norm(f.state() - out["history"][name][s]) / max(np.linalg.norm(f.state()), 1e-300))
         assert worst <= 1e-9, (name, worst)
     assert len(open(tmp_path / "chisquare.csv").readlines()) == ex.SAMPLES + 1
+
+
+def test_robot_example_in_cpp_writes_the_same_files_as_the_python_one(tmp_path):
+    """examples/robot.cpp is examples/robot/main.go transliterated onto include/gokalman_amd.hpp (the compiled-language twin of the Go
+    shim: NewAWGN, NewPurePredictorVanilla, NewVanilla, NewMonteCarloRuns(sims, steps, 1, controls, mcKF), runs.AsCSV(headers),
+    NewChiSquare(chiKF, runs, controls, true, true)).  Same seed and initial state as examples/robot.py: the three CSV files are
+    identical byte for byte (the same C ABI calls, the same device noise streams, the same %f formatting)."""
+    import subprocess
+    import robot as ex
+    exe = str(tmp_path / "robot_cpp")
+    lib = os.path.join(ROOT, "gokalman_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "robot.cpp"),
+                    "-L" + lib, "-lgokalman_amd", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    py_dir, cpp_dir = tmp_path / "py", tmp_path / "cpp"
+    os.makedirs(cpp_dir)
+    ex.main(str(py_dir), runs=50, seed=1)
+    mc_x0 = np.linalg.cholesky(ex.P0) @ np.random.default_rng(1).standard_normal(2)      # robot.py's draw for seed 1
+    r = subprocess.run([exe, str(cpp_dir), "1", "%.17g" % mc_x0[0], "%.17g" % mc_x0[1], "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for name in ("montecarlo-xi.csv", "montecarlo-xi_dot.csv", "chisquare.csv"):
+        a, b = open(py_dir / name).read(), open(cpp_dir / name).read()
+        assert a == b, name
+    assert len(open(cpp_dir / "chisquare.csv").read().split("\n")) == ex.STEPS + 2
