@@ -230,7 +230,7 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     a.stream_state = b.block_bytes(b.L.st_elems) > KB_MALL_BYTES ? 1 : 0;
     a.n = b.n; a.p = b.p; a.m = b.m; a.pmax = b.pmax; a.L = b.L; a.flags = b.flags;
     a.need_ctrl = b.need_ctrl; a.rinv_p = b.rinv_p; a.sqrt_p = b.sqrt_p; a.srif_tri = b.srif_tri;
-    a.srif_leftover = b.srif_leftover; a.srif_dense_fail = b.d_srif_fail;
+    a.srif_leftover = b.srif_leftover; a.srif_dense_fail = b.d_srif_fail; a.srif_dense = b.d_srif_dense;
     a.ekf = b.ekf; a.snc = b.snc; a.predict = (b.kind == KB_VANILLA_PREDICT);
     a.noise_kind = b.noise_kind; a.seed = b.seed; a.epoch = b.epoch; a.step0 = b.step; a.first_filter = 0;
     a.bn_proc = b.d_bn_proc; a.bn_meas = b.d_bn_meas; a.bn_p = b.bn_p;
@@ -339,6 +339,8 @@ int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, i
         KB_TRY(hipHostMalloc((void **)&b->h_srif_fail, sizeof(uint32_t), hipHostMallocMapped));
         *b->h_srif_fail = 0u;
         KB_TRY(hipHostGetDevicePointer((void **)&b->d_srif_fail, b->h_srif_fail, 0));
+        KB_TRY(hipMalloc((void **)&b->d_srif_dense, (size_t)b->ntiles * 2 * sizeof(uint32_t)));
+        KB_TRY(hipMemsetAsync(b->d_srif_dense, 0, (size_t)b->ntiles * 2 * sizeof(uint32_t), b->stream));
     }
     if (flags & KB_FLAG_FULL_ESTIMATE) {
         KB_TRY(hipMalloc(&b->d_est, b->block_bytes(b->L.es_elems)));
@@ -356,7 +358,7 @@ void kb_destroy(kb_batch *b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_est, b->d_model, b->d_status,
                     b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
-                    b->h_lag ? nullptr : (void *)b->d_lag};
+                    b->h_lag ? nullptr : (void *)b->d_lag, (void *)b->d_srif_dense};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_lag) (void)hipHostFree(b->h_lag);
@@ -411,6 +413,9 @@ int kb_set(kb_batch *b, int field, const double *host, int64_t count, int broadc
     if (t.block == b->d_model && field >= 0 && field < 32) {   // does every filter still have the same model? (StepArgs::mo_ts)
         if (broadcast) b->per_filter_model &= ~(1u << field); else b->per_filter_model |= 1u << field;
     }
+    if (field == KB_X || field == KB_P) {
+        if (broadcast) b->per_filter_init &= ~(1u << field); else b->per_filter_init |= 1u << field;
+    }
     if ((rc = after_set(b, field, p_rows, host, count * t.src_elems))) { (void)hipStreamSynchronize(b->stream); return rc; }
     KB_HIP(hipStreamSynchronize(b->stream));
     return KB_OK;
@@ -440,6 +445,7 @@ int kb_set_dev(kb_batch *b, int field, const void *src, int64_t ld, int p_rows) 
                            t.src_elems, b->N, (float *)t.block, t.block_elems, (const int16_t *)b->d_stage);
     KB_HIP(hipGetLastError());
     if (t.block == b->d_model && field >= 0 && field < 32) b->per_filter_model |= 1u << field;   // per-filter by construction (StepArgs::mo_ts)
+    if (field == KB_X || field == KB_P) b->per_filter_init |= 1u << field;
     if (field == KB_G && !b->initialized) b->need_ctrl = 1;  // device-side G: assumed non-nil
     if ((rc = after_set(b, field, p_rows, nullptr, 0))) return rc;
     KB_HIP(hipStreamSynchronize(b->stream));  // the map buffer may be reused by the next call
@@ -514,6 +520,7 @@ static int check_batch_noise(kb_batch *b, int nsteps) {
     // the largest kf.step any filter of the batch may be at (exact for one-tile batches, whose failed-step counts the host sees)
     int64_t step = b->step;
     if (b->h_lag) {
+        if (hipStreamQuery(b->stream) != hipSuccess) KB_HIP(hipStreamSynchronize(b->stream));   // the words of an asynchronous step still running
         uint32_t least = b->h_lag[0];
         for (int64_t i = 1; i < b->N; i++) least = b->h_lag[i] < least ? b->h_lag[i] : least;
         step -= least;
@@ -768,7 +775,11 @@ static bool wait_snapshot(const Batch &b) {
     for (unsigned spins = 0;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == b.pin_seq) return true;
         if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) return false;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield");
+#endif
     }
 }
 
@@ -808,14 +819,10 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
     // The status words travel (and are cleared) with the LAST launch: a member that cannot be delivered (pred_covariance of a
     // batch without KB_FLAG_FULL_ESTIMATE, a launch error) fails the call before anything has been cleared.
     const int status_pass = (lazy && v->pred_covariance) ? 1 : 0;
-    bool cleared = false;
     // which pass is the last one that launches anything (status travels with status_pass; pass 1 only exists for lazy pred_covariance)
     const int last_pass = (lazy && v->pred_covariance) ? 1 : 0;
     const bool flagged = pinned && count <= KB_SNAP_FLAG_MAX;
     bool flag_armed = false;
-    // after the clear nothing may fail silently: the SRIF Update finds filters that may hold a dense R through their status
-    // words (kb_srif_pair.h), so a lost word sends the next Update down the dense path
-    auto after_clear = [&](int code) { if (code && cleared && b->kind == KB_SRIF) b->srif_tri = 0; return code; };
     for (int pass = 0; pass < 2; pass++) {
         SnapArgs sa;
         sa.nmembers = 0;
@@ -837,12 +844,10 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
         if (flagged && pass == last_pass) { done = (uint32_t *)((char *)b->d_pin + KB_PIN_FLAG_OFF); ++b->pin_seq; }
         if ((rc = launch_snapshot(*b, sa, first, count, d_area, with_status ? b->d_status : nullptr, (int64_t)st_off, v->clear_status ? 1 : 0, done, b->pin_seq))) return rc;
         if (done) flag_armed = true;
-        if (with_status && v->clear_status) cleared = true;
     }
-#undef KB_HIP
-#define KB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return after_clear(::kb::hip_fail(e__, #call)); } while (0)
     if (pinned) {
         if (!(flag_armed && wait_snapshot(*b))) KB_HIP(hipStreamSynchronize(b->stream));
+        else KB_HIP(hipGetLastError());   // the polled word says the snapshot ran; an error raised by this handle's launches is reported here, not later
         for (int i = 0; i < 6; i++)
             if (want[i].dst) memcpy(want[i].dst, h_area + want[i].off, want[i].bytes);
         if (v->status) memcpy(v->status, h_area + st_off, (size_t)count * sizeof(uint32_t));
@@ -852,14 +857,7 @@ int kb_get_estimate(kb_batch *b, int64_t first, int64_t count, kb_estimate_view 
         if (v->status) KB_HIP(hipMemcpyAsync(v->status, d_area + st_off, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
         KB_HIP(hipStreamSynchronize(b->stream));
     }
-    if (v->status && v->clear_status && b->kind == KB_SRIF) {
-        // the SRIF Update finds filters that may hold a dense R through their status words (kb_srif_pair.h)
-        for (int64_t k = 0; k < count; k++)
-            if (v->status[k]) { b->srif_tri = 0; break; }
-    }
     return KB_OK;
-#undef KB_HIP
-#define KB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return ::kb::hip_fail(e__, #call); } while (0)
 }
 
 int kb_get_status(kb_batch *b, uint32_t *host, int64_t first, int64_t count) {
@@ -878,9 +876,6 @@ int kb_clear_status(kb_batch *b) {
     if (rc) return rc;
     KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
     KB_HIP(hipStreamSynchronize(b->stream));
-    // KB_SRIF: the fused Update finds the filters whose R may be dense (they skipped an Update after a Predict()) through
-    // their status words; with those gone the next Update takes the two-kernel path, which tests R itself
-    if (b->kind == KB_SRIF) b->srif_tri = 0;
     return KB_OK;
 }
 
@@ -913,7 +908,19 @@ int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first
 
 // kf.step: a failed Update does not advance it (vanilla.go:164-167 returns before :218).  One-tile batches: exact, filter 0's
 // counter (the host sees the failed-step counts); larger batches: the counter of a filter that never failed.
-int64_t kb_step(const kb_batch *b) { return b ? b->step - (b->h_lag ? (int64_t)b->h_lag[0] : 0) : -1; }
+// The failed-step words are written by the step kernels: with asynchronous work outstanding on the handle's stream (kb_update_dev,
+// kb_update_steps_dev) they are read only once it has drained.
+static void settle_lag(const Batch &b) {
+    if (b.h_lag && b.stream && hipStreamQuery(b.stream) != hipSuccess) {
+        (void)hipSetDevice(b.device);
+        (void)hipStreamSynchronize(b.stream);
+    }
+}
+int64_t kb_step(const kb_batch *b) {
+    if (!b) return -1;
+    settle_lag(*b);
+    return b->step - (b->h_lag ? (int64_t)b->h_lag[0] : 0);
+}
 int64_t kb_calls(const kb_batch *b) { return b ? b->calls : -1; }
 int kb_filter_step(kb_batch *b, int64_t filter, int64_t *step) {
     if (!b || !step) { set_error("null argument"); return KB_ERR_INVALID; }

@@ -82,7 +82,8 @@ static int nl_common(kb_batch *b, StepArgs &a, bool predict) {
         // Batch::srif_leftover: once the stream has drained, the pinned word tells whether a filter failed in the dense kernel
         if (b->srif_leftover && hipStreamQuery(b->stream) == hipSuccess) after_sync(*b);
         a.srif_leftover = b->srif_leftover;
-        if (!b->srif_tri) KB_HIP(hipMemsetAsync(b->d_srif_fail, 0, sizeof(uint32_t), b->stream));   // a whole-batch dense Update: failures are counted afresh
+        // every launch of the dense kernel counts its failures afresh: the word stays up only while some filter still fails in it
+        if (!b->srif_tri || b->srif_leftover) KB_HIP(hipMemsetAsync(b->d_srif_fail, 0, sizeof(uint32_t), b->stream));
     }
     if ((rc = launch_nl(b, a))) return rc;
     if (b->kind == KB_SRIF && !predict && !b->srif_tri) b->srif_leftover = 1;   // until a drained stream shows that nobody failed in it
@@ -303,6 +304,12 @@ int kb::mc_run_device(Batch &bb, int steps, const double *controls, int ncontrol
         return KB_ERR_INVALID;
     }
     if (b->noise_kind != KB_NOISE_AWGN) { set_error("Monte-Carlo runs need AWGN noise (kb_set_noise_kind)"); return KB_ERR_INVALID; }
+    // montecarlo.go:92-119 runs ONE filter `samples` times: the per-step sums are taken about the noise-free trajectory of that filter
+    // (the shift the statistics add back), which is only THE trajectory when every run starts from the same x0 with the same model
+    if (b->per_filter_model || b->per_filter_init) {
+        set_error("Monte-Carlo runs are N copies of one filter: upload x0, P0 and the model with broadcast = 1, or build the batch with kb_replicate");
+        return KB_ERR_INVALID;
+    }
     int rc = use_device(*b);
     if (rc) return rc;
     const int n = b->n, m = b->m;

@@ -55,6 +55,7 @@ struct Batch {
     // Batches of at most one tile (the reference's own use: one filter) skip the staging copies: the host writes / reads a
     // pinned, device-mapped buffer the kernels access directly (3 input tiles + one read-back area).
     unsigned per_filter_model = 0;   // bit f set: model field f (KB_F .. ) was last uploaded per filter; 0 = one model for the whole batch
+    unsigned per_filter_init = 0;    // same for the constructor arguments x0 (KB_X) / P0 (KB_P): the Monte-Carlo ensembles are N copies of ONE filter
     void *h_pin = nullptr, *d_pin = nullptr;
     uint32_t pin_seq = 0;   // sequence number of the last flagged snapshot (the word at KB_PIN_FLAG_OFF of the pinned block)
     void *d_y2 = nullptr;
@@ -73,6 +74,10 @@ struct Batch {
     // that finds the word at zero (kb_srif_pair.h)
     int srif_leftover = 0;
     uint32_t *h_srif_fail = nullptr, *d_srif_fail = nullptr;
+    // one word per half-tile (32 filters), written by the dense Update kernel only: non-zero = a filter of this half-tile failed in it
+    // and may still hold a dense R.  Both Update kernels of a step pick their half-tiles from these words, which the steady-state
+    // kernel never writes: ownership of a half-tile cannot change between the two launches of one step.
+    uint32_t *d_srif_dense = nullptr;
     int srif_tri = 1;      // KB_SRIF: R is upper triangular (constructor / measurement update wrote it; Predict() stores the full RBar)
     int rinv_p = 0;        // KB_INFORMATION: dimension R^-1 was computed for (stale-Rinv quirk)
     int sqrt_p = 0;        // KB_SQUAREROOT: dimension of chol(R)
@@ -120,6 +125,7 @@ struct StepArgs {
     int rinv_p, sqrt_p;
     int srif_tri;                               // KB_SRIF: R is upper triangular (last writer: constructor or a measurement update)
     int srif_leftover; uint32_t *srif_dense_fail;   // KB_SRIF: see Batch::srif_leftover
+    uint32_t *srif_dense;                           // KB_SRIF: Batch::d_srif_dense
     int ekf, snc, predict;
     int noise_kind; uint64_t seed; int64_t epoch; int64_t step0; int64_t first_filter;
     const void *bn_proc, *bn_meas; int bn_p;     // BatchNoise: [step][n], [step][bn_p]

@@ -337,10 +337,16 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         err = elo | ehi;
     }
     const bool ok = inb && err == 0;   // failed: (b, R) stay as they are, srif.go:111-114 returns before any assignment
-    if (err && inb && !is_hi) {
-        fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
-        // a filter that fails HERE keeps a dense R: the host must keep sending its half-tile to this kernel (kb_internal.h srif_leftover)
-        if constexpr (DENSE) __hip_atomic_store(a.srif_dense_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (err && inb && !is_hi) fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
+    if constexpr (DENSE) {
+        // a filter that fails HERE keeps a dense R: its half-tile stays with this kernel (Batch::d_srif_dense; the steady-state kernel
+        // never writes that word, so the two launches of one step cannot both take a half-tile) and the host keeps launching it
+        // (Batch::srif_leftover) until a drained stream shows a launch in which nobody failed
+        const bool left = __any(err != 0 && inb);
+        if (lane == 0) {
+            a.srif_dense[2 * tile + half] = left ? 1u : 0u;
+            if (left) __hip_atomic_store(a.srif_dense_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 
     __builtin_amdgcn_sched_barrier(0);
@@ -610,8 +616,8 @@ constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 *
                         // reserved until its three companions are done: 89.8 us against 86.7 us (fp32, 256k filters)
 #endif
 // Steady state: every R of the batch is upper triangular (Batch::srif_tri).  With a.srif_leftover the batch may still hold filters
-// with a dense R (they failed the Update that followed a Predict()); those carry a non-zero status word, and their half-tiles are
-// left to srif_pair_dense_kernel, which the host launches right behind this kernel for as long as that can be the case.
+// with a dense R (they failed the Update that followed a Predict()); the dense kernel marked their half-tiles in a.srif_dense, and
+// those are left to srif_pair_dense_kernel, which the host launches right behind this kernel for as long as that can be the case.
 template <typename T, int NS, int NM, bool FULL, bool EXT>
 __global__ void __launch_bounds__(64 * KB_PAIR_WPB, (srif_pair_waves_per_simd<T, NS>())) srif_pair_kernel(const StepArgs a) {
     __shared__ T lds[KB_PAIR_WPB * NS * NS * 32];
@@ -622,15 +628,12 @@ __global__ void __launch_bounds__(64 * KB_PAIR_WPB, (srif_pair_waves_per_simd<T,
     const int half = (int)(gw & 1);
     const int64_t first = tile * KB_TILE + half * 32;
     if (first >= a.N) return;
-    if (a.srif_leftover) {
-        const int64_t fi = first + (lane & 31);
-        if (__any(fi < a.N && a.status[fi] != 0u)) return;
-    }
+    if (a.srif_leftover && a.srif_dense[gw] != 0u) return;   // srif_pair_dense_kernel's (launched right behind this one)
     srif_pair_tile<T, NS, NM, FULL, EXT, false>(a, tile, half, lane, lds + wv * (NS * NS * 32));
 }
 
 // The Update right after a Predict() (a.srif_tri == 0: every R is the dense RBar the Predict() kernel stored), or the half-tiles
-// the steady-state kernel skipped (a.srif_tri != 0: only half-tiles with a non-zero status word).  One wave per SIMD: the
+// the steady-state kernel skipped (a.srif_tri != 0: only half-tiles marked in a.srif_dense).  One wave per SIMD: the
 // register-resident copy of R needs the 512-register budget.
 template <typename T, int NS, int NM, bool FULL, bool EXT>
 __global__ void __launch_bounds__(64, 1) srif_pair_dense_kernel(const StepArgs a) {
@@ -641,10 +644,7 @@ __global__ void __launch_bounds__(64, 1) srif_pair_dense_kernel(const StepArgs a
     const int half = (int)(gw & 1);
     const int64_t first = tile * KB_TILE + half * 32;
     if (first >= a.N) return;
-    if (a.srif_tri) {
-        const int64_t fi = first + (lane & 31);
-        if (!__any(fi < a.N && a.status[fi] != 0u)) return;
-    }
+    if (a.srif_tri && a.srif_dense[gw] == 0u) return;
     srif_pair_tile<T, NS, NM, FULL, EXT, true>(a, tile, half, lane, lds);
 }
 

@@ -166,3 +166,49 @@ def test_srif_partial_half_tiles_zero_copy_and_full_estimate(N, dtype, tol):
     assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in filters])) <= tol * 10
     assert synth.rel_frobenius(est.measurement(), np.array([f.measurement() for f in filters])) <= tol
     assert np.isfinite(est.covariance()).all()
+
+
+@pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F64, 1e-9), (12, 6, k.F32, 2e-3), (6, 2, k.F64, 1e-9)])
+def test_srif_leftover_dense_tiles_and_a_new_failure_update_every_filter_once(n, p, dtype, tol):
+    """while some filter may still hold a dense R (it failed the Update that followed a Predict()), every Update
+    launches the steady-state kernel AND the dense kernel.  Each half-tile must be taken by exactly one of them, also when a filter
+    of an untouched half-tile fails in the steady-state kernel of that very step (its 31 neighbours must not get the measurement
+    twice, its kf.step must fall behind by one, not two)."""
+    rng = np.random.default_rng(4242 + n)
+    N, steps = 200, 7
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((steps, N, n, n))
+    Ht = rng.standard_normal((steps, N, p, n))
+    real = rng.standard_normal((steps, N, p))
+    comp = real + 1e-2 * rng.standard_normal((steps, N, p))
+    # step 1: Predict().  step 2: filter 7 fails in the whole-batch dense Update (keeps its dense R: half-tile 0 stays with the
+    # dense kernel).  step 3: filters 40 (half-tile 1) and 130 (tile 2) fail in the steady-state kernel, filter 7 fails AGAIN in the
+    # dense one.  step 4: everybody succeeds (filter 7 in the dense kernel).  steps 5, 6: steady state; 150 fails at 5.
+    fails = {2: [7], 3: [7, 40, 130], 5: [150]}
+    for t, lst in fails.items():
+        for i in lst:
+            Phi[t, i, 1, :] = 0.0
+    b = _srif_batch(N, n, p, dtype, x0, P0, R)
+    filters = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+    nfail = np.zeros(N, dtype=np.int64)
+    for t in range(steps):
+        b.prepare(Phi[t], Ht[t])
+        predict = t == 1
+        if predict:
+            b.predict_nl()
+        else:
+            b.update_nl(real[t], comp[t])
+        for i, f in enumerate(filters):
+            f.prepare(Phi[t, i], Ht[t, i])
+            rc = f.predict_nl() if predict else f.update_nl(real[t, i], comp[t, i])
+            bad = i in fails.get(t, [])
+            assert rc == (orc.ERR_SINGULAR if bad else orc.OK)
+            nfail[i] += bad
+        assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in filters])) <= tol, t
+        assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in filters])) <= tol, t
+        for i in (6, 7, 8, 39, 40, 41, 130, 131, 150, 199):   # kf.step = calls - failed calls, per filter
+            assert b.filter_step(i) == t + 1 - nfail[i], (t, i)
+    st = b.status()
+    assert sorted(np.nonzero(st)[0].tolist()) == [7, 40, 130, 150]
