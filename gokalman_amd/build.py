@@ -36,7 +36,9 @@ def _deps_mtime():
 # the two-lanes-per-filter SRIF kernel is ~10k instructions of straight-line code per variant: past LLVM's default budget for
 # `#pragma unroll` (16k cost units) a loop silently stays rolled, its register arrays become scratch arrays
 _PAIR = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]
-EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR}
+_UNROLL = ["-mllvm", "-pragma-unroll-threshold=200000"]
+EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR,
+         "kb_vanilla_split12.hip": _UNROLL, "kb_vanilla_split16.hip": _UNROLL}
 
 
 def _compile(src, force):

@@ -92,6 +92,15 @@ struct UniformCursor {
 template <typename T>
 __device__ __forceinline__ T ld_uniform_nt(const T *uniform_ptr, unsigned lane_bytes) { return UniformCursor<T>(uniform_ptr).load_nt(lane_bytes); }
 
+// compile-time loop: f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
+template <int B, int E, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sfor<B + 1, E>(f);
+    }
+}
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct Eps<float>  { static constexpr float  tiny = 1.17549435e-38f; };

@@ -101,15 +101,6 @@ __device__ __forceinline__ double root(double x) { return sqrt(x); }
 
 __device__ __forceinline__ int pnib(uint64_t perm, int r) { return (int)((perm >> (4 * r)) & 15u); }
 
-// compile-time loop: f(integral_constant<int, B>), ..., f(integral_constant<int, E - 1>)
-template <int B, int E, class F>
-__device__ __forceinline__ void sfor(F &&f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        sfor<B + 1, E>(f);
-    }
-}
-
 // SL rows x (2 HS + 1) columns in registers: HS column pairs per row and the last column apart.  All indices are compile-time
 // constants once the loops are unrolled.
 template <typename T, int SL, int HS>

@@ -564,5 +564,8 @@ bool launch_vanilla_strict(const Batch &b, const StepArgs &a);
 // batches whose filters all share ONE model (StepArgs::mo_ts == 0), fp64, one step per launch (kb_vanilla_shared.hip): the SHARED
 // instantiations (model read with the default cache policy) of the exact and padded kernels, Noiseless and AWGN / BatchNoise
 bool launch_vanilla_shared(const Batch &b, const StepArgs &a);
+// one filter split over L lanes (kb_vanilla_split.h): n <= 12, p <= 8, m <= 2 (kb_vanilla_split12.hip), fp64, one step per launch
+bool launch_vanilla_split12(const Batch &b, const StepArgs &a);
+bool launch_vanilla_split16(const Batch &b, const StepArgs &a);   // 13..16 states: eight lanes per filter
 
 }  // namespace kb

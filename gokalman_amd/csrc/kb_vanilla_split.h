@@ -1,0 +1,758 @@
+// kb_vanilla_split.h -- Vanilla.Update (vanilla.go:128-220) for 8 < n <= 16 with ONE FILTER SPLIT OVER L LANES.
+//
+// Why: with one filter per lane a 12-state step needs F (144) + P (78) + P- (78) + A (144) + ... values per lane, far beyond the
+// 128 doubles that leave two waves on a SIMD; the run-time-dimension kernel (kb_vanilla.hip) keeps them in 10-31 KB of scratch per
+// lane and runs at a few % of the HBM roof.  Here a wave owns 64 / L filters (L = 4 at n = 12: a quarter of an AoSoA-64 tile):
+//
+//   lane mapping   lane = q * (64 / L) + f: lanes with the same q read 64 / L consecutive filters of one element, i.e. one
+//                  contiguous 128-byte segment in fp64 at L = 4 (the mapping kb_srif_pair.h measured at the rate of the
+//                  one-filter-per-lane stream; the interleaved mapping lane = L f + q loses a quarter of the bandwidth).
+//   rows           lane q owns rows i = q, q + L, q + 2 L, ... of every n-row matrix (cyclic, so that the triangles balance): its
+//                  rows of F, of T = F P, of P-, of P- H^T, K, A = I - K H, A P- and P+ live in ITS registers -- n / L rows.
+//   broadcast      a product (own rows) x (whole matrix) needs the second operand in every lane of the filter: that operand sits
+//                  in LDS, [element][filter] (conflict-free: the L lanes of a filter read the same word), one n x n region per
+//                  wave that is reused phase by phase:  P (packed) -> F -> P- (packed) | H -> K.  150 doubles per filter at 12/6:
+//                  19.2 KB per wave, eight waves per CU = two per SIMD.
+//   sums over rows S = H (P- H^T) + R and H x- run over ALL rows: each lane sums its own rows and the L partial sums are added
+//                  with v_permlane32_swap / v_permlane16_swap (gfx950), identically in every lane; (H P- H^T + R)^-1 (p x p) is
+//                  then formed redundantly by the L lanes.
+//
+// Arithmetic: the reference's statements in the reference's order, with these rounding-level differences: sums over all rows are
+// added as L partial sums; S is the mirrored upper triangle; P- enters P- H^T with the lane's own computed entries right of
+// column L r and with the mirrored upper triangle left of it; and the Joseph update is evaluated as
+//     A = I - K H,  AP = A P-,  P+ = AP - (AP H^T - K R) K^T      [= A P- A^T + K R K^T, vanilla.go:197-205]
+// i.e. A and A P- as the reference forms them (the cancellation 1 - (K H)_ii happens inside A, as there), and only the second
+// multiplication by A^T = I - H^T K^T distributed: no n x n operand has to be broadcast for it (K and H are n x p).
+// Failure semantics as in kb_vanilla_reg.h: a filter whose S is singular / ill-conditioned or whose result is non-finite keeps
+// its previous estimate and gets a status bit (the reference's (nil, err)).
+#pragma once
+#include <type_traits>
+
+#include "kb_internal.h"
+#include "kb_vanilla_reg.h"
+
+namespace kb {
+
+// ---- sums over the L lanes of a filter (lanes 64 / L apart) -------------------------------------------------------------
+__device__ __forceinline__ unsigned other32(unsigned x) {   // the value held by the lane 32 away
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0] = [x.lo | x.lo], r[1] = [x.hi | x.hi]
+    return (threadIdx.x & 32u) ? r[0] : r[1];
+}
+template <typename T> __device__ __forceinline__ T sum32(T x);
+template <> __device__ __forceinline__ unsigned sum32<unsigned>(unsigned x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return r[0] | r[1];   // flags: OR
+}
+template <> __device__ __forceinline__ float sum32<float>(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <> __device__ __forceinline__ double sum32<double>(double x) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);   // (lower half's) + (upper half's): same order in both
+}
+template <typename T> __device__ __forceinline__ T sum16(T x);
+template <> __device__ __forceinline__ unsigned sum16<unsigned>(unsigned x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // r[0] = rows [0 0 2 2], r[1] = rows [1 1 3 3]
+    return r[0] | r[1];
+}
+template <> __device__ __forceinline__ float sum16<float>(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <> __device__ __forceinline__ double sum16<double>(double x) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+template <typename T> __device__ __forceinline__ T sum8(T x);   // lanes 8 apart inside a row of 16: DPP row_ror:8
+template <> __device__ __forceinline__ unsigned sum8<unsigned>(unsigned x) { return x | (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ float sum8<float>(float x) {
+    const float o = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128, 0xf, 0xf, false));
+    return (threadIdx.x & 8u) ? o + x : x + o;   // (lower lane's) + (upper lane's) in both
+}
+template <> __device__ __forceinline__ double sum8<double>(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x128, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x128, 0xf, 0xf, false);
+    const double o = __hiloint2double(hi, lo);
+    return (threadIdx.x & 8u) ? o + x : x + o;
+}
+// total over the L lanes of a filter, identical (bit for bit) in all of them
+template <int L, typename T>
+__device__ __forceinline__ T sum_lanes(T x) {
+    static_assert(L == 2 || L == 4 || L == 8, "lanes per filter");
+    x = sum32(x);
+    if constexpr (L >= 4) x = sum16(x);
+    if constexpr (L >= 8) x = sum8(x);
+    return x;
+}
+
+// LDS accesses of one phase become visible to the other lanes of the wave: DS operations of a wave execute in order, so all that
+// is needed is that the COMPILER keeps the stores in front of the loads (per thread they go to different addresses)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// mat64.Dense.Inverse of the p x p innovation covariance (kb_device.h inverse_lu: LU with partial pivoting, then the columns of the
+// inverse by substitution; error = exact zero pivot or |A|_inf |A^-1|_inf > 1e16) in two halves, so that the inverse never has to
+// exist as a whole next to the factors: lu_factor_any keeps L and U in place and records the row exchanges (they only run when
+// some lane of the wave pivots in that column: a wave-uniform test), lu_inverse_column returns one column of A^-1.
+template <typename T, int P>
+__device__ __forceinline__ bool lu_factor_any(T (&a)[P * P], unsigned &swaps, T &anorm, int nreal) {
+    anorm = T(0);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < P; j++) s += fabs(a[i * P + j]);
+        if (i < nreal) anorm = (s > anorm || s != s) ? s : anorm;
+    }
+    bool bad = false;
+    swaps = 0u;
+    int bit = 0;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        bool need = false;
+#pragma unroll
+        for (int r = j + 1; r < P; r++) need = need || fabs(a[r * P + j]) > fabs(a[j * P + j]);
+        if (__any(need)) {
+#pragma unroll
+            for (int r = j + 1; r < P; r++) {
+                const bool sw = fabs(a[r * P + j]) > fabs(a[j * P + j]);
+                swaps |= sw ? (1u << (bit + r - j - 1)) : 0u;
+#pragma unroll
+                for (int c = 0; c < P; c++) {   // whole rows: the multipliers move with their row (dlaswp)
+                    const T t0 = a[j * P + c], t1 = a[r * P + c];
+                    a[j * P + c] = sw ? t1 : t0;
+                    a[r * P + c] = sw ? t0 : t1;
+                }
+            }
+        }
+        bit += P - 1 - j;
+        const T piv = a[j * P + j];
+        bad = bad || (piv == T(0));
+        const T rp = T(1) / piv;
+        a[j * P + j] = rp;   // the solves multiply by the reciprocal (as inverse_lu does: s * (1 / a_ii))
+#pragma unroll
+        for (int r = j + 1; r < P; r++) {
+            const T l = a[r * P + j] * rp;
+            a[r * P + j] = l;
+#pragma unroll
+            for (int c = j + 1; c < P; c++) a[r * P + c] -= l * a[j * P + c];
+        }
+    }
+    return bad;
+}
+// column C of the inverse: the exchanges and the elimination replayed on e_C, then the back substitution
+template <typename T, int P, int C>
+__device__ __forceinline__ void lu_inverse_column(const T (&a)[P * P], unsigned swaps, T (&v)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; i++) v[i] = i == C ? T(1) : T(0);
+    if (__any(swaps != 0u)) {
+        int bit = 0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+#pragma unroll
+            for (int r = j + 1; r < P; r++) {
+                const bool sw = (swaps >> (bit + r - j - 1)) & 1u;
+                const T t0 = v[j], t1 = v[r];
+                v[j] = sw ? t1 : t0;
+                v[r] = sw ? t0 : t1;
+            }
+            bit += P - 1 - j;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < P; j++)
+#pragma unroll
+        for (int r = j + 1; r < P; r++) v[r] -= a[r * P + j] * v[j];
+#pragma unroll
+    for (int i = P - 1; i >= 0; i--) {
+        T s = v[i];
+#pragma unroll
+        for (int k = i + 1; k < P; k++) s -= a[i * P + k] * v[k];
+        v[i] = s * a[i * P + i];
+    }
+}
+
+template <int NS, int NM>
+constexpr int split_lds_elems() { return NS * NS > tri(NS) + NM * NS ? NS * NS : tri(NS) + NM * NS; }
+template <typename T, int NS, int NM, int L>
+constexpr int split_waves_per_simd() { return (int)sizeof(T) * split_lds_elems<NS, NM>() * (64 / L) * 8 <= 160 * 1024 ? 2 : 1; }
+
+#define KB_SB() __builtin_amdgcn_sched_barrier(0)
+
+// GEN = false: the batch has exactly this shape, Noiseless, FULL / PREDICT as given.  GEN = true: any n <= NS, p <= NM, m <= NC
+// (zero padding as in kb_vanilla_reg.h PAD: zeros, and an identity block in R), FULL / PREDICT / Noise taken from the launch
+// arguments (wave-uniform branches): ONE instantiation per (NS, NM) carries every other member of the family.
+//
+// Scheduling.  The kernel is ~4000 instructions of straight-line code, and left alone the machine scheduler gathers loads (170
+// global, 600 LDS) far ahead of their uses: 2 KB of spills per lane.  So every phase is written as a PIPELINE over chunks -- the LDS
+// operands of chunk c + 1 are requested, a scheduling barrier, the arithmetic of chunk c, a scheduling barrier -- and the global
+// loads of a later phase are requested where the registers for them are free: F, P, x first; Q when T = F P is done; H when the first
+// rows of P- are done; R, y, G, u behind that.  The other wave of the SIMD covers what latency this leaves exposed.
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT>
+__global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
+    static_assert(NS % L == 0, "rows are dealt out cyclically");
+    constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
+    constexpr int HOFF = TR;                       // LDS element offset of H (later: K) next to the packed P-
+    constexpr int KP = (TR + L - 1) / L;           // packed elements of P per lane
+    __shared__ T lds[(split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L) * FPW];
+    const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
+    const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
+    const bool predict = GEN ? a.predict != 0 : PREDT;
+    const unsigned lane = threadIdx.x;
+    const int q = (int)((lane / FPW) & (L - 1)), f = (int)(lane & (FPW - 1));
+    const int64_t gw = blockIdx.x;
+    const int64_t tile = gw / L;
+    const int slot = (int)(gw % L) * FPW + f;
+    if (tile * KB_TILE + (gw % L) * FPW >= a.N) return;
+    const int64_t fi = tile * KB_TILE + slot;
+    const bool active = fi < a.N;
+
+    // Addressing (as in kb_vanilla_reg.h): every base is WAVE-UNIFORM (blockIdx), element offsets are folded into it (scalar adds,
+    // instruction immediates), and the lane enters as ONE unsigned 32-bit element offset -- the scalar-base form of global_load,
+    // no 64-bit address pair per access.  The lane offsets: `us` the filter's slot in the tile; `uq` = us + 64 q: element (e + q)
+    // of the own filter (own rows of a vector, own share of a packed triangle, own columns of H); `uf` = us + 64 q n: row q of F.
+    T *const st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn)));
+    const T *const mo = (const T *)a.model + tile * a.mo_ts;
+    const unsigned us = (unsigned)slot;
+    const unsigned um = a.mo_ts ? (unsigned)slot : 0u;                       // model block of a shared-model batch: slot 0 of tile 0
+    const unsigned uq = (unsigned)slot + (unsigned)(q * KB_TILE);
+    const unsigned umq = um + (unsigned)(q * KB_TILE);
+    const unsigned uf = um + (unsigned)(q * rn * KB_TILE);
+    T *lf = lds + f;
+    // ep(base, rt, c): element (rt + c) of a block -- rt wave-uniform at run time, c a compile-time constant -- as (scalar anchor,
+    // made opaque to the optimiser) + (immediate within +-8 elements): left alone, instruction selection adds the part of c that
+    // does not fit the 13-bit immediate to the VECTOR half of the address (a 64-bit VGPR pair and a v_lshl_add_u64 per 8 elements).
+    typedef __attribute__((address_space(1))) T *gptr;   // (the asm hides where the pointer came from: say that it is global memory)
+    auto ep = [&](const T *ubase, int rt, int c) -> gptr {
+        const int anchor = (c >= 0 ? c / 16 : -((-c + 15) / 16)) * 16 + 8;
+        unsigned long long s = (unsigned long long)(ubase + (int64_t)(rt + anchor) * KB_TILE);
+        asm("" : "+s"(s));
+        return (gptr)s + (c - anchor) * KB_TILE;
+    };
+    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
+    auto ldst = [&](auto NT, int rt, int c, unsigned off) {   // state block, cache policy NT (kb_vanilla_reg.h)
+        const gptr pe = ep(st, rt, c) + off;
+        if constexpr (decltype(NT)::value) return __builtin_nontemporal_load(pe);
+        else return *pe;
+    };
+    auto stst = [&](auto NT, int rt, int c, unsigned off, T v) {
+        const gptr pe = ep(st, rt, c) + off;
+        if constexpr (decltype(NT)::value) __builtin_nontemporal_store(v, pe);
+        else *pe = v;
+    };
+    // own rows: i_r = q + L r; rowok[r]: a real row of this batch (GEN); rowany[r] (wave-uniform): some lane's row r is real
+    bool rowok[RP], rowany[RP];
+#pragma unroll
+    for (int r = 0; r < RP; r++) { rowok[r] = !GEN || q + L * r < rn; rowany[r] = !GEN || L * r < rn; }
+
+    // ---- phase 0: F (own rows), x, P (a packed share per lane, handed to LDS) ---------------------------------------------
+    T Fo[RP][NS], x[NS];
+    {
+        T Pp[KP];
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                // (a lane whose row is padding reads lane-group 0's row, which is real whenever rowany[r])
+                const T v = (rowany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, rowok[r] ? uf : um) : T(0);
+                Fo[r][l] = rowok[r] ? v : T(0);
+            }
+        auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const int e = L * k + q;
+                const bool okp = e < tri(rn);
+                const T v = L * k < tri(rn) ? ldst(NT, rn, L * k, okp ? uq : us) : T(0);
+                Pp[k] = okp ? v : T(0);
+            }
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                x[l] = l < rn ? ldst(NT, 0, l, us) : T(0);
+            }
+        };
+        KB_WITH_STATE_POLICY(a, load_state);
+        KB_SB();
+#pragma unroll
+        for (int k = 0; k < KP; k++) lf[(L * k + q) * FPW] = Pp[k];
+    }
+    wave_lds_fence();
+    KB_SB();
+
+    // ---- phase 1: x- = F x [+ G u], T = F P (own rows), one column of P per chunk -------------------------------------------
+    T xm[RP], Tm[RP][NS];
+    [[maybe_unused]] T xo[RP];   // x_prev[i_r] (FULL: yhat = H x_prev, vanilla.go:155-157)
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+        T s = T(0);
+#pragma unroll
+        for (int l = 0; l < NS; l++) s += Fo[r][l] * x[l];
+        xm[r] = s;
+        pin(xm[r]);
+        xo[r] = T(0);
+        if (full) {
+#pragma unroll
+            for (int l = L * r; l < L * r + L; l++) xo[r] = (l % L == q) ? x[l] : xo[r];
+        }
+    }
+    {
+        T col[2][NS];
+#pragma unroll
+        for (int l = 0; l < NS; l++) col[0][l] = lf[symi(l, 0) * FPW];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            if (k + 1 < NS) {
+#pragma unroll
+                for (int l = 0; l < NS; l++) col[(k + 1) & 1][l] = lf[symi(l, k + 1) * FPW];
+            }
+            KB_SB();
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += Fo[r][l] * col[k & 1][l];
+                Tm[r][k] = s;
+                pin(Tm[r][k]);   // (kb_device.h) the products stay in THIS chunk: without it instruction selection places them at their first use
+            }
+            KB_SB();
+        }
+    }
+
+    // ---- phase 2: F goes to LDS; P- = T F^T + Q for the own rows, columns j >= L r (the upper triangle and up to L - 1 entries
+    // left of the diagonal), one row of F per chunk ------------------------------------------------------------------------
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int l = 0; l < NS; l++) lf[((q + L * r) * NS + l) * FPW] = Fo[r][l];
+    T Pm[RP][NS];   // [r][j] for j >= L r; the other entries are never touched.  First Q, then P-
+    unsigned utri[RP];   // um + 64 tri(i_r)
+#pragma unroll
+    for (int r = 0; r < RP; r++) utri[r] = um + (unsigned)(((q + L * r) * (q + L * r + 1) / 2) * KB_TILE);
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int j = L * r; j < NS; j++) {
+            // Q[i_r][j]: packed element (i_r, j) = tri(j) + i_r right of the diagonal, (j, i_r) = tri(i_r) + j left of it
+            T v = T(0);
+            if (rowany[r] && j < rn) {
+                if (j >= L * r + L - 1) v = ldg(mo, a.L.mo_Q, j * (j + 1) / 2 + L * r, rowok[r] ? umq : um);
+                else v = ldg(mo, a.L.mo_Q, 0, !rowok[r] ? um : (j >= q + L * r ? umq + (unsigned)((j * (j + 1) / 2 + L * r) * KB_TILE) : utri[r] + (unsigned)(j * KB_TILE)));
+            }
+            Pm[r][j] = rowok[r] ? v : T(0);
+        }
+    if constexpr (NC > 0) {   // G u while F settles in LDS
+        if (rm > 0) {
+            const T *up = (const T *)a.u + tile * a.u_ts;
+            T u[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) u[c] = (active && c < rm) ? ldnt_at(&(up + (int64_t)c * a.u_es)[us]) : T(0);
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                T s = T(0);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const T g = (rowany[r] && c < rm) ? ldg(mo, a.L.mo_G + L * r * rm, c, rowok[r] ? um + (unsigned)(q * rm * KB_TILE) : um) : T(0);
+                    s += (rowok[r] ? g : T(0)) * u[c];
+                }
+                xm[r] = xm[r] + s;
+            }
+        }
+    }
+    wave_lds_fence();
+    KB_SB();
+    T Hp[NM][RP];   // H[c][i_r]: the lane's own columns of H
+    {
+        T row[2][NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) row[0][k] = lf[(0 * NS + k) * FPW];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            if (j + 1 < NS) {
+#pragma unroll
+                for (int k = 0; k < NS; k++) row[(j + 1) & 1][k] = lf[((j + 1) * NS + k) * FPW];
+            }
+            if (j == NS / 2) {   // H is requested when half of P- is done (T is still alive: no room earlier)
+#pragma unroll
+                for (int c = 0; c < NM; c++)
+#pragma unroll
+                    for (int r = 0; r < RP; r++) {
+                        const T v = (rowany[r] && c < rp) ? ldg(mo, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um) : T(0);
+                        Hp[c][r] = rowok[r] ? v : T(0);
+                    }
+            }
+            KB_SB();
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+                if (L * r <= j) {
+                    T s = T(0);
+#pragma unroll
+                    for (int k = 0; k < NS; k++) s += Tm[r][k] * row[j & 1][k];
+                    Pm[r][j] = s + Pm[r][j];
+                    pin(Pm[r][j]);
+                }
+            KB_SB();
+        }
+    }
+
+    // ---- phase 3: P- (upper triangle, packed) and H go to LDS; R, y are requested ---------------------------------------------
+    // R is needed twice -- in S = H P- H^T + R and in the Joseph form's K R K^T -- with the p x p factorisation in between, where 21
+    // more values do not fit: it is read twice, the first time with the default cache policy (the second read finds it in the L2)
+    auto load_R = [&](T (&R)[TM], auto NT) {
+#pragma unroll
+        for (int c = 0; c < NM; c++)
+#pragma unroll
+            for (int r = 0; r <= c; r++) {
+                const gptr pr = ep(mo, a.L.mo_R, symi(r, c)) + um;
+                R[symi(r, c)] = c < rp ? (decltype(NT)::value ? __builtin_nontemporal_load(pr) : *pr) : (r == c ? T(1) : T(0));
+            }
+    };
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int j = L * r; j < NS; j++) {
+            if (j >= L * r + L - 1 || j >= q + L * r) lf[(j * (j + 1) / 2 + q + L * r) * FPW] = Pm[r][j];
+        }
+#pragma unroll
+    for (int c = 0; c < NM; c++)
+#pragma unroll
+        for (int r = 0; r < RP; r++) lf[(HOFF + c * NS + q + L * r) * FPW] = Hp[c][r];
+    wave_lds_fence();
+    KB_SB();
+    // P- from here on: the mirrored upper triangle in LDS (what AsSymDense returns, helper.go:65-84).  Own row i_r, column l:
+    // packed element (l, i_r) for l < i_r -- at lrow[r] + l -- and (i_r, l) for l >= i_r -- at lcol[l] + i_r
+    const T *lrow[RP];
+#pragma unroll
+    for (int r = 0; r < RP; r++) { const int i = q + L * r; lrow[r] = lf + (i * (i + 1) / 2) * FPW; }
+    const T *lq = lf + q * FPW;
+    auto pm_own = [&](int r, int l) -> T {   // r, l compile-time after unrolling
+        if (l >= L * r + L - 1) return lq[(l * (l + 1) / 2 + L * r) * FPW];
+        if (l < L * r) return lrow[r][l * FPW];
+        return *(l >= q + L * r ? lq + (l * (l + 1) / 2 + L * r) * FPW : lrow[r] + l * FPW);
+    };
+    // ---- P- H^T (own rows), two columns of P- / H per chunk ----------------------------------------------------------------
+    T PHt[RP][NM];
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int c = 0; c < NM; c++) PHt[r][c] = T(0);
+    {
+        constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+        T hb[2][CH][NM], pb[2][CH][RP];
+        auto fetch = [&](int ch, int b) {
+#pragma unroll
+            for (int d = 0; d < CH; d++) {
+                const int l = ch * CH + d;
+                if (l < NS) {
+#pragma unroll
+                    for (int c = 0; c < NM; c++) hb[b][d][c] = lf[(HOFF + c * NS + l) * FPW];
+#pragma unroll
+                    for (int r = 0; r < RP; r++) pb[b][d][r] = pm_own(r, l);
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            if (ch + 1 < NCH) fetch(ch + 1, (ch + 1) & 1);
+            KB_SB();
+#pragma unroll
+            for (int d = 0; d < CH; d++)
+                if (ch * CH + d < NS) {
+#pragma unroll
+                    for (int c = 0; c < NM; c++)
+#pragma unroll
+                        for (int r = 0; r < RP; r++) PHt[r][c] += pb[ch & 1][d][r] * hb[ch & 1][d][c];
+                }
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NM; c++) pin(PHt[r][c]);
+            KB_SB();
+        }
+    }
+    // ---- S = H P- H^T + R (upper triangle), H x-, [H x_prev]: partial sums over the own rows, then over the L lanes --------
+    T S[NM * NM], innov[NM];
+    [[maybe_unused]] T yhat[NM];
+    {
+        T R[TM], y[NM];
+        load_R(R, std::false_type{});
+        {
+            const T *yp = (const T *)a.y + tile * a.y_ts;
+#pragma unroll
+            for (int r = 0; r < NM; r++) y[r] = (!predict && active && r < rp) ? ldnt_at(&(yp + (int64_t)r * a.y_es)[us]) : T(0);
+        }
+        KB_SB();
+        T part[TM];
+#pragma unroll
+        for (int c2 = 0; c2 < NM; c2++)
+#pragma unroll
+            for (int c1 = 0; c1 <= c2; c1++) {
+                T s = T(0);
+#pragma unroll
+                for (int r = 0; r < RP; r++) s += Hp[c1][r] * PHt[r][c2];
+                part[symi(c1, c2)] = s;
+            }
+#pragma unroll
+        for (int c = 0; c < NM; c++) {
+            T s = T(0);
+#pragma unroll
+            for (int r = 0; r < RP; r++) s += Hp[c][r] * xm[r];
+            innov[c] = predict ? T(0) : y[c] - sum_lanes<L>(s);   // vanilla.go:183-184
+            pin(innov[c]);
+            if (full) {
+                T s2 = T(0);
+#pragma unroll
+                for (int r = 0; r < RP; r++) s2 += Hp[c][r] * xo[r];
+                yhat[c] = sum_lanes<L>(s2);
+            }
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < NM; c2++)
+#pragma unroll
+            for (int c1 = 0; c1 <= c2; c1++) {
+                const T v = sum_lanes<L>(part[symi(c1, c2)]) + R[symi(c1, c2)];
+                S[c1 * NM + c2] = v;
+                pin(S[c1 * NM + c2]);
+                if (c1 == c2) KB_SB();   // column by column
+            }
+#pragma unroll
+        for (int c2 = 0; c2 < NM; c2++)
+#pragma unroll
+            for (int c1 = 0; c1 < c2; c1++) S[c2 * NM + c1] = S[c1 * NM + c2];
+    }
+    KB_SB();
+    // ---- K = P- H^T S^-1 (own rows), column by column of the inverse; the same bits in the L lanes of a filter ---------------
+    unsigned err = 0, swaps;
+    T K[RP][NM];
+    {
+        T anorm, inorm = T(0), rows[NM];
+        if (lu_factor_any<T, NM>(S, swaps, anorm, rp)) err = KB_ST_SINGULAR;
+#pragma unroll
+        for (int i = 0; i < NM; i++) rows[i] = T(0);
+        sfor<0, NM>([&](auto C) __attribute__((always_inline)) {
+            constexpr int c = C;
+            T v[NM];
+            lu_inverse_column<T, NM, c>(S, swaps, v);
+#pragma unroll
+            for (int i = 0; i < NM; i++) rows[i] += fabs(v[i]);
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                T s = T(0);
+#pragma unroll
+                for (int k = 0; k < NM; k++) s += PHt[r][k] * v[k];
+                K[r][c] = s;
+                pin(K[r][c]);
+            }
+#pragma unroll
+            for (int i = 0; i < NM; i++) pin(rows[i]);
+            KB_SB();   // one column at a time: interleaved, the six independent solves keep six sets of temporaries alive
+        });
+#pragma unroll
+        for (int i = 0; i < NM; i++)
+            if (i < rp) inorm = (rows[i] > inorm || rows[i] != rows[i]) ? rows[i] : inorm;
+        if (!(anorm * inorm <= T(1e16))) err = KB_ST_SINGULAR;
+    }
+    KB_SB();
+
+    T xn[RP];
+    T Pn[RP][NS];   // P+, own rows, columns j >= L r
+    if (predict) {
+        // vanilla.go:170-179: estimate = {x-, yhat, 0, sym(P-), sym(P-), K}
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            xn[r] = xm[r];
+#pragma unroll
+            for (int j = L * r; j < NS; j++) Pn[r][j] = Pm[r][j];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
+            xn[r] = xm[r] + s;
+        }
+        // ---- Joseph form (see the header): A = I - K H column by column, AP = A P- accumulated row of P- by row of P- ------------
+        T AP[RP][NS];
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int k = 0; k < NS; k++) AP[r][k] = T(0);
+        {
+            T hb[2][NM], pb[2][NS];
+            auto fetch = [&](int l, int b) {
+#pragma unroll
+                for (int c = 0; c < NM; c++) hb[b][c] = lf[(HOFF + c * NS + l) * FPW];
+#pragma unroll
+                for (int k = 0; k < NS; k++) pb[b][k] = lf[symi(l, k) * FPW];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                if (l + 1 < NS) fetch(l + 1, (l + 1) & 1);
+                KB_SB();
+                T al[RP];
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int c = 0; c < NM; c++) s += K[r][c] * hb[l & 1][c];
+                    al[r] = ((l / L == r && l % L == q) ? T(1) : T(0)) - s;
+                }
+#pragma unroll
+                for (int r = 0; r < RP; r++)
+#pragma unroll
+                    for (int k = 0; k < NS; k++) { AP[r][k] += al[r] * pb[l & 1][k]; pin(AP[r][k]); }
+                KB_SB();
+            }
+        }
+        // V = K R - AP H^T (own rows): W = AP H^T first, two columns of H per chunk, with R on its way again
+        T V[RP][NM];
+        {
+            constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+            T R[TM];
+            T hb[2][CH][NM];
+            auto fetch = [&](int ch, int b) {
+#pragma unroll
+                for (int d = 0; d < CH; d++)
+                    if (ch * CH + d < NS) {
+#pragma unroll
+                        for (int c = 0; c < NM; c++) hb[b][d][c] = lf[(HOFF + c * NS + ch * CH + d) * FPW];
+                    }
+            };
+            fetch(0, 0);
+            load_R(R, std::true_type{});
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NM; c++) V[r][c] = T(0);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch + 1 < NCH) fetch(ch + 1, (ch + 1) & 1);
+                KB_SB();
+#pragma unroll
+                for (int d = 0; d < CH; d++)
+                    if (ch * CH + d < NS) {
+#pragma unroll
+                        for (int c = 0; c < NM; c++)
+#pragma unroll
+                            for (int r = 0; r < RP; r++) V[r][c] -= AP[r][ch * CH + d] * hb[ch & 1][d][c];
+                    }
+#pragma unroll
+                for (int r = 0; r < RP; r++)
+#pragma unroll
+                    for (int c = 0; c < NM; c++) pin(V[r][c]);
+                KB_SB();
+            }
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NM; c++) {
+                    T s = V[r][c];
+#pragma unroll
+                    for (int k = 0; k < NM; k++) s += K[r][k] * R[symi(k, c)];
+                    V[r][c] = s;
+                    pin(V[r][c]);
+                }
+            KB_SB();
+        }
+        // K takes H's place in LDS (P- stays: the FULL estimate stores it from there), P+ = AP + V K^T, two rows of K per chunk
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) lf[(HOFF + (q + L * r) * NM + c) * FPW] = K[r][c];
+        wave_lds_fence();
+        KB_SB();
+        {
+            constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+            T kb[2][CH][NM];
+            auto fetch = [&](int ch, int b) {
+#pragma unroll
+                for (int d = 0; d < CH; d++)
+                    if (ch * CH + d < NS) {
+#pragma unroll
+                        for (int c = 0; c < NM; c++) kb[b][d][c] = lf[(HOFF + (ch * CH + d) * NM + c) * FPW];
+                    }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch + 1 < NCH) fetch(ch + 1, (ch + 1) & 1);
+                KB_SB();
+#pragma unroll
+                for (int d = 0; d < CH; d++) {
+                    const int j = ch * CH + d;
+                    if (j < NS) {
+#pragma unroll
+                        for (int r = 0; r < RP; r++)
+                            if (L * r <= j) {
+                                T s = AP[r][j];
+#pragma unroll
+                                for (int c = 0; c < NM; c++) s += V[r][c] * kb[ch & 1][d][c];
+                                Pn[r][j] = s;
+                                pin(Pn[r][j]);
+                            }
+                    }
+                }
+                KB_SB();
+            }
+        }
+    }
+    // ---- non-finite screen over the own entries (stands in for AsSymDense's NaN-failing comparison), then over the L lanes
+    {
+        T chk = T(0);
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            chk += xn[r] * T(0);
+#pragma unroll
+            for (int j = L * r; j < NS; j++) chk += Pn[r][j] * T(0);
+        }
+        err |= sum_lanes<L>((chk != chk) ? (unsigned)KB_ST_NONFINITE : 0u);
+    }
+    const bool ok = err == 0;
+    if (active && ok) {
+        auto store_state = [&](auto NT) {
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                if (rowok[r]) stst(NT, 0, L * r, uq, xn[r]);
+#pragma unroll
+                for (int j = L * r; j < NS; j++)
+                    if (rowok[r] && j < rn && (j >= L * r + L - 1 || j >= q + L * r)) stst(NT, rn, j * (j + 1) / 2 + L * r, uq, Pn[r][j]);
+            }
+        };
+        KB_WITH_STATE_POLICY(a, store_state);
+        if (full) {   // the Estimate's extras: P- (from LDS: the lane's share of the packed triangle), K (own rows), innovation, yhat
+            T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const int e = L * k + q;
+                if (e < tri(rn)) __builtin_nontemporal_store(lf[e * FPW], ep(es, a.L.es_ppred, L * k) + uq);
+            }
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NM; c++)
+                    if (rowok[r] && c < rp) __builtin_nontemporal_store(K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < NM; c++)
+                    if (c < rp) {
+                        __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
+                        __builtin_nontemporal_store(yhat[c], ep(es, a.L.es_yhat, c) + us);
+                    }
+            }
+        }
+    }
+    if (active && err && q == 0) fail_step(a, fi, err);   // vanilla.go:164-167, :207-215 return before kf.step++ (:218)
+}
+#undef KB_SB
+
+}  // namespace kb

@@ -1,0 +1,27 @@
+// kb_vanilla_split12.hip -- Vanilla.Update with one filter split over four lanes (kb_vanilla_split.h): 12 states.
+//   exact 12 / 6 / 0, Noiseless: the orbit-determination-sized shape the SRIF benchmark (config E) uses, per-filter models
+//   GEN <12, 8, 2>: every other shape with n <= 12, p <= 8, m <= 2 that has no one-filter-per-lane register kernel
+#include "kb_vanilla_split.h"
+
+namespace kb {
+
+template <typename T, int NS, int NM, int NC, int L>
+static bool split_exact(const Batch &b, const StepArgs &a) {
+    if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    const dim3 grid((unsigned)(a.ntiles * L)), block(64);
+#define KB_GO(F_, P_) hipLaunchKernelGGL((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_>), grid, block, 0, b.stream, a)
+    if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
+    else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
+#undef KB_GO
+    return true;
+}
+
+bool launch_vanilla_split12(const Batch &b, const StepArgs &a) {
+    if (b.dtype != KB_F64 || a.n > 12 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
+    if (split_exact<double, 12, 6, 0, 4>(b, a)) return true;
+    hipLaunchKernelGGL((vanilla_split_kernel<double, 12, 8, 2, 4, true, false, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
+    return true;
+}
+
+}  // namespace kb

@@ -1,0 +1,13 @@
+// kb_vanilla_split16.hip -- Vanilla.Update with one filter split over eight lanes (kb_vanilla_split.h): 13..16 states
+// (any p <= 8, m <= 2): two rows per lane, eight filters per wave, 17 KB of LDS per wave (two waves per SIMD).
+#include "kb_vanilla_split.h"
+
+namespace kb {
+
+bool launch_vanilla_split16(const Batch &b, const StepArgs &a) {
+    if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
+    hipLaunchKernelGGL((vanilla_split_kernel<double, 16, 8, 2, 8, true, false, false>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
+    return true;
+}
+
+}  // namespace kb

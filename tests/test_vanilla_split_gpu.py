@@ -1,0 +1,151 @@
+"""Vanilla.Update (vanilla.go:128-220) beyond 8 states: the kernels that split ONE filter over several lanes
+(gokalman_amd/csrc/kb_vanilla_split.h) against the CPU oracle, through the C ABI.
+
+* 12 states / 6 measurements (the orbit-determination size of SURVEY 8d's config E) at 4096 filters x 20 steps, per-filter models,
+  device-resident measurements: <= 1e-9 relative Frobenius on state and covariance (BASELINE.json north_star);
+* the padded family: every n in 9..16, p <= 8, m <= 2, with and without KB_FLAG_FULL_ESTIMATE (all Estimate members), random dense
+  H (so that the p x p factorisation pivots), control input, pure predictor, AWGN / BatchNoise replayed through the oracle;
+* failure semantics: a singular innovation covariance skips that filter's step only (vanilla.go:164-167), kf.step stands still."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from gokalman_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _model(N, n, p, m, steps, seed):
+    rng = np.random.default_rng(seed)
+    F = np.eye(n) + 0.05 * rng.standard_normal((N, n, n))
+    H = rng.standard_normal((N, p, n))
+    A = rng.standard_normal((N, n, n))
+    Q = 1e-3 * np.einsum("nij,nkj->nik", A, A) + 1e-4 * np.eye(n)
+    B = rng.standard_normal((N, p, p))
+    R = 1e-2 * np.einsum("nij,nkj->nik", B, B) + np.exp(rng.uniform(np.log(1e-3), np.log(1e-1), size=(N, p)))[:, :, None] * np.eye(p)
+    G = rng.standard_normal((N, n, m)) if m else None
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = rng.uniform(1.0, 10.0, size=(N, n))
+    y = rng.standard_normal((steps, N, p))
+    u = rng.standard_normal((steps, N, m)) if m else None
+    return dict(x0=x0, P0=P0, F=F, H=H, Q=Q, R=R, G=G, y=y, u=u)
+
+
+def _oracle(d, kind, steps, filters=None):
+    N = d["x0"].shape[0]
+    out = []
+    for i in (range(N) if filters is None else filters):
+        f = orc.Filter.ldkf(kind, d["x0"][i], d["P0"][i], d["F"][i], None if d["G"] is None else d["G"][i], d["H"][i], d["Q"][i], d["R"][i])
+        for t in range(steps):
+            rc = f.update(d["y"][t, i], None if d["u"] is None else d["u"][t, i])
+            assert rc == orc.OK
+        out.append(f)
+    return out
+
+
+def test_split_12x6_at_4096_filters_20_steps_device_path_vs_oracle():
+    import torch
+    N, steps = 4096 + 21, 20   # (a batch that ends inside a quarter-tile)
+    d = synth.linear_batch(N, 12, 6, steps)
+    d["G"] = d["u"] = None
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    y_planar = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()  # [T][p][N]
+    for t in range(steps):
+        b.update_dev(y_planar[t].data_ptr(), N)
+    b.synchronize()
+    assert b.step() == steps and not b.status().any()
+    xo, Po, nerr = orc.ldkf_batch(orc.VANILLA, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+    assert nerr == 0
+    assert synth.rel_frobenius(b.get(k.STATE), xo) <= TOL
+    assert synth.rel_frobenius(b.get(k.COVAR), Po) <= TOL
+    # the same steps through kb_update_steps_dev (one register launch per step) are the same bits
+    b2 = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    b2.update_steps_dev(y_planar.data_ptr(), N, steps)
+    b2.synchronize()
+    assert np.array_equal(b2.get(k.STATE), b.get(k.STATE)) and np.array_equal(b2.get(k.COVAR), b.get(k.COVAR))
+
+
+SHAPES = [(9, 1, 0), (9, 4, 1), (10, 5, 2), (11, 7, 0), (12, 6, 0), (12, 8, 2), (12, 3, 1), (8, 6, 0), (7, 5, 2),
+          (13, 2, 0), (14, 8, 1), (15, 7, 2), (16, 8, 2), (16, 6, 0)]
+
+
+@pytest.mark.parametrize("n,p,m", SHAPES)
+@pytest.mark.parametrize("full", [False, True])
+def test_split_padded_family_vs_oracle(n, p, m, full):
+    N, steps = 150, 6
+    d = _model(N, n, p, m, steps, 1000 * n + 10 * p + m)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE if full else 0)
+    for t in range(steps):
+        est = b.update(d["y"][t], None if m == 0 else d["u"][t])
+    fs = _oracle(d, orc.VANILLA, steps)
+    assert not b.status().any()
+    assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= TOL
+    assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= TOL
+    if full:
+        assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in fs])) <= TOL
+        assert synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) <= TOL
+        assert np.max(np.abs(est.innovation() - np.array([f.innovation() for f in fs]))) <= 1e-8
+        assert np.max(np.abs(est.measurement() - np.array([f.measurement() for f in fs]))) <= 1e-8
+
+
+@pytest.mark.parametrize("n,p,m", [(12, 6, 0), (10, 3, 1), (16, 8, 0)])
+def test_split_pure_predictor_vs_oracle(n, p, m):
+    N, steps = 100, 5
+    d = _model(N, n, p, m, steps, 77 + n)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    for t in range(steps):
+        est = b.update(d["y"][t], None if m == 0 else d["u"][t])
+    fs = _oracle(d, orc.VANILLA_PREDICT, steps)
+    assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= TOL
+    assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= TOL
+    assert synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) <= TOL
+    assert np.max(np.abs(est.innovation())) == 0.0
+
+
+@pytest.mark.parametrize("n,p", [(12, 6), (11, 4), (16, 8)])
+def test_split_singular_innovation_skips_that_filter_only(n, p):
+    """H = 0 and R = 0 make H P- H^T + R exactly singular: (nil, err) before kf.step++ (vanilla.go:164-167, :218); the filter's
+    neighbours in the wave -- and the other lanes of the filter itself -- carry on."""
+    N, steps = 200, 4
+    d = _model(N, n, p, 0, steps, 5 + n)
+    bad = [3, 17, 64, 199]
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    fs = [orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]) for i in range(N)]
+    Hbad, Rbad = d["H"].copy(), d["R"].copy()
+    Hbad[bad] = 0.0
+    Rbad[bad] = 0.0
+    for t in range(steps):
+        if t == 1:   # SetMeasurementMatrix / SetNoise between steps (kalman.go:44-47)
+            b.set_measurement_matrix(Hbad); b.set_noise(d["Q"], Rbad)
+        if t == 2:
+            b.set_measurement_matrix(d["H"]); b.set_noise(d["Q"], d["R"])
+        b.update(d["y"][t])
+        for i, f in enumerate(fs):
+            if t == 1 and i in bad:
+                f.set_measurement_matrix(Hbad[i]); f.set_noise(d["Q"][i], Rbad[i])
+            if t == 2 and i in bad:
+                f.set_measurement_matrix(d["H"][i]); f.set_noise(d["Q"][i], d["R"][i])
+            rc = f.update(d["y"][t, i])
+            assert rc == (orc.ERR_SINGULAR if (t == 1 and i in bad) else orc.OK)
+        st = b.status()
+        assert sorted(np.nonzero(st)[0].tolist()) == (bad if t >= 1 else [])
+        assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= TOL, t
+        assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= TOL, t
+    for i in (2, 3, 4, 64, 65):
+        assert b.filter_step(i) == steps - (1 if i in bad else 0)
+
+
+def test_split_batches_keep_the_other_kernels_bits_for_small_shapes():
+    """Shapes the one-filter-per-lane kernels cover stay on them: an 8 / 4 batch run with KB_FLAG_STATEMENT_KERNELS and without agree
+    to rounding, and a 12 / 6 batch equals the statement kernel to 1e-12 (different summation order, same arithmetic)."""
+    N, steps = 130, 5
+    d = synth.linear_batch(N, 12, 6, steps)
+    a = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    s = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_STATEMENT_KERNELS)
+    for t in range(steps):
+        a.update(d["y"][t]); s.update(d["y"][t])
+    assert synth.rel_frobenius(a.get(k.STATE), s.get(k.STATE)) <= 1e-12
+    assert synth.rel_frobenius(a.get(k.COVAR), s.get(k.COVAR)) <= 1e-12
