@@ -101,6 +101,19 @@ __device__ __forceinline__ void sfor(F &&f) {
     }
 }
 
+// 1 / x from the hardware reciprocal (1 ulp) refined by Newton steps: 3 (fp32) / 5 (fp64) instructions where the IEEE
+// division sequence takes 10 / 15.  The result is within an ulp of the correctly rounded quotient; x = 0 gives a non-finite
+// value as 1 / 0 does (the callers flag a zero divisor themselves).
+__device__ __forceinline__ float recip(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+__device__ __forceinline__ double recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct Eps<float>  { static constexpr float  tiny = 1.17549435e-38f; };

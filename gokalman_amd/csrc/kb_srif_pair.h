@@ -81,19 +81,6 @@ __device__ __forceinline__ T from_half(T x, int h) {
     return h ? hi : lo;
 }
 
-// 1 / x from the hardware reciprocal (1 ulp) refined by Newton steps: 3 (fp32) / 5 (fp64) instructions where the IEEE
-// division sequence takes 10 / 15.  The result is within an ulp of the correctly rounded quotient; x = 0 gives a non-finite
-// value as 1 / 0 does (the callers flag a zero divisor themselves).
-__device__ __forceinline__ float recip(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(r, fmaf(-x, r, 1.0f), r);
-}
-__device__ __forceinline__ double recip(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(r, fma(-x, r, 1.0), r);
-    return fma(r, fma(-x, r, 1.0), r);
-}
-
 // sqrt: fp32 takes the hardware instruction (1 ulp) in place of the correctly rounded sequence the compiler expands sqrtf()
 // into (15 instructions, once per Householder column); fp64 keeps the library expansion
 __device__ __forceinline__ float root(float x) { return __builtin_amdgcn_sqrtf(x); }

@@ -259,7 +259,8 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
         if (!done && b.dtype == KB_F64 && !fused) done = launch_vanilla_padded(b, a) || launch_vanilla_padded8(b, a);
     }
     // shapes beyond the one-filter-per-lane kernels (n <= 16, p <= 8, m <= 2): one filter split over four lanes, kb_vanilla_split.h
-    if (!done && special && b.dtype == KB_F64 && !fused && a.nsteps == 1) done = launch_vanilla_split12(b, a) || launch_vanilla_split16(b, a);
+    if (!done && reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && b.dtype == KB_F64 && !fused && a.nsteps == 1)
+        done = launch_vanilla_split12(b, a) || launch_vanilla_split16(b, a);
     if (!done) {
         const int d = a.n > a.p ? (a.n > a.m ? a.n : a.m) : (a.p > a.m ? a.p : a.m);
         const dim3 grid((unsigned)a.ntiles), block(64);

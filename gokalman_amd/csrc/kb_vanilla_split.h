@@ -20,9 +20,11 @@
 // Arithmetic: the reference's statements in the reference's order, with these rounding-level differences: sums over all rows are
 // added as L partial sums; S is the mirrored upper triangle; P- enters P- H^T with the lane's own computed entries right of
 // column L r and with the mirrored upper triangle left of it; and the Joseph update is evaluated as
-//     A = I - K H,  AP = A P-,  P+ = AP - (AP H^T - K R) K^T      [= A P- A^T + K R K^T, vanilla.go:197-205]
-// i.e. A and A P- as the reference forms them (the cancellation 1 - (K H)_ii happens inside A, as there), and only the second
-// multiplication by A^T = I - H^T K^T distributed: no n x n operand has to be broadcast for it (K and H are n x p).
+//     AP = P- - K (P- H^T)^T  [= (I - K H) P-],   P+ = AP - (AP H^T - K R) K^T      [= A P- A^T + K R K^T, vanilla.go:197-205]
+// i.e. both multiplications by A = I - K H distributed: no n x n operand has to be formed or broadcast for them (K, H and P- H^T
+// are n x p), 650 FMAs per lane less than A = I - K H, A P-, (A P-) A^T.  The rounding error of AP is of the size the reference's
+// A P- has (there the cancellation 1 - (K H)_ii sits inside A, here in the subtraction: both leave eps |P-|), and AP H^T is formed
+// from the COMPUTED AP, so that error is multiplied by A^T as in the reference's product -- the property of the Joseph form.
 // Failure semantics as in kb_vanilla_reg.h: a filter whose S is singular / ill-conditioned or whose result is non-finite keeps
 // its previous estimate and gets a status bit (the reference's (nil, err)).
 #pragma once
@@ -88,6 +90,46 @@ __device__ __forceinline__ T sum_lanes(T x) {
     return x;
 }
 
+// Two values at a time: one exchange hands a's partner value to the lower lanes and b's to the upper lanes (v_permlane*_swap moves
+// both directions at once), one add forms both totals, a second exchange spreads them: 7 instructions per stage for two fp64
+// values where two single sums take 10.  Same additions in the same order as sum_lanes, so the same bits.
+__device__ __forceinline__ void pair32(double &a, double &b) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    const double t = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);   // [a.lo + a.hi | b.lo + b.hi]
+    const auto tl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(t), (unsigned)__double2loint(t), false, false);
+    const auto th = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(t), (unsigned)__double2hiint(t), false, false);
+    a = __hiloint2double((int)th[0], (int)tl[0]);
+    b = __hiloint2double((int)th[1], (int)tl[1]);
+}
+__device__ __forceinline__ void pair16(double &a, double &b) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    const double t = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);   // rows [a0 + a1, b0 + b1, a2 + a3, b2 + b3]
+    const auto tl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(t), (unsigned)__double2loint(t), false, false);
+    const auto th = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(t), (unsigned)__double2hiint(t), false, false);
+    a = __hiloint2double((int)th[0], (int)tl[0]);
+    b = __hiloint2double((int)th[1], (int)tl[1]);
+}
+template <int L, typename T>
+__device__ __forceinline__ void sum_lanes2(T &a, T &b) {
+    if constexpr (std::is_same<T, double>::value && L == 4) {
+        pair32(a, b);
+        pair16(a, b);
+    } else {
+        a = sum_lanes<L>(a);
+        b = sum_lanes<L>(b);
+    }
+}
+
+// threadIdx.x as a value the optimiser cannot connect to earlier uses: what is derived from it HERE is computed here, not kept alive
+// from the top of the kernel (address terms that are needed once, late)
+__device__ __forceinline__ unsigned late_lane() {
+    unsigned t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // LDS accesses of one phase become visible to the other lanes of the wave: DS operations of a wave execute in order, so all that
 // is needed is that the COMPILER keeps the stores in front of the loads (per thread they go to different addresses)
 __device__ __forceinline__ void wave_lds_fence() {
@@ -134,7 +176,7 @@ __device__ __forceinline__ bool lu_factor_any(T (&a)[P * P], unsigned &swaps, T 
         bit += P - 1 - j;
         const T piv = a[j * P + j];
         bad = bad || (piv == T(0));
-        const T rp = T(1) / piv;
+        const T rp = recip(piv);   // (kb_device.h: within an ulp of 1 / piv, a third of the instructions)
         a[j * P + j] = rp;   // the solves multiply by the reciprocal (as inverse_lu does: s * (1 / a_ii))
 #pragma unroll
         for (int r = j + 1; r < P; r++) {
@@ -164,11 +206,18 @@ __device__ __forceinline__ void lu_inverse_column(const T (&a)[P * P], unsigned 
             }
             bit += P - 1 - j;
         }
+#pragma unroll
+        for (int j = 0; j < P; j++)
+#pragma unroll
+            for (int r = j + 1; r < P; r++) v[r] -= a[r * P + j] * v[j];
+    } else {
+        // nobody in the wave pivoted: e_C is still e_C, rows above C stay zero through the elimination (the same operations on the
+        // non-zero part; the skipped ones would subtract exact zeros)
+#pragma unroll
+        for (int j = C; j < P; j++)
+#pragma unroll
+            for (int r = j + 1; r < P; r++) v[r] -= a[r * P + j] * v[j];
     }
-#pragma unroll
-    for (int j = 0; j < P; j++)
-#pragma unroll
-        for (int r = j + 1; r < P; r++) v[r] -= a[r * P + j] * v[j];
 #pragma unroll
     for (int i = P - 1; i >= 0; i--) {
         T s = v[i];
@@ -184,6 +233,20 @@ template <typename T, int NS, int NM, int L>
 constexpr int split_waves_per_simd() { return (int)sizeof(T) * split_lds_elems<NS, NM>() * (64 / L) * 8 <= 160 * 1024 ? 2 : 1; }
 
 #define KB_SB() __builtin_amdgcn_sched_barrier(0)
+// Where the later operands are requested (A/B on the box, profiles/NOTES.md): "as late as the registers' first use allows" beat
+// every earlier placement -- the kernel is not short of requests in flight, and early requests cost registers (spills)
+#ifndef KB_SPLIT_HJ
+#define KB_SPLIT_HJ (NS / 2)
+#endif
+#ifndef KB_SPLIT_RL
+#define KB_SPLIT_RL NS   // < NS: R is requested again at that step of the A P- loop; NS: at the start of the loop behind it
+#endif
+#ifndef KB_SPLIT_R1LATE
+#define KB_SPLIT_R1LATE 1
+#endif
+#ifndef KB_SPLIT_QK
+#define KB_SPLIT_QK NS   // < NS: Q is requested at that step of the T = F P loop; NS: when F has gone to LDS
+#endif
 
 // GEN = false: the batch has exactly this shape, Noiseless, FULL / PREDICT as given.  GEN = true: any n <= NS, p <= NM, m <= NC
 // (zero padding as in kb_vanilla_reg.h PAD: zeros, and an identity block in R), FULL / PREDICT / Noise taken from the launch
@@ -194,19 +257,26 @@ constexpr int split_waves_per_simd() { return (int)sizeof(T) * split_lds_elems<N
 // operands of chunk c + 1 are requested, a scheduling barrier, the arithmetic of chunk c, a scheduling barrier -- and the global
 // loads of a later phase are requested where the registers for them are free: F, P, x first; Q when T = F P is done; H when the first
 // rows of P- are done; R, y, G, u behind that.  The other wave of the SIMD covers what latency this leaves exposed.
+template <typename T, int NS, int NM, int L, bool GEN, bool FULLT>
+constexpr int split_lds_total() {
+    constexpr int KP = (tri(NS) + L - 1) / L;
+    constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;
+    return (XOFF + ((GEN || FULLT) ? 2 * NM + NS * NM : 0)) * (64 / L);
+}
+// one wave's part of one tile: filters [64 tile + (gw % L) 64 / L, ... + 64 / L), gw = L tile + part
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT>
-__global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
+__device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "rows are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
     constexpr int HOFF = TR;                       // LDS element offset of H (later: K) next to the packed P-
     constexpr int KP = (TR + L - 1) / L;           // packed elements of P per lane
-    __shared__ T lds[(split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L) * FPW];
+    constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;   // FULL: innovation and yhat wait here for the end of the step
+    constexpr int GOFF = (GEN || FULLT) ? XOFF + 2 * NM : 0;   // P- H^T for the Joseph form: over P-, unless P- is still to be stored (FULL)
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
     const bool predict = GEN ? a.predict != 0 : PREDT;
     const unsigned lane = threadIdx.x;
     const int q = (int)((lane / FPW) & (L - 1)), f = (int)(lane & (FPW - 1));
-    const int64_t gw = blockIdx.x;
     const int64_t tile = gw / L;
     const int slot = (int)(gw % L) * FPW + f;
     if (tile * KB_TILE + (gw % L) * FPW >= a.N) return;
@@ -225,6 +295,10 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
     const unsigned umq = um + (unsigned)(q * KB_TILE);
     const unsigned uf = um + (unsigned)(q * rn * KB_TILE);
     T *lf = lds + f;
+    auto lrows = [&]() -> T * {   // lf + q NM FPW: row q of an n x p matrix in LDS (late_lane: formed where it is used)
+        const unsigned t = late_lane();
+        return lds + (t & (FPW - 1)) + ((t / FPW) & (L - 1)) * (NM * FPW);
+    };
     // ep(base, rt, c): element (rt + c) of a block -- rt wave-uniform at run time, c a compile-time constant -- as (scalar anchor,
     // made opaque to the optimiser) + (immediate within +-8 elements): left alone, instruction selection adds the part of c that
     // does not fit the 13-bit immediate to the VECTOR half of the address (a 64-bit VGPR pair and a v_lshl_add_u64 per 8 elements).
@@ -300,12 +374,31 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
             for (int l = L * r; l < L * r + L; l++) xo[r] = (l % L == q) ? x[l] : xo[r];
         }
     }
+    T Pm[RP][NS];   // [r][j] for j >= L r; the other entries are never touched.  First Q, then P-
+    unsigned utri[RP];   // um + 64 tri(i_r)
+#pragma unroll
+    for (int r = 0; r < RP; r++) utri[r] = um + (unsigned)(((q + L * r) * (q + L * r + 1) / 2) * KB_TILE);
+    auto request_Q = [&]() {
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+    #pragma unroll
+            for (int j = L * r; j < NS; j++) {
+                // Q[i_r][j]: packed element (i_r, j) = tri(j) + i_r right of the diagonal, (j, i_r) = tri(i_r) + j left of it
+                T v = T(0);
+                if (rowany[r] && j < rn) {
+                    if (j >= L * r + L - 1) v = ldg(mo, a.L.mo_Q, j * (j + 1) / 2 + L * r, rowok[r] ? umq : um);
+                    else v = ldg(mo, a.L.mo_Q, 0, !rowok[r] ? um : (j >= q + L * r ? umq + (unsigned)((j * (j + 1) / 2 + L * r) * KB_TILE) : utri[r] + (unsigned)(j * KB_TILE)));
+                }
+                Pm[r][j] = rowok[r] ? v : T(0);
+            }
+    };
     {
         T col[2][NS];
 #pragma unroll
         for (int l = 0; l < NS; l++) col[0][l] = lf[symi(l, 0) * FPW];
 #pragma unroll
         for (int k = 0; k < NS; k++) {
+            if (k == KB_SPLIT_QK) request_Q();   // half of T is done and half of the room it needs is still free: Q arrives behind phase 1
             if (k + 1 < NS) {
 #pragma unroll
                 for (int l = 0; l < NS; l++) col[(k + 1) & 1][l] = lf[symi(l, k + 1) * FPW];
@@ -330,22 +423,6 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
     for (int r = 0; r < RP; r++)
 #pragma unroll
         for (int l = 0; l < NS; l++) lf[((q + L * r) * NS + l) * FPW] = Fo[r][l];
-    T Pm[RP][NS];   // [r][j] for j >= L r; the other entries are never touched.  First Q, then P-
-    unsigned utri[RP];   // um + 64 tri(i_r)
-#pragma unroll
-    for (int r = 0; r < RP; r++) utri[r] = um + (unsigned)(((q + L * r) * (q + L * r + 1) / 2) * KB_TILE);
-#pragma unroll
-    for (int r = 0; r < RP; r++)
-#pragma unroll
-        for (int j = L * r; j < NS; j++) {
-            // Q[i_r][j]: packed element (i_r, j) = tri(j) + i_r right of the diagonal, (j, i_r) = tri(i_r) + j left of it
-            T v = T(0);
-            if (rowany[r] && j < rn) {
-                if (j >= L * r + L - 1) v = ldg(mo, a.L.mo_Q, j * (j + 1) / 2 + L * r, rowok[r] ? umq : um);
-                else v = ldg(mo, a.L.mo_Q, 0, !rowok[r] ? um : (j >= q + L * r ? umq + (unsigned)((j * (j + 1) / 2 + L * r) * KB_TILE) : utri[r] + (unsigned)(j * KB_TILE)));
-            }
-            Pm[r][j] = rowok[r] ? v : T(0);
-        }
     if constexpr (NC > 0) {   // G u while F settles in LDS
         if (rm > 0) {
             const T *up = (const T *)a.u + tile * a.u_ts;
@@ -364,9 +441,19 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
             }
         }
     }
+    if (KB_SPLIT_QK >= NS) request_Q();
     wave_lds_fence();
     KB_SB();
     T Hp[NM][RP];   // H[c][i_r]: the lane's own columns of H
+    auto request_H = [&]() {
+#pragma unroll
+        for (int c = 0; c < NM; c++)
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                const T v = (rowany[r] && c < rp) ? ldg(mo, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um) : T(0);
+                Hp[c][r] = rowok[r] ? v : T(0);
+            }
+    };
     {
         T row[2][NS];
 #pragma unroll
@@ -377,15 +464,7 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
 #pragma unroll
                 for (int k = 0; k < NS; k++) row[(j + 1) & 1][k] = lf[((j + 1) * NS + k) * FPW];
             }
-            if (j == NS / 2) {   // H is requested when half of P- is done (T is still alive: no room earlier)
-#pragma unroll
-                for (int c = 0; c < NM; c++)
-#pragma unroll
-                    for (int r = 0; r < RP; r++) {
-                        const T v = (rowany[r] && c < rp) ? ldg(mo, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um) : T(0);
-                        Hp[c][r] = rowok[r] ? v : T(0);
-                    }
-            }
+            if (j == KB_SPLIT_HJ) request_H();
             KB_SB();
 #pragma unroll
             for (int r = 0; r < RP; r++)
@@ -397,6 +476,76 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
                     pin(Pm[r][j]);
                 }
             KB_SB();
+        }
+    }
+
+    // ---- Noise (GEN only; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
+    // into x+ (:195), k = kf.step of THIS filter.  The normals of a draw are the filter's (kb_vanilla_reg.h draw_normals: Philox keyed
+    // by the filter index), formed by each of its L lanes; the lane applies its own rows of chol(Q) (read from the model block: the
+    // constructor's factor) to them.
+    [[maybe_unused]] T wpost[RP], vmeas[NM];
+    if constexpr (GEN) {
+#pragma unroll
+        for (int r = 0; r < RP; r++) wpost[r] = T(0);
+#pragma unroll
+        for (int c = 0; c < NM; c++) vmeas[c] = T(0);
+        if (a.noise_kind != KB_NOISE_NOISELESS) {
+            const uint64_t gfi = (uint64_t)(a.first_filter + fi);
+            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[fi] : 0u);   // kf.step of this filter
+            if (a.noise_kind == KB_NOISE_AWGN) {
+                auto own_rows_of_LQ_times = [&](const T (&z)[NS], T (&w)[RP]) {
+#pragma unroll
+                    for (int r = 0; r < RP; r++) {
+                        T sacc = T(0);
+#pragma unroll
+                        for (int kk = 0; kk < L * r + L; kk++) {   // L[i_r][kk], kk <= i_r, at packed element tri(i_r) + kk
+                            const bool in = rowok[r] && kk <= q + L * r;
+                            const T l = (rowany[r] && kk < rn) ? ldg(mo, a.L.mo_LQ, kk, in ? utri[r] : um) : T(0);
+                            sacc += (in ? l : T(0)) * z[kk];
+                        }
+                        w[r] = sacc;
+                    }
+                };
+                T z[NS], w[RP];
+                draw_normals<T, NS>(a, gfi, stepno, 0u, z);
+                own_rows_of_LQ_times(z, w);
+#pragma unroll
+                for (int r = 0; r < RP; r++) { xm[r] += w[r]; pin(xm[r]); }
+                KB_SB();
+                if (!predict) {
+                    draw_normals<T, NS>(a, gfi, stepno, 2u, z);
+                    own_rows_of_LQ_times(z, wpost);
+#pragma unroll
+                    for (int r = 0; r < RP; r++) pin(wpost[r]);
+                    KB_SB();
+                }
+                if (full) {
+                    T z1[NM];
+                    draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+#pragma unroll
+                    for (int c = 0; c < NM; c++) {
+                        T sacc = T(0);
+#pragma unroll
+                        for (int kk = 0; kk <= c; kk++) sacc += ((c < rp) ? ldg(mo, a.L.mo_LR, symi(kk, c), um) : T(0)) * z1[kk];
+                        vmeas[c] = sacc;
+                        pin(vmeas[c]);
+                    }
+                    KB_SB();
+                }
+            } else {   // BatchNoise: the recorded vectors of step k (noise.go:72-86)
+                const T *bp = (const T *)a.bn_proc + (int64_t)stepno * rn;
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    const T w = rowok[r] ? bp[q + L * r] : T(0);
+                    xm[r] += w;
+                    wpost[r] = predict ? T(0) : w;
+                }
+                if (full) {
+                    const T *bm = (const T *)a.bn_meas + (int64_t)stepno * rp;
+#pragma unroll
+                    for (int c = 0; c < NM; c++) vmeas[c] = c < rp ? bm[c] : T(0);
+                }
+            }
         }
     }
 
@@ -442,6 +591,14 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
     for (int r = 0; r < RP; r++)
 #pragma unroll
         for (int c = 0; c < NM; c++) PHt[r][c] = T(0);
+    T R1[TM], y[NM];   // requested here, used behind the P- H^T loop
+    auto request_Ry = [&]() {
+        load_R(R1, std::false_type{});
+        const T *yp = (const T *)a.y + tile * a.y_ts;
+#pragma unroll
+        for (int r = 0; r < NM; r++) y[r] = (!predict && active && r < rp) ? ldnt_at(&(yp + (int64_t)r * a.y_es)[us]) : T(0);
+    };
+    if (!KB_SPLIT_R1LATE) request_Ry();
     {
         constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
         T hb[2][CH][NM], pb[2][CH][RP];
@@ -479,17 +636,11 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
     }
     // ---- S = H P- H^T + R (upper triangle), H x-, [H x_prev]: partial sums over the own rows, then over the L lanes --------
     T S[NM * NM], innov[NM];
-    [[maybe_unused]] T yhat[NM];
     {
-        T R[TM], y[NM];
-        load_R(R, std::false_type{});
-        {
-            const T *yp = (const T *)a.y + tile * a.y_ts;
-#pragma unroll
-            for (int r = 0; r < NM; r++) y[r] = (!predict && active && r < rp) ? ldnt_at(&(yp + (int64_t)r * a.y_es)[us]) : T(0);
-        }
-        KB_SB();
-        T part[TM];
+        if (KB_SPLIT_R1LATE) { request_Ry(); KB_SB(); }
+        // the partial sums: S (upper triangle) | H x- | [H x_prev], summed over the L lanes two at a time
+        constexpr int NV = TM + NM, NVF = NV + NM;
+        T part[NVF];
 #pragma unroll
         for (int c2 = 0; c2 < NM; c2++)
 #pragma unroll
@@ -501,31 +652,52 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
             }
 #pragma unroll
         for (int c = 0; c < NM; c++) {
-            T s = T(0);
+            T s = T(0), s2 = T(0);
 #pragma unroll
             for (int r = 0; r < RP; r++) s += Hp[c][r] * xm[r];
-            innov[c] = predict ? T(0) : y[c] - sum_lanes<L>(s);   // vanilla.go:183-184
-            pin(innov[c]);
             if (full) {
-                T s2 = T(0);
 #pragma unroll
                 for (int r = 0; r < RP; r++) s2 += Hp[c][r] * xo[r];
-                yhat[c] = sum_lanes<L>(s2);
+            }
+            part[TM + c] = s;
+            part[NV + c] = s2;
+        }
+#pragma unroll
+        for (int e = 0; e + 1 < NV; e += 2) {
+            sum_lanes2<L>(part[e], part[e + 1]);
+            pin(part[e]); pin(part[e + 1]);
+            if ((e & 6) == 6) KB_SB();   // a few at a time: interleaved, the chains keep all their temporaries alive
+        }
+        if (NV & 1) part[NV - 1] = sum_lanes<L>(part[NV - 1]);
+        KB_SB();
+#pragma unroll
+        for (int c = 0; c < NM; c++) {
+            innov[c] = predict ? T(0) : y[c] - part[TM + c];   // vanilla.go:183-184
+            pin(innov[c]);
+        }
+        if (full) {
+#pragma unroll
+            for (int c = 0; c < NM; c += 2) {
+                if (c + 1 < NM) sum_lanes2<L>(part[NV + c], part[NV + c + 1]);
+                else part[NV + c] = sum_lanes<L>(part[NV + c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T yh = part[NV + c];
+                if constexpr (GEN) yh += vmeas[c];   // Measurement(k), vanilla.go:157
+                if constexpr (GEN || FULLT) {
+                    if (q == 0) { lf[(XOFF + c) * FPW] = innov[c]; lf[(XOFF + NM + c) * FPW] = yh; }
+                }
             }
         }
 #pragma unroll
         for (int c2 = 0; c2 < NM; c2++)
 #pragma unroll
             for (int c1 = 0; c1 <= c2; c1++) {
-                const T v = sum_lanes<L>(part[symi(c1, c2)]) + R[symi(c1, c2)];
+                const T v = part[symi(c1, c2)] + R1[symi(c1, c2)];
                 S[c1 * NM + c2] = v;
-                pin(S[c1 * NM + c2]);
-                if (c1 == c2) KB_SB();   // column by column
+                S[c2 * NM + c1] = v;
             }
-#pragma unroll
-        for (int c2 = 0; c2 < NM; c2++)
-#pragma unroll
-            for (int c1 = 0; c1 < c2; c1++) S[c2 * NM + c1] = S[c1 * NM + c2];
     }
     KB_SB();
     // ---- K = P- H^T S^-1 (own rows), column by column of the inverse; the same bits in the L lanes of a filter ---------------
@@ -569,7 +741,7 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
         for (int r = 0; r < RP; r++) {
             xn[r] = xm[r];
 #pragma unroll
-            for (int j = L * r; j < NS; j++) Pn[r][j] = Pm[r][j];
+            for (int j = L * r; j < NS; j++) Pn[r][j] = pm_own(r, j);   // (read back: no register waits through the factorisation)
         }
     } else {
 #pragma unroll
@@ -578,38 +750,55 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
 #pragma unroll
             for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
             xn[r] = xm[r] + s;
+            if constexpr (GEN) xn[r] += wpost[r];   // vanilla.go:195: Process(k) a second time
         }
-        // ---- Joseph form (see the header): A = I - K H column by column, AP = A P- accumulated row of P- by row of P- ------------
-        T AP[RP][NS];
+        // ---- Joseph form (see the header): AP = (I - K H) P- = P- - K (P- H^T)^T for the own rows.  The own rows of P- are read
+        // into AP, then P- H^T -- every row of it is needed -- goes to LDS: in P-'s place, or behind everything else when the
+        // Estimate's P- is still to be stored from there (FULL); two columns of AP per chunk
+        T AP[RP][NS], R[TM];
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int k = 0; k < NS; k++) AP[r][k] = T(0);
+            for (int k = 0; k < NS; k++) AP[r][k] = pm_own(r, k);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) lrows()[(GOFF + L * r * NM + c) * FPW] = PHt[r][c];
+        wave_lds_fence();
+        KB_SB();
         {
-            T hb[2][NM], pb[2][NS];
-            auto fetch = [&](int l, int b) {
+            constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+            T gb[2][CH][NM];
+            auto fetch = [&](int ch, int b) {
 #pragma unroll
-                for (int c = 0; c < NM; c++) hb[b][c] = lf[(HOFF + c * NS + l) * FPW];
+                for (int d = 0; d < CH; d++) {
+                    const int k = ch * CH + d;
+                    if (k < NS) {
 #pragma unroll
-                for (int k = 0; k < NS; k++) pb[b][k] = lf[symi(l, k) * FPW];
+                        for (int c = 0; c < NM; c++) gb[b][d][c] = lf[(GOFF + k * NM + c) * FPW];
+                    }
+                }
             };
             fetch(0, 0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) {
-                if (l + 1 < NS) fetch(l + 1, (l + 1) & 1);
+            for (int ch = 0; ch < NCH; ch++) {
+                if (ch + 1 < NCH) fetch(ch + 1, (ch + 1) & 1);
                 KB_SB();
-                T al[RP];
 #pragma unroll
-                for (int r = 0; r < RP; r++) {
-                    T s = T(0);
+                for (int d = 0; d < CH; d++) {
+                    const int k = ch * CH + d;
+                    if (k < NS) {
 #pragma unroll
-                    for (int c = 0; c < NM; c++) s += K[r][c] * hb[l & 1][c];
-                    al[r] = ((l / L == r && l % L == q) ? T(1) : T(0)) - s;
+                        for (int r = 0; r < RP; r++) {
+                            T sacc = T(0);
+#pragma unroll
+                            for (int c = 0; c < NM; c++) sacc += K[r][c] * gb[ch & 1][d][c];
+                            AP[r][k] = AP[r][k] - sacc;
+                            pin(AP[r][k]);
+                        }
+                    }
                 }
-#pragma unroll
-                for (int r = 0; r < RP; r++)
-#pragma unroll
-                    for (int k = 0; k < NS; k++) { AP[r][k] += al[r] * pb[l & 1][k]; pin(AP[r][k]); }
                 KB_SB();
             }
         }
@@ -617,7 +806,6 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
         T V[RP][NM];
         {
             constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
-            T R[TM];
             T hb[2][CH][NM];
             auto fetch = [&](int ch, int b) {
 #pragma unroll
@@ -628,7 +816,7 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
                     }
             };
             fetch(0, 0);
-            load_R(R, std::true_type{});
+            if (KB_SPLIT_RL >= NS) load_R(R, std::true_type{});
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
@@ -668,7 +856,7 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) lf[(HOFF + (q + L * r) * NM + c) * FPW] = K[r][c];
+            for (int c = 0; c < NM; c++) lrows()[(HOFF + L * r * NM + c) * FPW] = K[r][c];
         wave_lds_fence();
         KB_SB();
         {
@@ -744,14 +932,35 @@ __global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM,
             if (q == 0) {
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (c < rp) {
-                        __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
-                        __builtin_nontemporal_store(yhat[c], ep(es, a.L.es_yhat, c) + us);
+                    if constexpr (GEN || FULLT) {
+                        if (c < rp) {
+                            __builtin_nontemporal_store(lf[(XOFF + c) * FPW], ep(es, a.L.es_innov, c) + us);
+                            __builtin_nontemporal_store(lf[(XOFF + NM + c) * FPW], ep(es, a.L.es_yhat, c) + us);
+                        }
                     }
             }
         }
     }
-    if (active && err && q == 0) fail_step(a, fi, err);   // vanilla.go:164-167, :207-215 return before kf.step++ (:218)
+    // (the filter index is formed again from the lane number: kept from the top of the kernel it would occupy two registers all along)
+    const unsigned lane_end = late_lane();
+    if (active && err && ((lane_end / FPW) & (L - 1)) == 0)
+        fail_step(a, tile * KB_TILE + (int64_t)((gw % L) * FPW + (lane_end & (FPW - 1))), err);   // vanilla.go:164-167, :207-215 return before kf.step++ (:218)
+}
+
+// One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
+// workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false>
+__global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
+    __shared__ T lds[split_lds_total<T, NS, NM, L, GEN, FULLT>()];
+    if constexpr (PERSIST) {
+        const int64_t nparts = a.ntiles * L;
+        for (int64_t gw = blockIdx.x; gw < nparts; gw += gridDim.x) {
+            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT>(a, gw, lds);
+            wave_lds_fence();
+        }
+    } else {
+        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT>(a, blockIdx.x, lds);
+    }
 }
 #undef KB_SB
 

@@ -9,8 +9,14 @@ template <typename T, int NS, int NM, int NC, int L>
 static bool split_exact(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC || a.noise_kind != KB_NOISE_NOISELESS) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+#ifdef KB_SPLIT_PERSIST
+    const int64_t slots = (int64_t)KB_SPLIT_PERSIST;
+    const dim3 grid((unsigned)(a.ntiles * L < slots ? a.ntiles * L : slots)), block(64);
+#define KB_GO(F_, P_) hipLaunchKernelGGL((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_, true>), grid, block, 0, b.stream, a)
+#else
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
 #define KB_GO(F_, P_) hipLaunchKernelGGL((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_>), grid, block, 0, b.stream, a)
+#endif
     if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
     else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
 #undef KB_GO

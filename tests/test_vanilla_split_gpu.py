@@ -149,3 +149,60 @@ def test_split_batches_keep_the_other_kernels_bits_for_small_shapes():
         a.update(d["y"][t]); s.update(d["y"][t])
     assert synth.rel_frobenius(a.get(k.STATE), s.get(k.STATE)) <= 1e-12
     assert synth.rel_frobenius(a.get(k.COVAR), s.get(k.COVAR)) <= 1e-12
+
+
+@pytest.mark.parametrize("n,p,m,full,predict", [(12, 6, 0, False, False), (12, 6, 0, True, False), (9, 2, 1, True, False), (11, 8, 2, False, False),
+                                                (16, 8, 2, True, False), (14, 5, 0, False, False), (13, 3, 1, True, True), (12, 4, 0, False, True)])
+def test_split_awgn_replayed_through_the_oracle(n, p, m, full, predict):
+    """AWGN (noise.go:109-164) on the split kernels: the device's draws (kb_noise_sample: the standard normals of (filter, epoch,
+    kf.step, which)) replayed through the oracle in the reference's call order -- Process(k) into x-, Measurement(k) into yhat,
+    Process(k) again into x+ (vanilla.go:146,157,195); 4096 filters x 20 steps for 12 / 6, smaller batches for the rest."""
+    bench_shape = (n, p, m) == (12, 6, 0) and not full
+    N, steps = (4096, 20) if bench_shape else (150, 5)
+    d = _model(N, n, p, m, steps, 31 * n + p + m)
+    kind, okind = (k.VANILLA_PREDICT, orc.VANILLA_PREDICT) if predict else (k.VANILLA, orc.VANILLA)
+    b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE if full else 0,
+                                noise=k.NOISE_AWGN, seed=1234)
+    for t in range(steps):
+        est = b.update(d["y"][t], d["u"][t] if m else None, snapshot=(t == steps - 1))
+    check = list(range(N)) if not bench_shape else list(range(0, N, 41)) + [N - 1]
+    xs, Ps, ys, inn = [], [], [], []
+    for i in check:
+        LQ, LR = orc.cholesky_lower(d["Q"][i])[1], orc.cholesky_lower(d["R"][i])[1]
+        f = orc.Filter.ldkf(okind, d["x0"][i], d["P0"][i], d["F"][i], d["G"][i] if m else None, d["H"][i], d["Q"][i], d["R"][i])
+        for t in range(steps):
+            w0, v, w2 = LQ @ b.noise_sample(i, 0, t, 0, n), LR @ b.noise_sample(i, 0, t, 1, p), LQ @ b.noise_sample(i, 0, t, 2, n)
+            assert f.update(d["y"][t, i], d["u"][t, i] if m else None, w_pred=w0, v_meas=v, w_post=w2) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); ys.append(f.measurement()); inn.append(f.innovation())
+    idx = np.array(check)
+    assert synth.rel_frobenius(est.state()[idx], np.array(xs)) <= TOL
+    assert synth.rel_frobenius(est.covariance()[idx], np.array(Ps)) <= TOL
+    if full:
+        assert synth.rel_frobenius(est.measurement()[idx], np.array(ys)) <= TOL
+        if not predict:
+            assert synth.rel_frobenius(est.innovation()[idx], np.array(inn)) <= 1e-7
+    assert not b.status().any() and b.step() == steps
+
+
+@pytest.mark.parametrize("n,p", [(12, 6), (15, 4)])
+def test_split_batch_noise_vs_oracle(n, p):
+    """BatchNoise (noise.go:67-106): recorded vectors, the same for every filter of a batch, indexed by kf.step."""
+    N, steps = 100, 5
+    d = _model(N, n, p, 0, steps, 900 + n)
+    rng = np.random.default_rng(n)
+    proc, meas = 1e-2 * rng.standard_normal((steps, n)), 1e-2 * rng.standard_normal((steps, p))
+    ZQ, ZR = np.zeros((n, n)), 1e-2 * np.eye(p)   # (BatchNoise reports zero matrices, noise.go:89-98; R > 0 keeps S invertible)
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], ZQ, ZR, nfilters=N, flags=k.FLAG_FULL_ESTIMATE)
+    b.set_batch_noise(proc, meas)
+    for t in range(steps):
+        est = b.update(d["y"][t])
+    xs, ys = [], []
+    for i in range(N):
+        f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], np.zeros((n, n)), np.zeros((p, p)))
+        for t in range(steps):
+            f.update(d["y"][t, i], None, proc[t], meas[t], proc[t])
+        xs.append(f.state()); ys.append(f.measurement())
+    ok = ~np.isnan(np.array(xs)).any(axis=1)
+    assert ok.any()
+    assert synth.rel_frobenius(est.state()[ok], np.array(xs)[ok]) <= TOL
+    assert synth.rel_frobenius(est.measurement()[ok], np.array(ys)[ok]) <= TOL
