@@ -73,6 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--shared-filters", type=int, default=1 << 20, help="Vanilla 6/3 filters per GPU sharing one model for extra.shared_model (0 = skip)")
     ap.add_argument("--sqrt-filters", type=int, default=1 << 20, help="SquareRoot 6/3 filters per GPU for extra.squareroot, config C (0 = skip)")
     ap.add_argument("--srif-filters", type=int, default=1 << 18, help="SRIF 12/6 fp32 filters per GPU for extra.srif_fp32, config E (0 = skip)")
+    ap.add_argument("--split-filters", type=int, default=1 << 18, help="Vanilla 12/6 fp64 filters per GPU for extra.vanilla_12x6: the split-lane kernels for 8 < n <= 16 (0 = skip)")
     ap.add_argument("--repeat", type=int, default=5, help="timed blocks of --steps steps (the first one is the contract's `value`)")
     ap.add_argument("--chisq-runs", type=int, default=1 << 20, help="chi-square runs per GPU for extra.chisq (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
@@ -152,6 +153,86 @@ def _parity(ga, k, synth):
     return {"filters": N, "steps": T, "max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
             "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any()),
             "against": "oracle/gokalman_oracle.c (reference-order C restatement of vanilla.go:128-220)"}
+
+
+def _leg_parity(ga, k, synth, leg):
+    """The same gate for the secondary legs: 4096 filters x 20 steps of each leg's configuration through
+    the entry points the leg times, against the CPU oracle -- outside every timed region, rank 0 only.  `srif_fp32` also reports
+    the ACHIEVED error of the fp32 kernel (max relative Frobenius error of R and b against the fp64 oracle on the same inputs)."""
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    N, T = 4096, 20
+    out = {"filters": N, "steps": T, "against": "oracle/gokalman_oracle.c"}
+    if leg in ("squareroot", "shared_model", "vanilla_12x6"):
+        nn, pp = (12, 6) if leg == "vanilla_12x6" else (N_STATE, N_MEAS)
+        d = synth.linear_batch(N, nn, pp, T, seed=synth.SEED + 77)
+        if leg == "shared_model":
+            for f in ("F", "H", "Q", "R"):
+                d[f] = np.ascontiguousarray(np.broadcast_to(d[f][0], d[f].shape))
+            b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"][0], None, d["H"][0], d["Q"][0], d["R"][0], nfilters=N)
+            okind = orc.VANILLA
+        else:
+            kind, okind = (k.VANILLA, orc.VANILLA) if leg == "vanilla_12x6" else (k.SQUAREROOT, orc.SQUAREROOT)
+            b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+        for t in range(T):
+            b.update_dev(y[t].data_ptr(), N)
+        b.synchronize()
+        xo, Po, nerr = orc.ldkf_batch(okind, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+        ex, eP = synth.rel_frobenius(b.get(k.STATE), xo), synth.rel_frobenius(b.get(k.COVAR), Po)
+        out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
+                    "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any())})
+        return out
+    # the NLDKF legs: per-step Phi / Htilde handed over on the device (kb_prepare_dev), as the timed loops do
+    fp32 = leg == "srif_fp32"
+    n, p = (12, 6) if fp32 else (6, 2)
+    tdt = torch.float32 if fp32 else torch.float64
+    g = torch.Generator(device="cuda"); g.manual_seed(2016)
+    rng = np.random.default_rng(99)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * (n // 2) + [1.0] * (n - n // 2)
+    if fp32:
+        R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=k.F32)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        fs = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+    else:
+        R = np.broadcast_to(np.diag([1e-6, 1e-6]), (N, p, p)).copy()
+        b = ga.FilterBatch(k.HYBRID, n, p, 0, N)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R[0], 2, p_rows=p); b.init(); b.enable_ekf()
+        fs = [orc.Filter.hybrid(x0[i], P0[i], None, R[i], p) for i in range(N)]
+        for f in fs:
+            f.enable_ekf()
+    eye = torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1)
+    nerr = 0
+    for t in range(T):
+        Phi = (eye + 1e-2 * torch.randn(n * n, N, dtype=tdt, device="cuda", generator=g)).contiguous()
+        Ht = torch.randn(p * n, N, dtype=tdt, device="cuda", generator=g)
+        real = torch.randn(p, N, dtype=tdt, device="cuda", generator=g)
+        comp = (real + (1e-2 if fp32 else 1e-3) * torch.randn(p, N, dtype=tdt, device="cuda", generator=g)).contiguous()
+        k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
+        k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
+        b.synchronize()
+        Ph, Hh = Phi.double().cpu().numpy().T.reshape(N, n, n), Ht.double().cpu().numpy().T.reshape(N, p, n)
+        rh, ch = real.double().cpu().numpy().T, comp.double().cpu().numpy().T
+        for i, f in enumerate(fs):
+            f.prepare(Ph[i], Hh[i])
+            nerr += f.update_nl(rh[i], ch[i]) != orc.OK
+    if fp32:
+        eR = synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs]))
+        eb = synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs]))
+        out.update({"achieved_max_rel_frobenius_R": eR, "achieved_max_rel_frobenius_b": eb, "tolerance": SRIF_F32_TOL, "dtype": "f32 kernel against the fp64 oracle",
+                    "ok": bool(eR <= SRIF_F32_TOL and eb <= SRIF_F32_TOL and nerr == 0 and not b.status().any())})
+    else:
+        ex = synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs]))
+        eP = synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs]))
+        out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
+                    "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any())})
+    return out
+
+
+SRIF_F32_TOL = 2e-3   # tests/test_srif_gpu.py uses the same figure
 
 
 STATOD = dict(  # examples/statOD5044/main.go:36-57
@@ -304,14 +385,11 @@ def main():
         fms = f0.elapsed_time(f1) / reps
         fused = {"steps_per_launch": T, "ms_per_launch": fms, "value": N * T / (fms * 1e-3),
                  "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev)"}
-        try:
-            vj = json.load(open(os.path.join(ROOT, "profiles", "valu_latest.json")))
-            e = vj["kernels"]["vanilla_fused"]
-            fused["roofline"] = rl.valu_roofline(fms, (N + 63) // 64, e["valu_insts_per_wave_per_step"] * T,
-                                                 {"file": "profiles/valu_latest.json", "profile_tag": vj.get("tag"),
-                                                  "counter": "SQ_INSTS_VALU / SQ_WAVES", "live": False})
-        except Exception:
-            pass
+        vk, vs = rl.load_valu(ROOT)
+        if "vanilla_fused" in vk:
+            fused["roofline"] = rl.valu_roofline(fms, (N + 63) // 64, vk["vanilla_fused"]["valu_insts_per_wave_per_step"] * T, vs)
+        elif vs:
+            fused["roofline"] = {"bound": "valu_issue", "frac": None, "source": vs}
         del yy
     torch.cuda.empty_cache()   # (the headline batch stays: warm_clocks() runs it before every later timed region)
 
@@ -362,12 +440,8 @@ def main():
                                      reduce=kd.allreduce_sum if use_dist else None)
         torch.cuda.synchronize()
         mc_s, _ = max_over_ranks(time.perf_counter() - t0)
-        valu = {}
-        try:
-            valu = json.load(open(os.path.join(ROOT, "profiles", "valu_latest.json")))
-        except Exception:
-            pass
-        vsrc = {"file": "profiles/valu_latest.json", "profile_tag": valu.get("tag"), "counter": "SQ_INSTS_VALU / SQ_WAVES", "live": False}
+        vkernels, vsrc = rl.load_valu(ROOT)
+        valu = {"kernels": vkernels}
         extra["mc"] = {"config": "configs[3] D(i): montecarlo.go pure-predictor statOD5044 (n=4, AWGN), runs sharded by global index",
                        "runs_total": world * args.mc_runs, "steps": args.mc_steps, "seconds": mc_s,
                        "value": world * args.mc_runs * args.mc_steps / mc_s, "unit": "run-steps/s (whole job)",
@@ -504,6 +578,21 @@ def main():
                                  "filters_with_error_status": hbad,
                                  "note": "the model block (672 B) is read from the L2 by every wave; moved bytes = x, P read and written + y"}
         del sh, yq
+    if args.split_filters > 0:
+        # Vanilla beyond 8 states (the north star's envelope is n <= 16): 12 / 6, per-filter models, one filter split over four lanes
+        M = args.split_filters
+        dq = synth.linear_batch(M, 12, 6, 1, seed=synth.SEED + 3000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)  # [p][M]
+        vb = ga.FilterBatch.new_ldkf(k.VANILLA, dq["x0"], dq["P0"], dq["F"], None, dq["H"], dq["Q"], dq["R"], device=local_rank)
+        K6 = 50
+        v_s, vms, vbad = timed_leg(vb, lambda: vb.update_dev(yq.data_ptr(), M), K6)
+        extra["vanilla_12x6"] = {"config": "%d Vanilla 12/6 fp64 filters per GPU, per-filter models (kb_vanilla_split.h: one filter per four lanes)" % M,
+                                 "filters_total": world * M, "steps": K6, "value": world * M * K6 / v_s,
+                                 "unit": "filter-update steps/s (whole job)", "kernel_ms": vms,
+                                 "roofline": rl.hbm_roofline(vms, M, rl.algorithmic_bytes("vanilla", 12, 6), rl.moved_bytes("vanilla", 12, 6),
+                                                             *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 12, 6, 0, 4, false, false, false")),
+                                 "filters_with_error_status": vbad}
+        del vb, yq
     if args.srif_filters > 0:
         M = args.srif_filters
         sn, sp = 12, 6
@@ -589,6 +678,9 @@ def main():
                                 "note": "%d MB of host measurements per call: H2D copy + pack + step + synchronise" % (N * p * 8 // 1000000)}
         if not args.no_parity:
             out["parity"] = _parity(ga, k, synth)
+            for leg in ("squareroot", "shared_model", "vanilla_12x6", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
+                if leg in extra:
+                    extra[leg]["parity"] = _leg_parity(ga, k, synth, leg)
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
             out["cpu_baseline"] = _cpu_baseline(d)
         print(json.dumps(out), flush=True)

@@ -6,10 +6,11 @@ import numpy as np
 
 
 def shard_range(n_items, rank, world):
-    """Contiguous block [lo, hi) of rank `rank` (sizes differ by at most one)."""
-    base, rem = divmod(int(n_items), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous block [lo, hi) of rank `rank`: SURVEY section 8e's formula, GPU g owns [g N / G, (g + 1) N / G) (integer
+    division; sizes differ by at most one) -- the same split kb_sharded_create makes (csrc/kb_sharded.hip), so that a job of one
+    process per GPU and the one-process sharded batch put every filter (and every Monte-Carlo run) on the same device."""
+    n_items, rank, world = int(n_items), int(rank), int(world)
+    return (n_items * rank) // world, (n_items * (rank + 1)) // world
 
 
 def allreduce_sum(arr):

@@ -65,22 +65,67 @@ def moved_bytes(kind, n, p, w=8):
     raise KeyError(kind)
 
 
+def kernel_source_hash(root=None):
+    """sha256 over what decides the machine code of the kernels: every file of gokalman_amd/csrc (*.hip, *.h), the C ABI header and
+    the compiler flags of gokalman_amd/build.py.  The counter files under profiles/ carry the hash of the sources they were
+    measured on; a bench line only quotes them while it still equals the hash of the sources it runs."""
+    import glob
+    import hashlib
+    from . import build as kb_build
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.h")) +
+                   [os.path.join(root, "include", "gokalman_amd.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(repr((kb_build.ARCH, kb_build.FLAGS, sorted(kb_build.EXTRA.items()))).encode())
+    return h.hexdigest()[:16]
+
+
+def counters_current(root, doc):
+    """(usable, note) for a counter document of profiles/: usable only if it was measured on these very kernel sources."""
+    have = doc.get("source_hash")
+    now = kernel_source_hash(root)
+    if have == now:
+        return True, {"source_hash": now, "matches_sources": True}
+    return False, {"counter_file_source_hash": have, "source_hash": now, "matches_sources": False,
+                   "note": "the kernel sources changed since the counters were collected: analytic byte / instruction counts are used instead"}
+
+
 def load_traffic(root, kernel_substr):
-    """Counter-measured bytes per launch for the kernel whose name contains `kernel_substr`, from the newest
-    profiles/traffic_latest.json entry; returns (bytes_per_filter, source dict) or (None, None)."""
+    """Counter-measured bytes per launch for the kernel whose name contains `kernel_substr`, from profiles/traffic_latest.json --
+    if that file was measured on the kernel sources of this checkout (kernel_source_hash); returns (bytes_per_filter, source
+    dict), or (None, source dict saying why not) when the sources have changed, or (None, None) without a file."""
     path = os.path.join(root, "profiles", "traffic_latest.json")
     try:
         tj = json.load(open(path))
     except Exception:
         return None, None
+    ok, note = counters_current(root, tj)
+    if not ok:
+        return None, dict(note, file="profiles/traffic_latest.json", profile_tag=tj.get("tag"), live=False,
+                          analytic="packed working set, gokalman_amd/roofline.py moved_bytes()")
     entries = tj.get("kernels") or [tj]
     for e in entries:
         if kernel_substr in e.get("kernel", ""):
             per_filter = e["hbm_bytes_per_launch"] / float(e.get("filters", 1 << 20))
-            src = {"file": "profiles/traffic_latest.json", "profile_tag": e.get("tag"), "head": e.get("head"),
-                   "live": False, "counters": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, separate passes"}
+            src = dict(note, file="profiles/traffic_latest.json", profile_tag=e.get("tag"), head=e.get("head"), live=False,
+                       counters="rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, separate passes")
             return per_filter, src
     return None, None
+
+
+def load_valu(root):
+    """profiles/valu_latest.json (SQ_INSTS_VALU / SQ_WAVES per kernel) if it matches the kernel sources: (kernels dict, source dict);
+    ({}, source dict with the reason) otherwise."""
+    try:
+        vj = json.load(open(os.path.join(root, "profiles", "valu_latest.json")))
+    except Exception:
+        return {}, None
+    ok, note = counters_current(root, vj)
+    src = dict(note, file="profiles/valu_latest.json", profile_tag=vj.get("tag"), counter="SQ_INSTS_VALU / SQ_WAVES", live=False)
+    return (vj.get("kernels", {}) if ok else {}), src
 
 
 def hbm_roofline(kernel_ms, filters, algo_bytes_per_filter, moved_bytes_per_filter, counter_bytes_per_filter=None,

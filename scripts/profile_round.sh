@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-B="--steps 40 --warmup 5 --repeat 1 --no-cpu-baseline --no-parity --no-host-path --ooc-filters 0 --mc-runs 0 --chisq-runs 0 --hybrid-filters 0 --sqrt-filters 0 --srif-filters 0 --shared-filters 0"
+B="--steps 40 --warmup 5 --repeat 1 --no-cpu-baseline --no-parity --no-host-path --ooc-filters 0 --mc-runs 0 --chisq-runs 0 --hybrid-filters 0 --sqrt-filters 0 --srif-filters 0 --shared-filters 0 --split-filters 0"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"
 run() { local name=$1; shift; echo "== $name"; "$@" > $OUT/$name.out 2> $OUT/$name.log; }
 run bench_plain   python3 bench.py --steps 2000 --warmup 100

@@ -14,6 +14,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gokalman_amd import roofline as rl   # noqa: E402  (kernel_source_hash: the counter files name the sources they were measured on)
 tag = sys.argv[1]
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 DST = os.path.join(ROOT, "profiles", tag)
@@ -151,11 +153,11 @@ def main():
     open(os.path.join(DST, "summary.md"), "w").write("\n".join(md) + "\n")
     json.dump({"tag": tag, "head": head, "condensed": c}, open(os.path.join(DST, "summary.json"), "w"), indent=1)
     if traffic:
-        json.dump({"tag": tag, "head": head, "kernels": traffic,
+        json.dump({"tag": tag, "head": head, "source_hash": rl.kernel_source_hash(ROOT), "kernels": traffic,
                    "note": "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE; separate --pmc passes; the counters sit on the "
                            "L2's fabric side and include Infinity-Cache hits"}, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
     if named:
-        json.dump({"tag": tag, "head": head, "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
+        json.dump({"tag": tag, "head": head, "source_hash": rl.kernel_source_hash(ROOT), "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
                   open(os.path.join(ROOT, "profiles", "valu_latest.json"), "w"), indent=1)
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resource_usage.py"), "--md", os.path.join(DST, "resource_usage.md"),
                     "reg_kernel", "srif_", "mc_kernel", "chisq_kernel"], stdout=subprocess.DEVNULL)

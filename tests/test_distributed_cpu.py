@@ -64,6 +64,8 @@ def test_shard_ranges_partition_the_batch():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+        # GPU g owns [g N / G, (g + 1) N / G) -- the split kb_sharded_create makes (tests/test_sharded_gpu.py checks the library)
+        assert spans == [((n * r) // w, (n * (r + 1)) // w) for r in range(w)]
 
 
 def test_monte_carlo_statistics_allreduce_gloo_world2(tmp_path):

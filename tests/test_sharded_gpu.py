@@ -28,6 +28,8 @@ def test_sharded_batch_is_bit_equal_to_the_unsharded_batch(kind, N, shards):
     sh = ga.ShardedBatch(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], N, devices=[0] * shards)
     assert sh.shards() == shards
     assert [sh.first(g) for g in range(shards + 1)] == [(N * g) // shards for g in range(shards + 1)]   # GPU g owns [g N / G, (g + 1) N / G)
+    from gokalman_amd import dist as kd   # the one-process-per-GPU job splits alike (ragged N included)
+    assert [kd.shard_range(N, g, shards) for g in range(shards)] == [(sh.first(g), sh.first(g + 1)) for g in range(shards)]
     for t in range(steps):
         one.update(d["y"][t], snapshot=False)
         sh.update(d["y"][t])

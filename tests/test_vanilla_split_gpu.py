@@ -186,12 +186,14 @@ def test_split_awgn_replayed_through_the_oracle(n, p, m, full, predict):
 
 @pytest.mark.parametrize("n,p", [(12, 6), (15, 4)])
 def test_split_batch_noise_vs_oracle(n, p):
-    """BatchNoise (noise.go:67-106): recorded vectors, the same for every filter of a batch, indexed by kf.step."""
-    N, steps = 100, 5
+    """BatchNoise (noise.go:67-106): recorded vectors, the same for every filter of a batch, indexed by kf.step.  BatchNoise reports
+    ZERO noise matrices (noise.go:89-98), so after the first update P is singular along the rows of H and the later innovation
+    covariances H P- H^T are badly conditioned (the model's F only mixes 5 % per step): the comparison is at 1e-7, three steps."""
+    N, steps = 100, 3
     d = _model(N, n, p, 0, steps, 900 + n)
     rng = np.random.default_rng(n)
     proc, meas = 1e-2 * rng.standard_normal((steps, n)), 1e-2 * rng.standard_normal((steps, p))
-    ZQ, ZR = np.zeros((n, n)), 1e-2 * np.eye(p)   # (BatchNoise reports zero matrices, noise.go:89-98; R > 0 keeps S invertible)
+    ZQ, ZR = np.zeros((n, n)), np.zeros((p, p))
     b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], ZQ, ZR, nfilters=N, flags=k.FLAG_FULL_ESTIMATE)
     b.set_batch_noise(proc, meas)
     for t in range(steps):
@@ -202,7 +204,6 @@ def test_split_batch_noise_vs_oracle(n, p):
         for t in range(steps):
             f.update(d["y"][t, i], None, proc[t], meas[t], proc[t])
         xs.append(f.state()); ys.append(f.measurement())
-    ok = ~np.isnan(np.array(xs)).any(axis=1)
-    assert ok.any()
-    assert synth.rel_frobenius(est.state()[ok], np.array(xs)[ok]) <= TOL
-    assert synth.rel_frobenius(est.measurement()[ok], np.array(ys)[ok]) <= TOL
+    assert not b.status().any()
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-7
+    assert synth.rel_frobenius(est.measurement(), np.array(ys)) <= 1e-7
