@@ -69,6 +69,8 @@ def parse_args(argv=None):
                     help="filters of the out-of-Infinity-Cache measurement of the same kernel (0 = skip)")
     ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")
     ap.add_argument("--mc-steps", type=int, default=1086)
+    ap.add_argument("--mc-total", type=int, default=8 << 20, help="runs of the WHOLE configs[3] ensemble (8M): every rank takes mc_total / world of them as "
+                    "consecutive shards of --mc-runs runs (one rank: eight shards one after the other); 0 = skip extra.mc.ensemble")
     ap.add_argument("--hybrid-filters", type=int, default=1 << 20, help="Hybrid EKF filters per GPU for extra.hybrid_ekf (0 = skip)")
     ap.add_argument("--shared-filters", type=int, default=1 << 20, help="Vanilla 6/3 filters per GPU sharing one model for extra.shared_model (0 = skip)")
     ap.add_argument("--sqrt-filters", type=int, default=1 << 20, help="SquareRoot 6/3 filters per GPU for extra.squareroot, config C (0 = skip)")
@@ -204,6 +206,14 @@ def _leg_parity(ga, k, synth, leg):
         fs = [orc.Filter.hybrid(x0[i], P0[i], None, R[i], p) for i in range(N)]
         for f in fs:
             f.enable_ekf()
+    # D(ii) as SURVEY 8d specifies it (R = 1e-6 against P0 = 10) is ILL-CONDITIONED: a second oracle run whose Phi is perturbed in
+    # the last place shows how far two correct fp64 evaluations of it drift apart (~1e-5 after 20 steps); the engine is held to a
+    # small multiple of that, and to 1e-9 where the problem allows it
+    fs2 = []
+    if not fp32:
+        fs2 = [orc.Filter.hybrid(x0[i], P0[i], None, R[i], p) for i in range(N)]
+        for f in fs2:
+            f.enable_ekf()
     eye = torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1)
     nerr = 0
     for t in range(T):
@@ -219,20 +229,30 @@ def _leg_parity(ga, k, synth, leg):
         for i, f in enumerate(fs):
             f.prepare(Ph[i], Hh[i])
             nerr += f.update_nl(rh[i], ch[i]) != orc.OK
+        if fs2:
+            Pp = np.nextafter(Ph, np.where(rng.random(Ph.shape) < 0.5, -np.inf, np.inf))   # every entry of Phi moved by one ulp
+            for i, f in enumerate(fs2):
+                f.prepare(Pp[i], Hh[i])
+                f.update_nl(rh[i], ch[i])
     if fp32:
         eR = synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs]))
         eb = synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs]))
         out.update({"achieved_max_rel_frobenius_R": eR, "achieved_max_rel_frobenius_b": eb, "tolerance": SRIF_F32_TOL, "dtype": "f32 kernel against the fp64 oracle",
                     "ok": bool(eR <= SRIF_F32_TOL and eb <= SRIF_F32_TOL and nerr == 0 and not b.status().any())})
     else:
-        ex = synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs]))
-        eP = synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs]))
-        out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
-                    "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any())})
+        xo, Po = np.array([f.state() for f in fs]), np.array([f.covariance() for f in fs])
+        ex, eP = synth.rel_frobenius(b.get(k.STATE), xo), synth.rel_frobenius(b.get(k.COVAR), Po)
+        cx = synth.rel_frobenius(np.array([f.state() for f in fs2]), xo)
+        cP = synth.rel_frobenius(np.array([f.covariance() for f in fs2]), Po)
+        tx, tP = max(1e-9, 8 * cx), max(1e-9, 8 * cP)
+        out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP,
+                    "oracle_vs_oracle_with_phi_moved_by_one_ulp": {"state": cx, "covariance": cP},
+                    "tolerance": {"state": tx, "covariance": tP, "rule": "max(1e-9, 8 x the drift of the oracle itself under a one-ulp change of Phi)"},
+                    "ok": bool(ex <= tx and eP <= tP and nerr == 0 and not b.status().any())})
     return out
 
 
-SRIF_F32_TOL = 2e-3   # tests/test_srif_gpu.py uses the same figure
+SRIF_F32_TOL = 2e-5   # tests/test_srif_gpu.py uses the same figure (achieved: ~1.3e-6 on R, ~2.7e-6 on b)
 
 
 STATOD = dict(  # examples/statOD5044/main.go:36-57
@@ -454,6 +474,42 @@ def main():
             per_step = e["valu_insts_per_wave"] / float(e.get("steps_per_launch", 1086))
             extra["mc"]["roofline"] = rl.valu_roofline(mc_s * 1e3, (args.mc_runs + 63) // 64, per_step * args.mc_steps, vsrc)
             extra["mc"]["roofline"]["kernel_ms_is"] = "the whole NewMonteCarloRuns call (mc_kernel + fold + D2H of the sums + host object), not the kernel alone"
+        # ---- configs[3] at its stated size: the 8 388 608-run ensemble, mc_total / world runs per rank as consecutive shards of
+        # mc_runs runs (fresh batches: the noise of a run depends only on (seed, global run index, step)), partial sums added in
+        # shard order, ONE all-reduce -- the reduction the 8-GPU job performs, rehearsed on however many GPUs there are
+        if args.mc_total >= world * args.mc_runs and args.mc_total % (world * args.mc_runs) == 0:
+            S = args.mc_total // (world * args.mc_runs)
+            shards = [ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, s["x0"], s["P0"], s["F"], s["G"], s["H"], s["Q"], s["R"],
+                                              nfilters=args.mc_runs, device=local_rank, noise=k.NOISE_AWGN, seed=2016) for _ in range(S)]
+            warm_clocks()
+            barrier()
+            t0 = time.perf_counter()
+            tot = None
+            for si, kb_s in enumerate(shards):
+                part = ga.new_monte_carlo_runs(args.mc_runs, args.mc_steps, 2, np.zeros((1, 2)), kb_s, first_run=(rank * S + si) * args.mc_runs, keep_runs=False).sums
+                if tot is None:
+                    tot = part.copy()
+                else:
+                    tot[:, :2, :] += part[:, :2, :]
+            if use_dist:
+                tot[:, :2, :] = kd.allreduce_sum(np.ascontiguousarray(tot[:, :2, :]))
+            torch.cuda.synchronize()
+            ens_s, _ = max_over_ranks(time.perf_counter() - t0)
+            ens = ga.MonteCarloRuns(args.mc_total, args.mc_steps, 4, tot)
+            # montecarlo.go:18-59 against what it estimates: Mean(k) = F^k x0, StdDev(k)^2 = diag(sum_j F^j Q F^jT), within 6 standard errors
+            xk, Pk, ok_mc = s["x0"].copy(), np.zeros((4, 4)), True
+            for t in range(args.mc_steps):
+                xk, Pk = s["F"] @ xk, s["F"] @ Pk @ s["F"].T + s["Q"]
+                if t in (0, 10, 100, args.mc_steps - 1):
+                    sd = np.sqrt(np.diag(Pk))
+                    ok_mc = ok_mc and bool(np.all(np.abs(ens.mean(t) - xk) <= 6 * sd / np.sqrt(args.mc_total) + 1e-12 * np.abs(xk)))
+                    ok_mc = ok_mc and bool(np.all(np.abs(ens.stddev(t) / sd - 1.0) <= 6 / np.sqrt(2 * args.mc_total)))
+            extra["mc"]["ensemble"] = {"config": "configs[3] at its stated size: %d runs x %d steps = %d shard(s) of %d runs per rank, sums added in shard order + one all-reduce"
+                                                 % (args.mc_total, args.mc_steps, S, args.mc_runs),
+                                       "runs_total": args.mc_total, "shards_per_rank": S, "seconds": ens_s,
+                                       "value": args.mc_total * args.mc_steps / ens_s, "unit": "run-steps/s (whole job)",
+                                       "matches_covariance_recursion": ok_mc, "stddev_last": ens.stddev(args.mc_steps - 1).tolist()}
+            del shards
         # ---- chi-square on the same ensemble (chisquare.go:16-95): NIS / NEES sums all-reduced like the means ----
         if args.chisq_runs > 0:
             R = min(args.chisq_runs, args.mc_runs)

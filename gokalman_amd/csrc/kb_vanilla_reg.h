@@ -393,54 +393,90 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
                 for (int i = 0; i < NS; i++) xn[i] += wpost[i];   // vanilla.go:195: Process(k) a second time
             }
+            if constexpr (FUSED) {
+                // ---- Joseph form with both multiplications by A = I - K H distributed (kb_vanilla_split.h has the argument):
+                //   AP = P- - K (P- H^T)^T,   P+ = AP + (K R - AP H^T) K^T     [= A P- A^T + K R K^T, vanilla.go:197-205]
+                // 333 FMAs where forming A, A P- and (A P-) A^T takes 567, and no 6 x 6 A in the register file.  The time-fused
+                // kernel is bound by instruction issue (one wave per SIMD), so this is where it pays: 17.4 -> 20+ G filter-steps/s.
+                // AP H^T is formed from the COMPUTED AP: its rounding error (eps |P-|, as that of the reference's A P-) is
+                // multiplied by A^T as in the reference's product.
+#pragma unroll
+                for (int i = 0; i < NS; i++) {   // row by row: only one row of AP is alive at a time
+                    T ap[NS], v[NM];
+#pragma unroll
+                    for (int k = 0; k < NS; k++) {
+                        T s = T(0);
+#pragma unroll
+                        for (int c = 0; c < NM; c++) s += K[i * NM + c] * PHt[k * NM + c];
+                        ap[k] = Pm[symi(i, k)] - s;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NM; c++) {
+                        T s = T(0);
+#pragma unroll
+                        for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
+#pragma unroll
+                        for (int k = 0; k < NS; k++) s -= ap[k] * H[c * NS + k];
+                        v[c] = s;
+                    }
+#pragma unroll
+                    for (int j = i; j < NS; j++) {
+                        T s = ap[j];
+#pragma unroll
+                        for (int c = 0; c < NM; c++) s += v[c] * K[j * NM + c];
+                        Pn[symi(i, j)] = s;
+                    }
+                }
+            } else {
             // ---- Joseph form, upper triangle: P+ = K R K^T + A P- A^T,  A = I - K H
 #pragma unroll
-            for (int i = 0; i < NS; i++) {
-                T kr[NM];
+                for (int i = 0; i < NS; i++) {
+                    T kr[NM];
 #pragma unroll
-                for (int c = 0; c < NM; c++) {
-                    T s = T(0);
+                    for (int c = 0; c < NM; c++) {
+                        T s = T(0);
 #pragma unroll
-                    for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
-                    kr[c] = s;
+                        for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
+                        kr[c] = s;
+                    }
+#pragma unroll
+                    for (int j = i; j < NS; j++) {
+                        T s = T(0);
+#pragma unroll
+                        for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
+                        Pn[symi(i, j)] = s;
+                    }
                 }
+                T A[NS * NS];
 #pragma unroll
-                for (int j = i; j < NS; j++) {
-                    T s = T(0);
+                for (int i = 0; i < NS; i++)
 #pragma unroll
-                    for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
-                    Pn[symi(i, j)] = s;
+                    for (int j = 0; j < NS; j++) {
+                        T s = T(0);
+#pragma unroll
+                        for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
+                        A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
+                    }
+#pragma unroll
+                for (int i = 0; i < NS; i++) {
+                    T ap[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; k++) {
+                        T s = T(0);
+#pragma unroll
+                        for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
+                        ap[k] = s;
+                    }
+#pragma unroll
+                    for (int j = i; j < NS; j++) {
+                        T s = T(0);
+#pragma unroll
+                        for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
+                        Pn[symi(i, j)] = s + Pn[symi(i, j)];
+                    }
                 }
             }
-            T A[NS * NS];
-#pragma unroll
-            for (int i = 0; i < NS; i++)
-#pragma unroll
-                for (int j = 0; j < NS; j++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
-                    A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
-                }
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                T ap[NS];
-#pragma unroll
-                for (int k = 0; k < NS; k++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
-                    ap[k] = s;
-                }
-#pragma unroll
-                for (int j = i; j < NS; j++) {
-                    T s = T(0);
-#pragma unroll
-                    for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
-                    Pn[symi(i, j)] = s + Pn[symi(i, j)];
-                }
             }
-        }
         // ---- non-finite screen (stands in for AsSymDense's NaN-failing comparison)
         T chk = T(0);
 #pragma unroll

@@ -44,7 +44,7 @@ def test_world_size_mismatch_is_refused():
 
 
 SMALL = ["--steps", "30", "--warmup", "5", "--filters", "65536", "--fused-steps", "0", "--ooc-filters", "0",
-         "--mc-runs", "16384", "--mc-steps", "64", "--hybrid-filters", "16384", "--sqrt-filters", "16384", "--srif-filters", "8192", "--shared-filters", "16384",
+         "--mc-runs", "16384", "--mc-steps", "64", "--mc-total", "65536", "--split-filters", "8192", "--hybrid-filters", "16384", "--sqrt-filters", "16384", "--srif-filters", "8192", "--shared-filters", "16384",
          "--no-cpu-baseline"]
 
 
@@ -67,6 +67,18 @@ def test_two_ranks_self_launched_over_gloo_on_one_gpu():
     assert mc2["runs_total"] == 2 * mc1["runs_total"]
     for a, b in zip(mc1["stddev_last"], mc2["stddev_last"]):
         assert abs(a - b) <= 0.05 * abs(a)
+    # the whole ensemble (--mc-total runs IN TOTAL, as consecutive shards per rank + one all-reduce) is the same ensemble on one rank
+    # (four shards) and on two (two shards each): same runs, same noise, sums equal to rounding; and it is what montecarlo.go estimates
+    e1, e2 = mc1["ensemble"], mc2["ensemble"]
+    assert e1["runs_total"] == e2["runs_total"] == 65536 and e1["shards_per_rank"] == 4 and e2["shards_per_rank"] == 2
+    assert e1["matches_covariance_recursion"] and e2["matches_covariance_recursion"]
+    for a, b in zip(e1["stddev_last"], e2["stddev_last"]):
+        assert abs(a - b) <= 1e-9 * abs(a)
+    # every leg proves itself against the oracle on rank 0 (4096 filters x 20 steps), the fp32 SRIF leg reports its achieved error
+    for leg in ("squareroot", "shared_model", "vanilla_12x6", "hybrid_ekf", "srif_fp32"):
+        assert one["extra"][leg]["parity"]["ok"], (leg, one["extra"][leg]["parity"])
+    assert one["extra"]["srif_fp32"]["parity"]["achieved_max_rel_frobenius_R"] <= one["extra"]["srif_fp32"]["parity"]["tolerance"]
+    assert two["extra"]["vanilla_12x6"]["filters_total"] == 2 * 8192 and two["extra"]["vanilla_12x6"]["filters_with_error_status"] == 0
     assert two["extra"]["hybrid_ekf"]["filters_total"] == 2 * 16384
     assert two["extra"]["squareroot"]["filters_total"] == 2 * 16384 and two["extra"]["squareroot"]["filters_with_error_status"] == 0
     assert two["extra"]["srif_fp32"]["filters_total"] == 2 * 8192 and two["extra"]["srif_fp32"]["filters_with_error_status"] == 0

@@ -10,6 +10,9 @@ from oracle import oracle as orc
 from tests import jerkcar as jc
 
 pytestmark = pytest.mark.gpu
+# fp32 SRIF against the fp64 oracle: achieved 1.3e-6 (R) / 2.7e-6 (b) over 4096 filters x 20 Updates (bench.py extra.srif_fp32.parity prints
+# it on every run); the bound is a little under 10x that -- the sequences here contain Predict() steps and 2^18 filters
+SRIF_F32_TOL = 2e-5
 TOL = 1e-9
 
 
@@ -144,7 +147,7 @@ def _nl_models(N, n, p, steps, rng):
 
 
 @pytest.mark.parametrize("pivoting", [False, True])
-@pytest.mark.parametrize("n,p,dtype,tol", [(6, 2, k.F64, 1e-9), (12, 6, k.F64, 1e-9), (12, 6, k.F32, 2e-3)])
+@pytest.mark.parametrize("n,p,dtype,tol", [(6, 2, k.F64, 1e-9), (12, 6, k.F64, 1e-9), (12, 6, k.F32, SRIF_F32_TOL)])
 def test_srif_vs_oracle(n, p, dtype, tol, pivoting):
     """pivoting: Phi = (a different row permutation per filter and step) x (I + noise), so the partial pivoting of
     Phi's LU exchanges rows, differently in every lane of a wave."""

@@ -95,3 +95,33 @@ def test_rccl_reduction_path_with_one_shard():
     kf1 = ga.FilterBatch.new_ldkf(k.VANILLA, *args, nfilters=runs)
     nis1, nees1 = ga.new_chi_square(kf1, mc1, np.zeros((1, 2)))
     assert truth.used_rccl() and np.allclose(nis, nis1, rtol=1e-10) and np.allclose(nees, nees1, rtol=1e-10)
+
+
+def test_config_d_at_its_stated_size_eight_shards_of_2_20_runs_equal_one_8m_run_batch():
+    """BASELINE configs[3] at size: the 8 388 608-run ensemble of the statOD5044 pure predictor (1086 steps) as EIGHT shards of 2^20
+    runs -- kb_sharded_* with eight handles on the one GPU of the test box: the host-sum branch of the reduction the 8-GPU run
+    performs over RCCL -- against ONE batch of 8M runs.  A run's noise depends only on (seed, global run index, step), so both
+    hold the same 8M trajectories; the sums are the same up to the order of the (atomic) floating-point additions, which is why
+    the comparison is 1e-12 relative on the means, not bit for bit.  Both must also be what montecarlo.go:18-59 estimates:
+    Mean(k) = F^k x0, StdDev(k)^2 = diag(sum_j F^j Q F^jT), within 6 standard errors of 8M runs."""
+    s = _statod()
+    runs, steps, seed = 8 << 20, 1086, 2016
+    args = (s["x0"], s["P0"], s["F"], s["G"], s["H"], s["Q"], s["R"])
+    truth = ga.ShardedBatch(k.VANILLA_PREDICT, *args, runs, devices=[0] * 8, noise=k.NOISE_AWGN, seed=seed)
+    assert truth.shards() == 8 and [truth.first(g) for g in range(9)] == [g << 20 for g in range(9)]
+    mc = truth.monte_carlo(steps, np.zeros((1, 2)))
+    assert not truth.used_rccl()
+    del truth
+    one = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, *args, nfilters=runs, noise=k.NOISE_AWGN, seed=seed)
+    mc1 = ga.new_monte_carlo_runs(runs, steps, 2, np.zeros((1, 2)), one, keep_runs=False)
+    del one
+    x, P = s["x0"].copy(), np.zeros((4, 4))
+    for t in range(steps):
+        x, P = s["F"] @ x, s["F"] @ P @ s["F"].T + s["Q"]
+        if t in (0, 1, 10, 100, 500, steps - 1):
+            sd = np.sqrt(np.diag(P))
+            assert np.allclose(mc.mean(t), mc1.mean(t), rtol=1e-12, atol=1e-13 * np.max(sd)), t
+            assert np.allclose(mc.stddev(t), mc1.stddev(t), rtol=1e-9), t
+            for m in (mc, mc1):
+                assert np.all(np.abs(m.mean(t) - x) <= 6 * sd / np.sqrt(runs) + 1e-12 * np.abs(x)), (t, m.mean(t), x)
+                assert np.all(np.abs(m.stddev(t) / sd - 1.0) <= 6 / np.sqrt(2 * runs)), (t, m.stddev(t), sd)

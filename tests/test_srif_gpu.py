@@ -17,6 +17,9 @@ from gokalman_amd import synth
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
+# fp32 SRIF against the fp64 oracle: achieved 1.3e-6 (R) / 2.7e-6 (b) over 4096 filters x 20 Updates (bench.py extra.srif_fp32.parity prints
+# it on every run); the bound is a little under 10x that -- the sequences here contain Predict() steps and 2^18 filters
+SRIF_F32_TOL = 2e-5
 
 
 def _srif_batch(N, n, p, dtype, x0, P0, R, flags=0):
@@ -25,7 +28,7 @@ def _srif_batch(N, n, p, dtype, x0, P0, R, flags=0):
     return b
 
 
-@pytest.mark.parametrize("dtype,tol", [(k.F32, 2e-3), (k.F64, 1e-9)])
+@pytest.mark.parametrize("dtype,tol", [(k.F32, SRIF_F32_TOL), (k.F64, 1e-9)])
 def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
     import torch
     N, n, p, CH = 1 << 18, 12, 6, 4096
@@ -89,7 +92,7 @@ def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
 
 
 @pytest.mark.parametrize("fail_step", [1, 3])   # 1: steady state (triangular R); 3: right after a Predict() (dense R: the skipped filters keep it)
-@pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F32, 2e-3), (12, 6, k.F64, 1e-9), (6, 2, k.F64, 1e-9), (6, 2, k.F32, 2e-3), (5, 2, k.F64, 1e-9)])
+@pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F32, SRIF_F32_TOL), (12, 6, k.F64, 1e-9), (6, 2, k.F64, 1e-9), (6, 2, k.F32, SRIF_F32_TOL), (5, 2, k.F64, 1e-9)])
 def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
     """(5, 2) has no register kernel: the generic one must behave the same."""
     rng = np.random.default_rng(100 * n + fail_step)
@@ -128,7 +131,7 @@ def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
 
 
 @pytest.mark.parametrize("N", [1, 31, 33, 65])
-@pytest.mark.parametrize("dtype,tol", [(k.F32, 2e-3), (k.F64, 1e-9)])
+@pytest.mark.parametrize("dtype,tol", [(k.F32, SRIF_F32_TOL), (k.F64, 1e-9)])
 def test_srif_partial_half_tiles_zero_copy_and_full_estimate(N, dtype, tol):
     """The two-lanes-per-filter kernel owns 32 filters per wave: batches that end inside a half-tile, models read in place from
     planar arrays whose leading dimension exceeds N (kb_prepare_dev), every Estimate member written (FULL_ESTIMATE)."""
@@ -168,7 +171,7 @@ def test_srif_partial_half_tiles_zero_copy_and_full_estimate(N, dtype, tol):
     assert np.isfinite(est.covariance()).all()
 
 
-@pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F64, 1e-9), (12, 6, k.F32, 2e-3), (6, 2, k.F64, 1e-9)])
+@pytest.mark.parametrize("n,p,dtype,tol", [(12, 6, k.F64, 1e-9), (12, 6, k.F32, SRIF_F32_TOL), (6, 2, k.F64, 1e-9)])
 def test_srif_leftover_dense_tiles_and_a_new_failure_update_every_filter_once(n, p, dtype, tol):
     """while some filter may still hold a dense R (it failed the Update that followed a Predict()), every Update
     launches the steady-state kernel AND the dense kernel.  Each half-tile must be taken by exactly one of them, also when a filter
