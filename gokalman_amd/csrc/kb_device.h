@@ -136,7 +136,9 @@ __device__ __forceinline__ bool sym_close(T a, T b) {
 // cond_inf = |A|_inf |A^-1|_inf > 1e16 (gonum matrix.ConditionTolerance), or NaN.
 // ---------------------------------------------------------------------------
 // `nreal`: rows >= nreal are identity padding (kb_vanilla_reg.h PAD) and stay out of the norms.
-template <typename T, int P>
+// FASTDIV: the reciprocals come from recip() (within an ulp of the IEEE quotient, a third of its instructions): the instruction-bound
+// time-fused kernel uses it.
+template <typename T, int P, bool FASTDIV = false>
 __device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P], int nreal = P) {
     T a[P * P], b[P * P];
     T anorm = T(0);
@@ -172,7 +174,7 @@ __device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P],
         }
         const T piv = a[j * P + j];
         bad = bad || (piv == T(0));
-        const T rp = T(1) / piv;
+        const T rp = FASTDIV ? recip(piv) : T(1) / piv;
 #pragma unroll
         for (int r = j + 1; r < P; r++) {
             const T l = a[r * P + j] * rp;
@@ -186,7 +188,7 @@ __device__ __forceinline__ bool inverse_lu(const T (&Ain)[P * P], T (&X)[P * P],
     T inorm = T(0);
 #pragma unroll
     for (int i = P - 1; i >= 0; i--) {
-        const T rd = T(1) / a[i * P + i];
+        const T rd = FASTDIV ? recip(a[i * P + i]) : T(1) / a[i * P + i];
 #pragma unroll
         for (int c = 0; c < P; c++) {
             T s = b[i * P + c];

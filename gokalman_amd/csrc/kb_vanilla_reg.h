@@ -329,6 +329,16 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
             for (int i = 0; i < NS; i++) pin(xm[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // FULL, one step per launch: yhat and (below) the innovation are complete long before they are stored, through the register
+        // peak of the Joseph form.  They wait in LDS ([value][lane]: conflict-free, private to the lane) instead of in registers the
+        // allocator would spill (36 B of scratch per lane otherwise).
+        constexpr bool PARK = FULL && !FUSED && !PAD && sizeof(T) == 8;   // (fp32 and the padded one-wave-per-SIMD variants allocate better without)
+        __shared__ T park_lds[PARK ? KB_VANILLA_WPB * 64 * 2 * NM : 1];
+        [[maybe_unused]] volatile T *park = park_lds + (threadIdx.x >> 6) * (64 * 2 * NM) + lane;
+        if constexpr (PARK) {
+#pragma unroll
+            for (int r = 0; r < NM; r++) park[r * 64] = yhat[r];
+        }
         // ---- gain K = P- H^T (H P- H^T + R)^-1
         T PHt[NS * NM];
 #pragma unroll
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
                 for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
                 S[r * NM + c] = s + R[symi(r, c)];
             }
-        unsigned err = inverse_lu<T, NM>(S, Si, rp) ? KB_ST_SINGULAR : 0u;
+        unsigned err = inverse_lu<T, NM, FUSED>(S, Si, rp) ? KB_ST_SINGULAR : 0u;
         T K[NS * NM];
 #pragma unroll
         for (int i = 0; i < NS; i++)
@@ -393,11 +403,18 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
                 for (int i = 0; i < NS; i++) xn[i] += wpost[i];   // vanilla.go:195: Process(k) a second time
             }
+            if constexpr (PARK) {
+#pragma unroll
+                for (int r = 0; r < NM; r++) park[(NM + r) * 64] = innov[r];
+            }
             if constexpr (FUSED) {
                 // ---- Joseph form with both multiplications by A = I - K H distributed (kb_vanilla_split.h has the argument):
                 //   AP = P- - K (P- H^T)^T,   P+ = AP + (K R - AP H^T) K^T     [= A P- A^T + K R K^T, vanilla.go:197-205]
                 // 333 FMAs where forming A, A P- and (A P-) A^T takes 567, and no 6 x 6 A in the register file.  The time-fused
-                // kernel is bound by instruction issue (one wave per SIMD), so this is where it pays: 17.4 -> 20+ G filter-steps/s.
+                // kernel is bound by instruction issue (one wave per SIMD), so this is where it pays: 17.4 -> 19.5+ G filter-steps/s.
+                // The per-step kernels are bound by HBM and keep the reference's order of operations: on a DEGENERATE problem (zero
+                // noise matrices, the state pinned down exactly -- BatchNoise, noise.go:89-98) results are rounding noise amplified,
+                // and only the same operations in the same order reproduce the reference's digits there.
                 // AP H^T is formed from the COMPUTED AP: its rounding error (eps |P-|, as that of the reference's A P-) is
                 // multiplied by A^T as in the reference's product.
 #pragma unroll
@@ -507,8 +524,13 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
                 for (int r = 0; r < NM; r++) {
                     if (r < rp) {
-                        stnt(esI, r, innov[r]);
-                        stnt(esY, r, yhat[r]);
+                        if constexpr (PARK) {
+                            stnt(esI, r, (T)(PREDICT ? T(0) : park[(NM + r) * 64]));
+                            stnt(esY, r, (T)park[r * 64]);
+                        } else {
+                            stnt(esI, r, innov[r]);
+                            stnt(esY, r, yhat[r]);
+                        }
                     }
                 }
             }

@@ -233,16 +233,16 @@ template <typename T, int NS, int NM, int L>
 constexpr int split_waves_per_simd() { return (int)sizeof(T) * split_lds_elems<NS, NM>() * (64 / L) * 8 <= 160 * 1024 ? 2 : 1; }
 
 #define KB_SB() __builtin_amdgcn_sched_barrier(0)
-// Where the later operands are requested (A/B on the box, profiles/NOTES.md): "as late as the registers' first use allows" beat
-// every earlier placement -- the kernel is not short of requests in flight, and early requests cost registers (spills)
+// Where the later operands are requested (A/B runs on one box, profiles/NOTES.md): H at the start of the P- loop and R, y at the start
+// of the P- H^T loop (2-4 % ahead of requesting them at their first use); Q only when F has gone to LDS (earlier costs spills)
 #ifndef KB_SPLIT_HJ
-#define KB_SPLIT_HJ (NS / 2)
+#define KB_SPLIT_HJ 0
 #endif
 #ifndef KB_SPLIT_RL
 #define KB_SPLIT_RL NS   // < NS: R is requested again at that step of the A P- loop; NS: at the start of the loop behind it
 #endif
 #ifndef KB_SPLIT_R1LATE
-#define KB_SPLIT_R1LATE 1
+#define KB_SPLIT_R1LATE 0
 #endif
 #ifndef KB_SPLIT_QK
 #define KB_SPLIT_QK NS   // < NS: Q is requested at that step of the T = F P loop; NS: when F has gone to LDS
