@@ -35,6 +35,20 @@
 
 namespace kb {
 
+// Diagnostic builds only (scripts/srif_phases.sh, profiles/<tag>/srif_phases.md): -DKB_SRIF_STOP=k ends the Update after phase k --
+// 1 operands loaded + State(prev), 2 xBar + LU of Phi, 3 whitened measurement rows, 4 RBar and bBar -- with everything computed so
+// far kept alive by a store that never happens; the differences between the variants' times are the phases' costs under load.
+#ifndef KB_SRIF_STOP
+#define KB_SRIF_STOP 0
+#endif
+#define KB_SRIF_STOP_AT(k, sum_expr)                                        \
+    if constexpr (KB_SRIF_STOP == (k)) {                                    \
+        T sink__ = T(0);                                                    \
+        sum_expr;                                                           \
+        if (sink__ == T(-1.2345e30)) st[vf] = sink__;                       \
+        return;                                                             \
+    }
+
 // ---- exchange between lane f and lane 32 + f -------------------------------------------------------
 __device__ __forceinline__ void halves(unsigned x, unsigned &lo, unsigned &hi) {
     const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // [x.lo | x.lo], [x.hi | x.hi]
@@ -247,6 +261,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             for (int s = 0; s <= si; s++) acc[s] -= A.get(s, i) * xprev[i];   // rows 2 s + l < i; the structural zeros contribute 0
         }
     }
+    KB_SRIF_STOP_AT(1, {
+        for (int i = 0; i < NS; i++) sink__ += xprev[i];
+        for (int e = 0; e < NS * HS; e++) sink__ += pc[e];
+        if constexpr (!MEAS_LATE) { for (int e = 0; e < NM * HS; e++) sink__ += Hc[e]; for (int e = 0; e < tri(NM); e++) sink__ += Lw[e]; for (int e = 0; e < NM; e++) sink__ += yv[e]; }
+    })
     // ---- xBar = Phi State(prev) (srif.go:118): each half sums over its columns ------------------------------------------
     T xbar[NS];
     {
@@ -303,6 +322,12 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         }
     }
     const bool anyswap = __any(perm != 0xBA9876543210ull);
+    KB_SRIF_STOP_AT(2, {
+        for (int i = 0; i < NS; i++) sink__ += xbar[i];
+        for (int e = 0; e < NS * HS; e++) sink__ += pc[e];
+        for (int s2 = 0; s2 < HS; s2++) for (int j = 0; j < NS; j++) sink__ += A.get(s2, j);
+        if constexpr (!MEAS_LATE) { for (int e = 0; e < NM * HS; e++) sink__ += Hc[e]; for (int e = 0; e < tri(NM); e++) sink__ += Lw[e]; for (int e = 0; e < NM; e++) sink__ += yv[e]; }
+    })
     // the factors go to LDS, [element][32 filters]: element (r, 2 cs + l) from this lane; the solves below read every
     // element from both halves (lanes f and 32 + f read the same word: a broadcast, no bank conflict)
 #pragma unroll
@@ -357,6 +382,13 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     };
     if constexpr (!MEAS_LATE) whiten();
 
+    if constexpr (!MEAS_LATE) {
+        KB_SRIF_STOP_AT(3, {
+            for (int i = 0; i < NS; i++) sink__ += xbar[i];
+            for (int s2 = 0; s2 < SL; s2++) for (int j = 0; j <= NS; j++) sink__ += A.get(s2, j);
+            for (int e = 0; e < NS * HS; e++) sink__ += pc[e];
+        })
+    }
     __builtin_amdgcn_sched_barrier(0);   // (!MEAS_LATE) the measurement operands are dead from here on
     // ---- RBar = R Phi^-1 (srif.go:115) for the own rows: z Phi = R[i,:], i.e. w U = r, v L = w, z[perm_k] = v_k --------
     // A[s][0..NS) is z for row 2 s + l; columns < 2 s are structural zeros (skipped) unless DENSE
@@ -480,6 +512,9 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         }
     }
 
+    KB_SRIF_STOP_AT(4, {
+        for (int s2 = 0; s2 < SL; s2++) for (int j = 0; j <= NS; j++) sink__ += A.get(s2, j);
+    })
     __builtin_amdgcn_sched_barrier(0);
     // ---- HouseholderTransf (helper.go:142-172) with the rows split over the halves ----------------------------------
     T chk = T(0);

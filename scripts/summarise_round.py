@@ -26,7 +26,7 @@ def short(name):
 
 
 def condense():
-    out = {"stats": {}, "pmc": {}}
+    out = {"stats": {}, "pmc": {}, "source_hash": rl.kernel_source_hash(ROOT)}   # the sources the counters were measured on
     for d in sorted(glob.glob(os.path.join(SRC, "*"))):
         if not os.path.isdir(d):
             continue
@@ -93,7 +93,8 @@ def main():
     md.append("| kernel | launches | read B | written B | total B | per filter |\n|---|---|---|---|---|---|")
     filters = {"vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, true": 1 << 20,   # AWGN (bench_kinds vnoise)
                "vanilla_reg_kernel<double, 6, 3, 0": 1 << 20, "squareroot_reg_kernel<double, 6, 3": 1 << 20, "information_reg_kernel<double, 6, 3": 1 << 20,
-               "hybrid_reg_kernel<double, 6, 2": 1 << 20, "srif_pair_kernel<float, 12, 6": 1 << 18, "srif_pair_kernel<double, 12, 6": 1 << 18}
+               "hybrid_reg_kernel<double, 6, 2": 1 << 20, "srif_pair_kernel<float, 12, 6": 1 << 18, "srif_pair_kernel<double, 12, 6": 1 << 18,
+               "vanilla_split_kernel<double, 12, 6": 1 << 18}
     for fkey, wkey in (("bench_fetch", "bench_write"), ("kinds_fetch", "kinds_write")):
         fe, wr = c["pmc"].get(fkey, {}), c["pmc"].get(wkey, {})
         for kn, e in fe.items():
@@ -153,11 +154,11 @@ def main():
     open(os.path.join(DST, "summary.md"), "w").write("\n".join(md) + "\n")
     json.dump({"tag": tag, "head": head, "condensed": c}, open(os.path.join(DST, "summary.json"), "w"), indent=1)
     if traffic:
-        json.dump({"tag": tag, "head": head, "source_hash": rl.kernel_source_hash(ROOT), "kernels": traffic,
+        json.dump({"tag": tag, "head": head, "source_hash": c.get("source_hash", rl.kernel_source_hash(ROOT)), "kernels": traffic,
                    "note": "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE; separate --pmc passes; the counters sit on the "
                            "L2's fabric side and include Infinity-Cache hits"}, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
     if named:
-        json.dump({"tag": tag, "head": head, "source_hash": rl.kernel_source_hash(ROOT), "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
+        json.dump({"tag": tag, "head": head, "source_hash": c.get("source_hash", rl.kernel_source_hash(ROOT)), "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
                   open(os.path.join(ROOT, "profiles", "valu_latest.json"), "w"), indent=1)
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resource_usage.py"), "--md", os.path.join(DST, "resource_usage.md"),
                     "reg_kernel", "srif_", "mc_kernel", "chisq_kernel"], stdout=subprocess.DEVNULL)
