@@ -114,6 +114,28 @@ __device__ __forceinline__ double recip(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
+// threadIdx.x as a value the optimiser cannot connect to earlier uses: what is derived from it HERE is computed here, not kept alive
+// from the top of the kernel (address terms that are needed once, late)
+__device__ __forceinline__ unsigned late_lane() {
+    unsigned t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// Element (rt + c) of a tile block -- rt wave-uniform at run time, c a compile-time constant -- as (scalar anchor made opaque to the
+// optimiser) + (an immediate within +-8 elements), in the global address space; the lane adds ONE unsigned 32-bit element offset:
+// the scalar-base form of global_load.  Left alone, instruction selection adds the part of c that does not fit the 13-bit immediate
+// to the VECTOR half of the address: a 64-bit VGPR pair and a v_lshl_add_u64 per 8 elements, formed at the top of the kernel and
+// carried (or spilled) to the access (kb_vanilla_split.h; the late reads of kb_information_reg.hip).
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *anchored(const T *ubase, int rt, int c) {
+    typedef const __attribute__((address_space(1))) T *gptr;
+    const int anchor = (c >= 0 ? c / 16 : -((-c + 15) / 16)) * 16 + 8;
+    unsigned long long s = (unsigned long long)(ubase + (int64_t)(rt + anchor) * KB_TILE);
+    asm("" : "+s"(s));
+    return (gptr)s + (c - anchor) * KB_TILE;
+}
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double tiny = 2.2250738585072014e-308; };
 template <> struct Eps<float>  { static constexpr float  tiny = 1.17549435e-38f; };

@@ -280,7 +280,16 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
     if constexpr (FULL) {
         __builtin_amdgcn_sched_barrier(0);
         T Pp[NS * NS], xp[NS], yhat[NM];
+        // H (and chol R) are read again here, long after the top of the kernel: through anchored() (kb_device.h), or their 18 + 6
+        // vector addresses are formed up there, carried through the 6 x 6 inverse and spilled (180 B of scratch, one wait per reload)
+        const int64_t tile_u = (int64_t)blockIdx.x * INFO_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // the tile index as a scalar
+        const T *const mo_u = SHARED ? (const T *)a.model : (const T *)a.model + tile_u * a.mo_ts;
         const bool bad = inverse_lu<T, NS>(Iprev, Pp, rn);
+        const unsigned mo_lane = (SHARED || a.mo_ts == 0) ? 0u : (late_lane() & 63u);   // (formed behind the inverse, not carried through it)
+        auto late_mo = [&](int rt, int c) __attribute__((always_inline)) {
+            const auto gp = anchored(mo_u, rt, c) + mo_lane;
+            return SHARED ? *gp : __builtin_nontemporal_load(gp);
+        };
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             T s = T(0);
@@ -295,23 +304,28 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         for (int r = 0; r < NM; r++) {
             T s = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? ldmo(mo, a.L.mo_H + r * rn + l) : T(0)) * xp[l];
+            for (int l = 0; l < NS; l++) s += ((r < rp && l < rn) ? late_mo(a.L.mo_H + (PAD ? r * rn : 0), (PAD ? 0 : r * NS) + l) : T(0)) * xp[l];
             yhat[r] = s;
         }
         if constexpr (NOISE) {
 #pragma unroll
             for (int r = 0; r < NM; r++) pin(yhat[r]);
             __builtin_amdgcn_sched_barrier(0);
-            const TilePtr<const T> mot{(const T *)a.model + tile * a.mo_ts, a.mo_ts ? (unsigned)lane : 0u};
             const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
             T z1[NM], v[NM];
             draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
-            chol_times<T, NM>(mot.field(a.L.mo_LR), rp, z1, v);
+#pragma unroll
+            for (int i = 0; i < NM; i++) {   // v = chol(R) z (chol_times, kb_vanilla_reg.h), the factor read through anchored()
+                T sacc = T(0);
+#pragma unroll
+                for (int kk = 0; kk <= i; kk++) sacc += ((i < rp) ? late_mo(a.L.mo_LR, symi(kk, i)) : T(0)) * z1[kk];
+                v[i] = sacc;
+            }
 #pragma unroll
             for (int r = 0; r < NM; r++) yhat[r] += v[r];
         }
-        T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
+        T *es = (T *)a.est + tile_u * ((int64_t)KB_TILE * a.L.es_elems) + (late_lane() & 63u);   // (formed here: kept from the top it costs a spilled register pair)
         if (active && ok) {
 #pragma unroll
             for (int r = 0; r < NM; r++)

@@ -122,14 +122,6 @@ __device__ __forceinline__ void sum_lanes2(T &a, T &b) {
     }
 }
 
-// threadIdx.x as a value the optimiser cannot connect to earlier uses: what is derived from it HERE is computed here, not kept alive
-// from the top of the kernel (address terms that are needed once, late)
-__device__ __forceinline__ unsigned late_lane() {
-    unsigned t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
-
 // LDS accesses of one phase become visible to the other lanes of the wave: DS operations of a wave execute in order, so all that
 // is needed is that the COMPILER keeps the stores in front of the loads (per thread they go to different addresses)
 __device__ __forceinline__ void wave_lds_fence() {
@@ -302,13 +294,9 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     // ep(base, rt, c): element (rt + c) of a block -- rt wave-uniform at run time, c a compile-time constant -- as (scalar anchor,
     // made opaque to the optimiser) + (immediate within +-8 elements): left alone, instruction selection adds the part of c that
     // does not fit the 13-bit immediate to the VECTOR half of the address (a 64-bit VGPR pair and a v_lshl_add_u64 per 8 elements).
-    typedef __attribute__((address_space(1))) T *gptr;   // (the asm hides where the pointer came from: say that it is global memory)
-    auto ep = [&](const T *ubase, int rt, int c) -> gptr {
-        const int anchor = (c >= 0 ? c / 16 : -((-c + 15) / 16)) * 16 + 8;
-        unsigned long long s = (unsigned long long)(ubase + (int64_t)(rt + anchor) * KB_TILE);
-        asm("" : "+s"(s));
-        return (gptr)s + (c - anchor) * KB_TILE;
-    };
+    // ep(base, rt, c): element (rt + c) of a block as (opaque scalar anchor) + (immediate): kb_device.h anchored()
+    typedef __attribute__((address_space(1))) T *gptr;
+    auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
     auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
     auto ldst = [&](auto NT, int rt, int c, unsigned off) {   // state block, cache policy NT (kb_vanilla_reg.h)
         const gptr pe = ep(st, rt, c) + off;

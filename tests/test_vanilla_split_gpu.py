@@ -207,3 +207,39 @@ def test_split_batch_noise_vs_oracle(n, p):
     assert not b.status().any()
     assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-7
     assert synth.rel_frobenius(est.measurement(), np.array(ys)) <= 1e-7
+
+
+def test_split_shared_model_one_filter_batches_and_measurement_dimension_changes():
+    """The uses around the benchmark shape: (a) ONE model for all filters (every model field uploaded with broadcast = 1: the wave reads
+    tile 0's model block) gives the bits of the same batch with per-filter copies; (b) a batch of ONE 12-state filter through the
+    host path with every Estimate member (the drop-in use: pinned staging, FULL); (c) SetMeasurementMatrix / SetNoise with a smaller
+    measurement dimension between steps (examples/jerkcar/main.go:141-159 does that every tenth step)."""
+    N, n, p, steps = 200, 12, 6, 5
+    d = _model(N, n, p, 0, steps, 4711)
+    shared = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"][0], None, d["H"][0], d["Q"][0], d["R"][0], nfilters=N)
+    rep = lambda v: np.ascontiguousarray(np.broadcast_to(v[0], v.shape))
+    perf = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], rep(d["F"]), None, rep(d["H"]), rep(d["Q"]), rep(d["R"]))
+    for t in range(steps):
+        shared.update(d["y"][t]); perf.update(d["y"][t])
+    assert np.array_equal(shared.get(k.STATE), perf.get(k.STATE)) and np.array_equal(shared.get(k.COVAR), perf.get(k.COVAR))
+    # (b) + (c): one filter, p = 6 -> 3 -> 6
+    i = 17
+    one = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i], flags=k.FLAG_FULL_ESTIMATE, pmax=p)
+    f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i])
+    H3, R3 = d["H"][i][:3], d["R"][i][:3, :3]
+    for t in range(steps):
+        if t == 2:
+            one.set_measurement_matrix(H3); one.set_noise(d["Q"][i], R3)
+            f.set_measurement_matrix(H3); f.set_noise(d["Q"][i], R3)
+        if t == 4:
+            one.set_measurement_matrix(d["H"][i]); one.set_noise(d["Q"][i], d["R"][i])
+            f.set_measurement_matrix(d["H"][i]); f.set_noise(d["Q"][i], d["R"][i])
+        y = d["y"][t, i][:3] if t in (2, 3) else d["y"][t, i]
+        est = one.update(y)
+        assert f.update(y) == orc.OK
+        assert synth.rel_frobenius(est.state().reshape(1, -1), f.state().reshape(1, -1)) <= TOL, t
+        assert synth.rel_frobenius(est.covariance().reshape(1, -1), f.covariance().reshape(1, -1)) <= TOL, t
+        assert synth.rel_frobenius(est.pred_covariance().reshape(1, -1), f.pred_covariance().reshape(1, -1)) <= TOL, t
+        assert synth.rel_frobenius(est.gain().reshape(1, -1), f.gain().reshape(1, -1)) <= TOL, t
+        assert np.max(np.abs(est.innovation().ravel() - f.innovation())) <= 1e-9 and np.max(np.abs(est.measurement().ravel() - f.measurement())) <= 1e-9
+    assert one.step() == steps
