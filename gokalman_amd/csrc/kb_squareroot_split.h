@@ -1,0 +1,578 @@
+// kb_squareroot_split.h -- SquareRoot.Update (squareroot.go:129-274) for 6 < n <= 16 with ONE FILTER SPLIT OVER L LANES.
+//
+// The one-filter-per-lane kernel (kb_squareroot_reg.hip) holds the 2n x n and (n + p) x (n + p) Householder panels in one lane's
+// registers: 9 x 9 at 6 / 3, but 24 x 12 + 18 x 18 = 612 values at 12 / 6.  Here, as in kb_vanilla_split.h, a wave owns 64 / L
+// filters (lane = q (64 / L) + f: 128-byte segments at L = 4), and the panels are distributed BY COLUMNS:
+//
+//   columns        lane q owns columns q, q + L, ... of C = [S^T F^T ; sqrtQ^T] and of Delta's state block, and measurement columns
+//                  q, q + L, ... of Delta.  Column j of S^T F^T is row j of F S: (own row of F) x (all of S), S broadcast through LDS
+//                  (packed, as P in the Vanilla kernel); column j of sqrtQ^T is row j of chol(Q): the lane's own rows.
+//   Householder    (Dgeqr2 / Dlarfg as kb_static.h sqr_r states them) the reflector of column k is formed by the ONE lane that owns
+//                  the column -- norm, beta, u0, 1 / (beta u0): no sum over lanes -- and handed to the other lanes of the filter
+//                  through LDS (n + 2 values per step); every lane then applies it to its own columns right of k: the dot products
+//                  u . C[:, c] are local as well.  Cyclic ownership keeps the shrinking set of active columns spread over the lanes.
+//   results        Uc (= S-, the quirk of squareroot.go:185) goes to LDS once (packed) for Delta's S-^T H^T and S-^T blocks; of the
+//                  second factor, W^T and S+^T are the top / bottom parts of the lane's own state columns (so K = W Syy^-1 and the
+//                  store of S+ need nothing from other lanes); Syy (p x p) is gathered through LDS and inverted by every lane.
+//
+// Same operations in the same order as the register kernel per panel entry (the sums run over the rows of a column in ascending
+// order, structural zeros skipped as ActC / ActD do); the padded family (GEN) relies on the same facts: a zero column makes no
+// reflection, chol(R) is padded with an identity block.
+#pragma once
+#include "kb_vanilla_split.h"
+
+namespace kb {
+
+#define KB_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int NS, int NM>
+constexpr int sqsplit_lds_elems() { return tri(NS) + 2 * NS + 2; }   // S / Uc packed | the reflector of one column step (u0, f, then <= 2 n rows; n + p <= 2 n)
+
+// Dlarfg for one column (kb_static.h sqr_r): given alpha = a[k][k] and the squared norm of the active entries below it, the
+// unnormalised reflector H = I + f u u^T, u = (u0, x); returns the new diagonal entry
+template <typename T>
+__device__ __forceinline__ T reflector(T alpha, T xnorm2, bool more_rows, T &u0, T &f) {
+    const bool refl = more_rows && (xnorm2 != T(0));
+    const T beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+    u0 = alpha - beta;
+    f = refl ? T(1) / (beta * u0) : T(0);
+    return refl ? beta : alpha;
+}
+
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT>
+__device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const int64_t gw, T *lds) {
+    static_assert(NS % L == 0, "columns are dealt out cyclically");
+    constexpr int FPW = 64 / L, RP = NS / L, PC = (NM + L - 1) / L, TR = tri(NS), TM = tri(NM), DD = NS + NM;
+    constexpr int BOFF = TR;   // LDS: [0, TR) S, later Uc, later the gathers; [TR, TR + DD + 2) the reflector of the current step
+    typedef __attribute__((address_space(1))) T *gptr;
+    const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
+    const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
+    const bool awgn = GEN && a.noise_kind == KB_NOISE_AWGN;
+    const unsigned lane = threadIdx.x;
+    const int q = (int)((lane / FPW) & (L - 1)), f = (int)(lane & (FPW - 1));
+    const int64_t tile = gw / L;
+    const int slot = (int)(gw % L) * FPW + f;
+    if (tile * KB_TILE + (gw % L) * FPW >= a.N) return;
+    const bool active = tile * KB_TILE + slot < a.N;
+
+    T *const st = (T *)a.state + tile * ((int64_t)KB_TILE * (rn + tri(rn)));
+    const T *const mo = (const T *)a.model + tile * a.mo_ts;
+    const unsigned us = (unsigned)slot;
+    const unsigned um = a.mo_ts ? (unsigned)slot : 0u;
+    const unsigned uq = us + (unsigned)(q * KB_TILE);
+    const unsigned uf = um + (unsigned)(q * rn * KB_TILE);   // row q of an n-column matrix of the model block (F, and H's row q)
+    T *lf = lds + f;
+    T *lq = lf + q * FPW;
+    auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
+    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
+    bool colok[RP], colany[RP];   // own column / row j_r = q + L r is a real one; some lane's is (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < RP; r++) { colok[r] = !GEN || q + L * r < rn; colany[r] = !GEN || L * r < rn; }
+    unsigned utri[RP];   // 64 tri(j_r): row j_r of a packed lower-triangular matrix (chol Q, S) starts there
+#pragma unroll
+    for (int r = 0; r < RP; r++) utri[r] = (unsigned)(((q + L * r) * (q + L * r + 1) / 2) * KB_TILE);
+
+    // ---- phase 0: F (own rows), x, S (a packed share per lane, handed to LDS) ----------------------------------------------------
+    T Fo[RP][NS], x[NS];
+    {
+        constexpr int KP = (TR + L - 1) / L;
+        T Sp[KP];
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                const T v = (colany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, colok[r] ? uf : um) : T(0);
+                Fo[r][l] = colok[r] ? v : T(0);
+            }
+        auto load_state = [&](auto NT) {
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const bool okp = L * k + q < tri(rn);
+                const gptr pe = ep(st, rn, L * k) + (okp ? uq : us);
+                const T v = L * k < tri(rn) ? (decltype(NT)::value ? __builtin_nontemporal_load(pe) : *pe) : T(0);
+                Sp[k] = okp ? v : T(0);
+            }
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                const gptr pe = ep(st, 0, l) + us;
+                x[l] = l < rn ? (decltype(NT)::value ? __builtin_nontemporal_load(pe) : *pe) : T(0);
+            }
+        };
+        KB_WITH_STATE_POLICY(a, load_state);
+        KB_SB();
+#pragma unroll
+        for (int k = 0; k < KP; k++)
+            if (L * k + L - 1 < TR || L * k + q < TR) lf[(L * k + q) * FPW] = Sp[k];
+    }
+    wave_lds_fence();
+    KB_SB();
+
+    // ---- phase 1: x- = F x [+ G u]; the top block of C, own columns: C[i][j] = sum_{l >= i} S[l][i] F[j][l] (squareroot.go:155-175),
+    // one row of S per chunk (row l of S is packed contiguously: S[l][i] at tri(l) + i) ------------------------------------------------
+    T xm[RP], Ct[RP][NS], Cb[RP][NS];
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+        T s = T(0);
+#pragma unroll
+        for (int l = 0; l < NS; l++) s += Fo[r][l] * x[l];
+        xm[r] = s;
+        pin(xm[r]);
+#pragma unroll
+        for (int i = 0; i < NS; i++) Ct[r][i] = T(0);
+    }
+    if constexpr (NC > 0) {
+        if (rm > 0) {
+            const T *up = (const T *)a.u + tile * a.u_ts;
+            T u[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) u[c] = (active && c < rm) ? ldnt_at(&(up + (int64_t)c * a.u_es)[us]) : T(0);
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                T s = T(0);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const T g = (colany[r] && c < rm) ? ldg(mo, a.L.mo_G + L * r * rm, c, colok[r] ? um + (unsigned)(q * rm * KB_TILE) : um) : T(0);
+                    s += (colok[r] ? g : T(0)) * u[c];
+                }
+                xm[r] = xm[r] + s;
+            }
+        }
+    }
+    {
+        T row[2][NS];
+        auto fetch = [&](int l, int b) {
+#pragma unroll
+            for (int i = 0; i <= l; i++) row[b][i] = lf[(l * (l + 1) / 2 + i) * FPW];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int l = 0; l < NS; l++) {
+            if (l + 1 < NS) fetch(l + 1, (l + 1) & 1);
+            KB_SB();
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int i = 0; i <= l; i++) { Ct[r][i] += row[l & 1][i] * Fo[r][l]; pin(Ct[r][i]); }
+            KB_SB();
+        }
+    }
+    // the bottom block: column j of sqrtQ^T = row j of chol(Q) (the lane's own rows, packed contiguously), zero below the diagonal
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T v = T(0);
+            if (colany[r] && i < rn && i < L * r + L) v = ldg(mo, a.L.mo_LQ, i, (colok[r] && i <= q + L * r) ? um + utri[r] : um);
+            Cb[r][i] = (colok[r] && i <= q + L * r) ? v : T(0);
+        }
+    KB_SB();
+
+    // ---- Householder on C (2n x n; Dgeqr2): column k's owner forms the reflector, everybody applies it to the own columns c > k --------
+    wave_lds_fence();   // (the S reads are done; the reflector buffer is a different region, but the compiler does not know the lanes)
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int rk = k / L, qk = k % L;   // compile-time after unrolling
+        {   // the owner's part, computed by every lane on its local column rk; only lane group qk publishes it
+            T xn2 = T(0);
+#pragma unroll
+            for (int i = k + 1; i < NS; i++) xn2 += Ct[rk][i] * Ct[rk][i];
+#pragma unroll
+            for (int i = 0; i <= k; i++) xn2 += Cb[rk][i] * Cb[rk][i];
+            T u0, fr;
+            const T dg = reflector<T>(Ct[rk][k], xn2, true, u0, fr);
+            if (q == qk) {
+                lf[(BOFF + 0) * FPW] = u0;
+                lf[(BOFF + 1) * FPW] = fr;
+#pragma unroll
+                for (int i = k + 1; i < NS; i++) lf[(BOFF + 2 + i) * FPW] = Ct[rk][i];
+#pragma unroll
+                for (int i = 0; i <= k; i++) lf[(BOFF + 2 + NS + i) * FPW] = Cb[rk][i];   // (the bottom rows sit behind the n top slots)
+                Ct[rk][k] = dg;
+            }
+        }
+        wave_lds_fence();
+        {
+            const T u0 = lf[(BOFF + 0) * FPW], fr = lf[(BOFF + 1) * FPW];
+            T ut[NS], ub[NS];
+#pragma unroll
+            for (int i = k + 1; i < NS; i++) ut[i] = lf[(BOFF + 2 + i) * FPW];
+#pragma unroll
+            for (int i = 0; i <= k; i++) ub[i] = lf[(BOFF + 2 + NS + i) * FPW];
+#pragma unroll
+            for (int r = rk; r < RP; r++) {
+                const bool upd = r > rk || q > qk;   // own column q + L r lies right of k
+                T s = u0 * Ct[r][k];
+#pragma unroll
+                for (int i = k + 1; i < NS; i++) s += ut[i] * Ct[r][i];
+#pragma unroll
+                for (int i = 0; i <= k; i++) s += ub[i] * Cb[r][i];
+                const T fs = upd ? fr * s : T(0);
+                Ct[r][k] += fs * u0;
+#pragma unroll
+                for (int i = k + 1; i < NS; i++) Ct[r][i] += fs * ut[i];
+#pragma unroll
+                for (int i = 0; i <= k; i++) Cb[r][i] += fs * ub[i];
+            }
+#pragma unroll
+            for (int r = rk; r < RP; r++)
+#pragma unroll
+                for (int i = 0; i < NS; i++) { pin(Ct[r][i]); pin(Cb[r][i]); }
+        }
+        wave_lds_fence();
+        KB_SB();
+    }
+    // Uc[i][j] = Ct[r][i], i <= j = j_r: S- := Uc (QUIRK squareroot.go:185).  It goes to LDS packed by columns (tri(j) + i): the own
+    // columns are contiguous.  FULL: the Estimate's predicted factor leaves at once (as in kb_squareroot_reg.hip).
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int i = 0; i < L * r + L; i++)
+            if (i <= q + L * r) (lf + (utri[r] / KB_TILE) * FPW)[i * FPW] = Ct[r][i];
+    if (full && active) {
+        T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int i = 0; i < L * r + L; i++)
+                if (colok[r] && i <= q + L * r) __builtin_nontemporal_store(Ct[r][i], ep(es, a.L.es_ppred, i) + (us + utri[r]));
+    }
+    wave_lds_fence();
+    KB_SB();
+
+    // ---- Delta = [[sqrtR^T, 0], [S-^T H^T, S-^T]] (squareroot.go:190-216), by columns ------------------------------------------------
+    // measurement columns c = q + L r2: top = row c of chol(R) (own row), bottom (S-^T H^T)[i][c] = sum_{l <= i} Uc[l][i] H[c][l]
+    T Dm[PC][DD], Ds[RP][DD];
+    bool mcol[PC];   // own measurement column exists (c < NM); real (c < rp) or identity padding
+    [[maybe_unused]] T hxp[PC];   // FULL: (H x_prev)[c] for the own measurement rows
+    {
+        T Hrow[PC][NS];
+#pragma unroll
+        for (int r2 = 0; r2 < PC; r2++) {
+            const int cbase = L * r2;
+            mcol[r2] = cbase + L - 1 < NM || q + cbase < NM;
+            const bool real = mcol[r2] && q + cbase < rp;
+            const unsigned urow = real ? um + (unsigned)((q + cbase) * rn * KB_TILE) : um;
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                const T v = (cbase < rp && l < rn) ? ldg(mo, a.L.mo_H, l, urow) : T(0);
+                Hrow[r2][l] = real ? v : T(0);
+            }
+            const unsigned utr = real ? um + (unsigned)(((q + cbase) * (q + cbase + 1) / 2) * KB_TILE) : um;
+#pragma unroll
+            for (int rr = 0; rr < NM; rr++) {
+                T v = T(0);
+                if (cbase < rp && rr < cbase + L && rr < rp) v = ldg(mo, a.L.mo_LR, rr, utr);
+                Dm[r2][rr] = real ? (rr <= q + cbase ? v : T(0)) : ((mcol[r2] && rr == q + cbase) ? T(1) : T(0));
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) Dm[r2][NM + i] = T(0);
+        }
+        if (full) {   // squareroot.go:237-239 yhat = H x_prev: x is read a second time (a cache hit), not kept through the first factorisation
+#pragma unroll
+            for (int r2 = 0; r2 < PC; r2++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += Hrow[r2][l] * ((l < rn) ? *(ep(st, 0, l) + us) : T(0));
+                hxp[r2] = s;
+            }
+        }
+        // bottom rows, one column of Uc per chunk (column i of Uc is packed contiguously: Uc[l][i] at tri(i) + l)
+        T col[2][NS];
+        auto fetch = [&](int i, int b) {
+#pragma unroll
+            for (int l = 0; l <= i; l++) col[b][l] = lf[(i * (i + 1) / 2 + l) * FPW];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            if (i + 1 < NS) fetch(i + 1, (i + 1) & 1);
+            KB_SB();
+#pragma unroll
+            for (int r2 = 0; r2 < PC; r2++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l <= i; l++) s += col[i & 1][l] * Hrow[r2][l];
+                Dm[r2][NM + i] = s;
+                pin(Dm[r2][NM + i]);
+            }
+            KB_SB();
+        }
+        // H x- for the innovation (squareroot.go:255-262): x- is gathered through LDS (its rows are spread over the lanes), the own
+        // measurement rows are formed here, and gathered below
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = xm[r];
+        wave_lds_fence();
+        T hx[PC];
+#pragma unroll
+        for (int r2 = 0; r2 < PC; r2++) {
+            T s = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) s += Hrow[r2][l] * lf[(BOFF + l) * FPW];
+            hx[r2] = s;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r2 = 0; r2 < PC; r2++)
+            if (mcol[r2]) lq[(BOFF + NS + L * r2) * FPW] = hx[r2];
+    }
+    // state columns p + j, j = j_r: top zero, bottom S-^T[i][j] = Uc[j][i] for i >= j (element tri(i) + j of the packed Uc)
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+#pragma unroll
+        for (int rr = 0; rr < NM; rr++) Ds[r][rr] = T(0);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T v = T(0);
+            if (i >= L * r) v = lq[(i * (i + 1) / 2 + L * r) * FPW];
+            Ds[r][NM + i] = (i >= q + L * r) ? v : T(0);
+        }
+    }
+    wave_lds_fence();
+    T hxm[NM];   // H x-, every row, in every lane
+#pragma unroll
+    for (int c = 0; c < NM; c++) hxm[c] = lf[(BOFF + NS + c) * FPW];
+#pragma unroll
+    for (int c = 0; c < NM; c++) pin(hxm[c]);
+    wave_lds_fence();
+    KB_SB();
+
+    // ---- Householder on Delta ((n + p) x (n + p); ActD: below the diagonal the first p columns are zero in their first p rows) -------
+    // (a) the measurement columns k < p: active rows below the diagonal are the n bottom rows; every state column is updated
+#pragma unroll
+    for (int k = 0; k < NM; k++) {
+        const int rk = k / L, qk = k % L;
+        {
+            T xn2 = T(0);
+#pragma unroll
+            for (int i = NM; i < DD; i++) xn2 += Dm[rk][i] * Dm[rk][i];
+            T u0, fr;
+            const T dg = reflector<T>(Dm[rk][k], xn2, true, u0, fr);
+            if (q == qk) {
+                lf[(BOFF + 0) * FPW] = u0;
+                lf[(BOFF + 1) * FPW] = fr;
+#pragma unroll
+                for (int i = NM; i < DD; i++) lf[(BOFF + 2 + i) * FPW] = Dm[rk][i];
+                Dm[rk][k] = dg;
+            }
+        }
+        wave_lds_fence();
+        {
+            const T u0 = lf[(BOFF + 0) * FPW], fr = lf[(BOFF + 1) * FPW];
+            T u[DD];
+#pragma unroll
+            for (int i = NM; i < DD; i++) u[i] = lf[(BOFF + 2 + i) * FPW];
+#pragma unroll
+            for (int r2 = rk; r2 < PC; r2++) {
+                const bool upd = r2 > rk || q > qk;
+                T s = u0 * Dm[r2][k];
+#pragma unroll
+                for (int i = NM; i < DD; i++) s += u[i] * Dm[r2][i];
+                const T fs = upd ? fr * s : T(0);
+                Dm[r2][k] += fs * u0;
+#pragma unroll
+                for (int i = NM; i < DD; i++) { Dm[r2][i] += fs * u[i]; pin(Dm[r2][i]); }
+                pin(Dm[r2][k]);
+            }
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                T s = u0 * Ds[r][k];
+#pragma unroll
+                for (int i = NM; i < DD; i++) s += u[i] * Ds[r][i];
+                const T fs = fr * s;
+                Ds[r][k] += fs * u0;
+#pragma unroll
+                for (int i = NM; i < DD; i++) { Ds[r][i] += fs * u[i]; pin(Ds[r][i]); }
+                pin(Ds[r][k]);
+            }
+        }
+        wave_lds_fence();
+        KB_SB();
+    }
+    // (b) the state columns k = p + kk: all rows below the diagonal are active; the last column makes no reflection (Dgeqr2: M - i > 1)
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) {
+        const int k = NM + kk, rk = kk / L, qk = kk % L;
+        {
+            T xn2 = T(0);
+#pragma unroll
+            for (int i = k + 1; i < DD; i++) xn2 += Ds[rk][i] * Ds[rk][i];
+            T u0, fr;
+            const T dg = reflector<T>(Ds[rk][k], xn2, k + 1 < DD, u0, fr);
+            if (q == qk) {
+                lf[(BOFF + 0) * FPW] = u0;
+                lf[(BOFF + 1) * FPW] = fr;
+#pragma unroll
+                for (int i = k + 1; i < DD; i++) lf[(BOFF + 2 + i) * FPW] = Ds[rk][i];
+                Ds[rk][k] = dg;
+            }
+        }
+        wave_lds_fence();
+        {
+            const T u0 = lf[(BOFF + 0) * FPW], fr = lf[(BOFF + 1) * FPW];
+            T u[DD];
+#pragma unroll
+            for (int i = k + 1; i < DD; i++) u[i] = lf[(BOFF + 2 + i) * FPW];
+#pragma unroll
+            for (int r = rk; r < RP; r++) {
+                const bool upd = r > rk || q > qk;
+                T s = u0 * Ds[r][k];
+#pragma unroll
+                for (int i = k + 1; i < DD; i++) s += u[i] * Ds[r][i];
+                const T fs = upd ? fr * s : T(0);
+                Ds[r][k] += fs * u0;
+#pragma unroll
+                for (int i = k + 1; i < DD; i++) { Ds[r][i] += fs * u[i]; pin(Ds[r][i]); }
+                pin(Ds[r][k]);
+            }
+        }
+        wave_lds_fence();
+        KB_SB();
+    }
+
+    // ---- Syy = UD[:p,:p]^T gathered through LDS (the Uc region is free now), K = W Syy^-1 (squareroot.go:225-252; the inverse's
+    // error is never looked at).  W^T is the top part of the own state columns: W[j_r][k2] = UD[k2][p + j_r] = Ds[r][k2]
+#pragma unroll
+    for (int r2 = 0; r2 < PC; r2++)
+#pragma unroll
+        for (int j = 0; j < NM; j++)
+            if (mcol[r2] && j < L * r2 + L) lf[(NM * (L * r2) + j) * FPW + NM * q * FPW] = Dm[r2][j];   // slot NM c + j, c = q + L r2
+    wave_lds_fence();
+    T K[RP][NM];
+    {
+        T Syy[NM * NM], SyyI[NM * NM];
+#pragma unroll
+        for (int i = 0; i < NM; i++)
+#pragma unroll
+            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lf[(NM * i + j) * FPW] : T(0);   // Syy[i][j] = UD[j][i]
+        inverse_lu<T, NM>(Syy, SyyI, rp);
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int k2 = 0; k2 < NM; k2++) s += Ds[r][k2] * SyyI[k2 * NM + c];
+                K[r][c] = s;
+            }
+    }
+    // ---- squareroot.go:255-268 x+ = x- + K (y - H x-) [+ Process(k)] -----------------------------------------------------------------
+    T innov[NM], xn[RP];
+    {
+        const T *yp = (const T *)a.y + tile * a.y_ts;
+#pragma unroll
+        for (int c = 0; c < NM; c++) innov[c] = ((active && c < rp) ? ldnt_at(&(yp + (int64_t)c * a.y_es)[us]) : T(0)) - hxm[c];
+    }
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+        T s = T(0);
+#pragma unroll
+        for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
+        xn[r] = xm[r] + s;
+    }
+    [[maybe_unused]] T vown[PC];
+#pragma unroll
+    for (int r2 = 0; r2 < PC; r2++) vown[r2] = T(0);
+    if constexpr (GEN) {
+        if (awgn) {   // noise.go:109-164: Process(k) into x+ (which = 2), Measurement(k) into yhat (which = 1, FULL only); the factors are read again
+            const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + (unsigned)slot;
+            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + slot] : 0u);   // kf.step of this filter
+            {
+                T z[NS];
+                draw_normals<T, NS>(a, gfi, stepno, 2u, z);
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    T sacc = T(0);
+#pragma unroll
+                    for (int i = 0; i < L * r + L; i++) {
+                        const bool in = colok[r] && i <= q + L * r;
+                        const T l = (colany[r] && i < rn) ? ldg(mo, a.L.mo_LQ, i, in ? um + utri[r] : um) : T(0);
+                        sacc += (in ? l : T(0)) * z[i];
+                    }
+                    xn[r] += sacc;
+                }
+            }
+            if (full) {
+                T z1[NM];
+                draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+#pragma unroll
+                for (int r2 = 0; r2 < PC; r2++) {
+                    const int cbase = L * r2;
+                    const bool real = mcol[r2] && q + cbase < rp;
+                    const unsigned utr = real ? um + (unsigned)(((q + cbase) * (q + cbase + 1) / 2) * KB_TILE) : um;
+                    T sacc = T(0);
+#pragma unroll
+                    for (int i = 0; i < NM; i++) {
+                        const bool in = real && i <= q + cbase;
+                        const T l = (cbase < rp && i < cbase + L && i < rp) ? ldg(mo, a.L.mo_LR, i, utr) : T(0);
+                        sacc += (in ? l : T(0)) * z1[i];
+                    }
+                    vown[r2] = sacc;
+                }
+            }
+        }
+    }
+    // ---- non-finite screen over the own entries of x+ and S+ (S+[i][j] = UD[p + j][p + i]: the own column's bottom part), all lanes
+    unsigned err;
+    {
+        T chk = T(0);
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            chk += xn[r] * T(0);
+#pragma unroll
+            for (int j = 0; j < L * r + L; j++) chk += ((j <= q + L * r) ? Ds[r][NM + j] : T(0)) * T(0);
+        }
+        err = sum_lanes<L>((chk != chk) ? (unsigned)KB_ST_NONFINITE : 0u);
+    }
+    const bool ok = err == 0;
+    T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
+    if (active && ok) {
+        auto store_state = [&](auto NT) {
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                if (colok[r]) {
+                    const gptr pe = ep(st, 0, L * r) + uq;
+                    if constexpr (decltype(NT)::value) __builtin_nontemporal_store(xn[r], pe); else *pe = xn[r];
+                }
+#pragma unroll
+                for (int j = 0; j < L * r + L; j++)
+                    if (colok[r] && j <= q + L * r) {   // row i = j_r of S+ is packed contiguously at tri(i)
+                        const gptr pe = ep(st, rn, j) + (us + utri[r]);
+                        if constexpr (decltype(NT)::value) __builtin_nontemporal_store(Ds[r][NM + j], pe); else *pe = Ds[r][NM + j];
+                    }
+            }
+        };
+        KB_WITH_STATE_POLICY(a, store_state);
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NM; c++)
+                    if (colok[r] && c < rp) __builtin_nontemporal_store(K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < NM; c++)
+                    if (c < rp) __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
+            }
+        }
+    }
+    if (full && active) {   // yhat leaves whether or not the step is applied (as in kb_squareroot_reg.hip): the owner of row c stores it
+#pragma unroll
+        for (int r2 = 0; r2 < PC; r2++)
+            if (mcol[r2] && q + L * r2 < rp) __builtin_nontemporal_store(hxp[r2] + vown[r2], ep(es, a.L.es_yhat, L * r2) + uq);
+    }
+    const unsigned lane_end = late_lane();
+    if (active && !ok && ((lane_end / FPW) & (L - 1)) == 0)
+        atomicOr(a.status + tile * KB_TILE + (int64_t)((gw % L) * FPW + (lane_end & (FPW - 1))), (unsigned)KB_ST_NONFINITE);
+    (void)TM;
+}
+
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT>
+__global__ void __launch_bounds__(64, GEN ? 1 : 2) squareroot_split_kernel(const StepArgs a) {
+    __shared__ T lds[sqsplit_lds_elems<NS, NM>() * (64 / L)];
+    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT>(a, blockIdx.x, lds);
+}
+#undef KB_SB
+
+}  // namespace kb
