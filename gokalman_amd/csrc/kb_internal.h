@@ -177,6 +177,7 @@ int launch_srif_gen(const Batch &b, const StepArgs &a);
 int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)
 bool launch_squareroot_split12(const Batch &b, const StepArgs &a);      // kb_squareroot_split12.hip: 6 < n <= 12, one filter over four lanes
+bool launch_squareroot_split16(const Batch &b, const StepArgs &a);      // kb_squareroot_split16.hip: 12 < n <= 16, eight lanes
 int launch_srif(const Batch &b, const StepArgs &a);
 int launch_hybrid(const Batch &b, const StepArgs &a);
 int launch_batch_ls(const Batch &b, const StepArgs &a);

@@ -329,7 +329,7 @@ int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
     if (!done && b.dtype == KB_F64)   // AWGN batches: the benchmark shape exactly, everything else up to 6 / 4 / 2 padded
         done = sqrt_try<double, 6, 3, 0, true>(b, a) || sqrt_try_pad<double, 4, 2, 0, true>(b, a) || sqrt_try_pad<double, 4, 2, 2, true>(b, a) ||
                sqrt_try_pad<double, 6, 4, 0, true>(b, a) || sqrt_try_pad<double, 6, 4, 2, true>(b, a);
-    if (!done) done = launch_squareroot_split12(b, a);   // 6 < n <= 12 (p <= 8, m <= 2): one filter over four lanes, kb_squareroot_split.h
+    if (!done) done = launch_squareroot_split12(b, a) || launch_squareroot_split16(b, a);   // 6 < n <= 16 (p <= 8, m <= 2): one filter over four / eight lanes, kb_squareroot_split.h
     if (!done) return launch_squareroot_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -26,7 +26,7 @@ namespace kb {
 #define KB_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int NS, int NM>
-constexpr int sqsplit_lds_elems() { return tri(NS) + 2 * NS + 2; }   // S / Uc packed | the reflector of one column step (u0, f, then <= 2 n rows; n + p <= 2 n)
+constexpr int sqsplit_lds_elems() { return tri(NS) + 2 * NS + 2 + NS + NM; }   // S / Uc packed | the reflector of one column step (u0, f, then <= 2 n rows; n + p <= 2 n)
 
 // Dlarfg for one column (kb_static.h sqr_r): given alpha = a[k][k] and the squared norm of the active entries below it, the
 // unnormalised reflector H = I + f u u^T, u = (u0, x); returns the new diagonal entry
@@ -43,7 +43,8 @@ template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT>
 __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "columns are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, PC = (NM + L - 1) / L, TR = tri(NS), TM = tri(NM), DD = NS + NM;
-    constexpr int BOFF = TR;   // LDS: [0, TR) S, later Uc, later the gathers; [TR, TR + DD + 2) the reflector of the current step
+    constexpr int BOFF = TR;   // LDS: [0, TR) S, later Uc, later Syy; [TR, TR + 2 NS + 2) the reflector of the current step;
+    constexpr int XOFF = TR + 2 * NS + 2;   // then x- (n) and H x- (p), gathered once and parked until the end of the step
     typedef __attribute__((address_space(1))) T *gptr;
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
@@ -140,21 +141,24 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     }
     {
         T row[2][NS];
-        auto fetch = [&](int l, int b) {
+        auto fetch = [&](int l, int b) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i <= l; i++) row[b][i] = lf[(l * (l + 1) / 2 + i) * FPW];
+            for (int i = 0; i < NS; i++)
+                if (i <= l) row[b][i] = lf[(l * (l + 1) / 2 + i) * FPW];
         };
         fetch(0, 0);
-#pragma unroll
-        for (int l = 0; l < NS; l++) {
-            if (l + 1 < NS) fetch(l + 1, (l + 1) & 1);
+        // (sfor, kb_device.h: the bounds of the triangular inner loops are compile-time constants from the start; as `#pragma unroll`
+        // loops inside a loop they are unrolled at run time with remainder loops BEFORE the outer loop is, and the panels land in scratch)
+        sfor<0, NS>([&](auto LL) __attribute__((always_inline)) {
+            constexpr int l = LL;
+            if constexpr (l + 1 < NS) fetch(l + 1, (l + 1) & 1);
             KB_SB();
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int i = 0; i <= l; i++) { Ct[r][i] += row[l & 1][i] * Fo[r][l]; pin(Ct[r][i]); }
             KB_SB();
-        }
+        });
     }
     // the bottom block: column j of sqrtQ^T = row j of chol(Q) (the lane's own rows, packed contiguously), zero below the diagonal
 #pragma unroll
@@ -169,10 +173,8 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 
     // ---- Householder on C (2n x n; Dgeqr2): column k's owner forms the reflector, everybody applies it to the own columns c > k --------
     wave_lds_fence();   // (the S reads are done; the reflector buffer is a different region, but the compiler does not know the lanes)
-#pragma unroll
-    for (int k = 0; k < NS; k++) {
-        constexpr int dummy = 0; (void)dummy;
-        const int rk = k / L, qk = k % L;   // compile-time after unrolling
+    sfor<0, NS>([&](auto KK) __attribute__((always_inline)) {
+        constexpr int k = KK, rk = k / L, qk = k % L;
         {   // the owner's part, computed by every lane on its local column rk; only lane group qk publishes it
             T xn2 = T(0);
 #pragma unroll
@@ -221,7 +223,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         }
         wave_lds_fence();
         KB_SB();
-    }
+    });
     // Uc[i][j] = Ct[r][i], i <= j = j_r: S- := Uc (QUIRK squareroot.go:185).  It goes to LDS packed by columns (tri(j) + i): the own
     // columns are contiguous.  FULL: the Estimate's predicted factor leaves at once (as in kb_squareroot_reg.hip).
 #pragma unroll
@@ -279,14 +281,15 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         }
         // bottom rows, one column of Uc per chunk (column i of Uc is packed contiguously: Uc[l][i] at tri(i) + l)
         T col[2][NS];
-        auto fetch = [&](int i, int b) {
+        auto fetch = [&](int i, int b) __attribute__((always_inline)) {
 #pragma unroll
-            for (int l = 0; l <= i; l++) col[b][l] = lf[(i * (i + 1) / 2 + l) * FPW];
+            for (int l = 0; l < NS; l++)
+                if (l <= i) col[b][l] = lf[(i * (i + 1) / 2 + l) * FPW];
         };
         fetch(0, 0);
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            if (i + 1 < NS) fetch(i + 1, (i + 1) & 1);
+        sfor<0, NS>([&](auto II) __attribute__((always_inline)) {
+            constexpr int i = II;
+            if constexpr (i + 1 < NS) fetch(i + 1, (i + 1) & 1);
             KB_SB();
 #pragma unroll
             for (int r2 = 0; r2 < PC; r2++) {
@@ -297,25 +300,25 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
                 pin(Dm[r2][NM + i]);
             }
             KB_SB();
-        }
+        });
         // H x- for the innovation (squareroot.go:255-262): x- is gathered through LDS (its rows are spread over the lanes), the own
         // measurement rows are formed here, and gathered below
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = xm[r];
+        for (int r = 0; r < RP; r++) lq[(XOFF + L * r) * FPW] = xm[r];
         wave_lds_fence();
         T hx[PC];
 #pragma unroll
         for (int r2 = 0; r2 < PC; r2++) {
             T s = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += Hrow[r2][l] * lf[(BOFF + l) * FPW];
+            for (int l = 0; l < NS; l++) s += Hrow[r2][l] * lf[(XOFF + l) * FPW];
             hx[r2] = s;
         }
         wave_lds_fence();
 #pragma unroll
         for (int r2 = 0; r2 < PC; r2++)
-            if (mcol[r2]) lq[(BOFF + NS + L * r2) * FPW] = hx[r2];
+            if (mcol[r2]) lq[(XOFF + NS + L * r2) * FPW] = hx[r2];
     }
     // state columns p + j, j = j_r: top zero, bottom S-^T[i][j] = Uc[j][i] for i >= j (element tri(i) + j of the packed Uc)
 #pragma unroll
@@ -330,19 +333,12 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         }
     }
     wave_lds_fence();
-    T hxm[NM];   // H x-, every row, in every lane
-#pragma unroll
-    for (int c = 0; c < NM; c++) hxm[c] = lf[(BOFF + NS + c) * FPW];
-#pragma unroll
-    for (int c = 0; c < NM; c++) pin(hxm[c]);
-    wave_lds_fence();
     KB_SB();
 
     // ---- Householder on Delta ((n + p) x (n + p); ActD: below the diagonal the first p columns are zero in their first p rows) -------
     // (a) the measurement columns k < p: active rows below the diagonal are the n bottom rows; every state column is updated
-#pragma unroll
-    for (int k = 0; k < NM; k++) {
-        const int rk = k / L, qk = k % L;
+    sfor<0, NM>([&](auto KK) __attribute__((always_inline)) {
+        constexpr int k = KK, rk = k / L, qk = k % L;
         {
             T xn2 = T(0);
 #pragma unroll
@@ -389,11 +385,62 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         }
         wave_lds_fence();
         KB_SB();
-    }
-    // (b) the state columns k = p + kk: all rows below the diagonal are active; the last column makes no reflection (Dgeqr2: M - i > 1)
+    });
+    // the measurement columns are final: their top parts (Syy^T) go to LDS now (the Uc region is free), and their registers are free for (b)
 #pragma unroll
-    for (int kk = 0; kk < NS; kk++) {
-        const int k = NM + kk, rk = kk / L, qk = kk % L;
+    for (int r2 = 0; r2 < PC; r2++)
+#pragma unroll
+        for (int j = 0; j < NM; j++)
+            if (mcol[r2] && j < L * r2 + L) lf[(NM * (L * r2) + j) * FPW + NM * q * FPW] = Dm[r2][j];   // slot NM c + j, c = q + L r2
+    // ---- Syy = UD[:p,:p]^T gathered through LDS, K = W Syy^-1 (squareroot.go:225-252; the inverse's error is never looked at).  W^T is
+    // the top part of the own state columns: W[j_r][k2] = UD[k2][p + j_r] = Ds[r][k2].  Both are FINAL once the measurement columns are
+    // done, so the gain and x+ are formed here, before the state columns are factorised: W would otherwise wait in registers through (b)
+    wave_lds_fence();
+    T K[RP][NM];
+    {
+        T Syy[NM * NM], SyyI[NM * NM];
+#pragma unroll
+        for (int i = 0; i < NM; i++)
+#pragma unroll
+            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lf[(NM * i + j) * FPW] : T(0);   // Syy[i][j] = UD[j][i]
+        inverse_lu<T, NM>(Syy, SyyI, rp);
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) {
+                T s = T(0);
+#pragma unroll
+                for (int k2 = 0; k2 < NM; k2++) s += Ds[r][k2] * SyyI[k2 * NM + c];
+                K[r][c] = s;
+            }
+    }
+    // ---- squareroot.go:255-268 x+ = x- + K (y - H x-) [+ Process(k)] -----------------------------------------------------------------
+    T innov[NM], xn[RP];
+    {
+        const T *yp = (const T *)a.y + tile * a.y_ts;
+#pragma unroll
+        for (int c = 0; c < NM; c++) innov[c] = ((active && c < rp) ? ldnt_at(&(yp + (int64_t)c * a.y_es)[us]) : T(0)) - lf[(XOFF + NS + c) * FPW];
+    }
+#pragma unroll
+    for (int r = 0; r < RP; r++) {
+        T s = T(0);
+#pragma unroll
+        for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
+        xn[r] = lq[(XOFF + L * r) * FPW] + s;   // x-[j_r], parked in LDS until here
+        pin(xn[r]);
+    }
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int c = 0; c < NM; c++) pin(K[r][c]);
+#pragma unroll
+        for (int c = 0; c < NM; c++) pin(innov[c]);
+    }
+    KB_SB();
+    // (b) the state columns k = p + kk: all rows below the diagonal are active; the last column makes no reflection (Dgeqr2: M - i > 1)
+    sfor<0, NS>([&](auto KK) __attribute__((always_inline)) {
+        constexpr int kk = KK, k = NM + kk, rk = kk / L, qk = kk % L;
         {
             T xn2 = T(0);
 #pragma unroll
@@ -429,48 +476,8 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         }
         wave_lds_fence();
         KB_SB();
-    }
+    });
 
-    // ---- Syy = UD[:p,:p]^T gathered through LDS (the Uc region is free now), K = W Syy^-1 (squareroot.go:225-252; the inverse's
-    // error is never looked at).  W^T is the top part of the own state columns: W[j_r][k2] = UD[k2][p + j_r] = Ds[r][k2]
-#pragma unroll
-    for (int r2 = 0; r2 < PC; r2++)
-#pragma unroll
-        for (int j = 0; j < NM; j++)
-            if (mcol[r2] && j < L * r2 + L) lf[(NM * (L * r2) + j) * FPW + NM * q * FPW] = Dm[r2][j];   // slot NM c + j, c = q + L r2
-    wave_lds_fence();
-    T K[RP][NM];
-    {
-        T Syy[NM * NM], SyyI[NM * NM];
-#pragma unroll
-        for (int i = 0; i < NM; i++)
-#pragma unroll
-            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lf[(NM * i + j) * FPW] : T(0);   // Syy[i][j] = UD[j][i]
-        inverse_lu<T, NM>(Syy, SyyI, rp);
-#pragma unroll
-        for (int r = 0; r < RP; r++)
-#pragma unroll
-            for (int c = 0; c < NM; c++) {
-                T s = T(0);
-#pragma unroll
-                for (int k2 = 0; k2 < NM; k2++) s += Ds[r][k2] * SyyI[k2 * NM + c];
-                K[r][c] = s;
-            }
-    }
-    // ---- squareroot.go:255-268 x+ = x- + K (y - H x-) [+ Process(k)] -----------------------------------------------------------------
-    T innov[NM], xn[RP];
-    {
-        const T *yp = (const T *)a.y + tile * a.y_ts;
-#pragma unroll
-        for (int c = 0; c < NM; c++) innov[c] = ((active && c < rp) ? ldnt_at(&(yp + (int64_t)c * a.y_es)[us]) : T(0)) - hxm[c];
-    }
-#pragma unroll
-    for (int r = 0; r < RP; r++) {
-        T s = T(0);
-#pragma unroll
-        for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
-        xn[r] = xm[r] + s;
-    }
     [[maybe_unused]] T vown[PC];
 #pragma unroll
     for (int r2 = 0; r2 < PC; r2++) vown[r2] = T(0);

@@ -1,6 +1,6 @@
 """SquareRoot.Update (squareroot.go:129-274) beyond 6 states: the kernel that splits ONE filter over four lanes with the Householder
 panels distributed by columns (gokalman_amd/csrc/kb_squareroot_split.h) against the CPU oracle, through the C ABI: 12 / 6 at 4096
-filters x 20 steps (<= 1e-9 relative Frobenius on x and on the covariance S S^T), the padded family 7..12 states with / without
+filters x 20 steps (<= 1e-9 relative Frobenius on x and on the covariance S S^T), the padded family 7..16 states (eight lanes per filter beyond 12) with / without
 KB_FLAG_FULL_ESTIMATE, control input, AWGN replayed through the oracle, and equality with the statement kernel to 1e-12."""
 import numpy as np
 import pytest
@@ -36,7 +36,8 @@ def test_sqsplit_12x6_at_4096_filters_20_steps_vs_oracle():
     assert synth.rel_frobenius(b.get(k.STATE, 0, 256), s.get(k.STATE)) <= 1e-11
 
 
-@pytest.mark.parametrize("n,p,m", [(7, 2, 0), (8, 4, 1), (9, 5, 2), (10, 1, 0), (11, 7, 0), (12, 6, 0), (12, 8, 2), (12, 3, 1)])
+@pytest.mark.parametrize("n,p,m", [(7, 2, 0), (8, 4, 1), (9, 5, 2), (10, 1, 0), (11, 7, 0), (12, 6, 0), (12, 8, 2), (12, 3, 1),
+                                   (13, 2, 0), (14, 8, 1), (15, 7, 2), (16, 8, 2), (16, 6, 0)])
 @pytest.mark.parametrize("full", [False, True])
 def test_sqsplit_padded_family_vs_oracle(n, p, m, full):
     N, steps = 150, 6
@@ -57,7 +58,7 @@ def test_sqsplit_padded_family_vs_oracle(n, p, m, full):
         assert np.max(np.abs(est.measurement() - np.array([f.measurement() for f in fs]))) <= 1e-8
 
 
-@pytest.mark.parametrize("n,p,m,full", [(12, 6, 0, False), (12, 6, 0, True), (9, 3, 1, True), (11, 8, 2, False)])
+@pytest.mark.parametrize("n,p,m,full", [(12, 6, 0, False), (12, 6, 0, True), (9, 3, 1, True), (11, 8, 2, False), (16, 8, 2, True), (14, 5, 0, False)])
 def test_sqsplit_awgn_replayed_through_the_oracle(n, p, m, full):
     """AWGN: Measurement(k) into yhat (squareroot.go:239), Process(k) into x+ (:268); the device's draws replayed through the oracle."""
     N, steps = 150, 5
