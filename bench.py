@@ -166,8 +166,8 @@ def _leg_parity(ga, k, synth, leg):
     from oracle import oracle as orc
     N, T = 4096, 20
     out = {"filters": N, "steps": T, "against": "oracle/gokalman_oracle.c"}
-    if leg in ("squareroot", "shared_model", "vanilla_12x6"):
-        nn, pp = (12, 6) if leg == "vanilla_12x6" else (N_STATE, N_MEAS)
+    if leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6"):
+        nn, pp = (12, 6) if leg in ("vanilla_12x6", "squareroot_12x6") else (N_STATE, N_MEAS)
         d = synth.linear_batch(N, nn, pp, T, seed=synth.SEED + 77)
         if leg == "shared_model":
             for f in ("F", "H", "Q", "R"):
@@ -649,6 +649,18 @@ def main():
                                                              *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 12, 6, 0, 4, false, false, false")),
                                  "filters_with_error_status": vbad}
         del vb, yq
+        # ... and SquareRoot at the same size (kb_squareroot_split.h: the Householder panels distributed by columns over four lanes)
+        dq = synth.linear_batch(M, 12, 6, 1, seed=synth.SEED + 4000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)
+        qb = ga.FilterBatch.new_ldkf(k.SQUAREROOT, dq["x0"], dq["P0"], dq["F"], None, dq["H"], dq["Q"], dq["R"], device=local_rank)
+        q_s, qms2, qbad2 = timed_leg(qb, lambda: qb.update_dev(yq.data_ptr(), M), K6)
+        extra["squareroot_12x6"] = {"config": "%d SquareRoot 12/6 fp64 filters per GPU, per-filter models (kb_squareroot_split.h: one filter per four lanes)" % M,
+                                    "filters_total": world * M, "steps": K6, "value": world * M * K6 / q_s,
+                                    "unit": "filter-update steps/s (whole job)", "kernel_ms": qms2,
+                                    "roofline": rl.hbm_roofline(qms2, M, rl.algorithmic_bytes("squareroot", 12, 6), rl.moved_bytes("squareroot", 12, 6),
+                                                                *rl.load_traffic(ROOT, "squareroot_split_kernel<double, 12, 6, 0, 4, false, false")),
+                                    "filters_with_error_status": qbad2}
+        del qb, yq
     if args.srif_filters > 0:
         M = args.srif_filters
         sn, sp = 12, 6
@@ -734,7 +746,7 @@ def main():
                                 "note": "%d MB of host measurements per call: H2D copy + pack + step + synchronise" % (N * p * 8 // 1000000)}
         if not args.no_parity:
             out["parity"] = _parity(ga, k, synth)
-            for leg in ("squareroot", "shared_model", "vanilla_12x6", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
+            for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
                 if leg in extra:
                     extra[leg]["parity"] = _leg_parity(ga, k, synth, leg)
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
