@@ -387,6 +387,7 @@ int launch_information(const Batch &b, const StepArgs &a) {
     if (!done && b.dtype == KB_F64)   // shapes without an exact instantiation: padded register kernels up to 6 / 4 / 2
         done = info_try_pad<double, 4, 2, 0>(b, a) || info_try_pad<double, 4, 2, 2>(b, a) || info_try_pad<double, 6, 4, 0>(b, a) ||
                info_try_pad<double, 6, 4, 2>(b, a);
+    if (!done) done = launch_information_split(b, a);   // 6 < n <= 16 (p <= 8, m <= 2), state-only outputs: kb_information_split.h
     if (!done) return launch_information_gen(b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;

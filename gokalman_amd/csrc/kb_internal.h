@@ -173,6 +173,7 @@ int launch_refresh(Batch &b, int field, int *not_pd);
 int launch_squareroot_gen(const Batch &b, const StepArgs &a);
 int launch_information(const Batch &b, const StepArgs &a);   // kb_information_reg.hip (falls back to _gen)
 int launch_information_gen(const Batch &b, const StepArgs &a);
+bool launch_information_split(const Batch &b, const StepArgs &a);       // kb_information_split12.hip: 6 < n <= 16, one filter over four / eight lanes
 int launch_srif_gen(const Batch &b, const StepArgs &a);
 int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)
