@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vsplit", "sqsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hstrict", "mc"]
+which = args or ["vsplit", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -120,6 +120,23 @@ if "sqsplit" in which:
         ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N), K=3, warm=1)
         report("SquareRoot 12/6 f64, statement kernel (KB_FLAG_STATEMENT_KERNELS)", N, ms, rl.algorithmic_bytes("squareroot", 12, 6), {"errors": int(np.count_nonzero(b.status()))},
                moved=rl.moved_bytes("squareroot", 12, 6))
+        del b
+
+if "infsplit" in which:
+    # Information beyond 6 states: 12 / 6 (kb_information_split.h: the pivoted LU solve distributed over four lanes)
+    N = Nopt or (1 << 18)
+    d = synth.linear_batch(N, 12, 6, 1)
+    y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    b = ga.FilterBatch.new_ldkf(k.INFORMATION, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_INFO_FROM_STATE)
+    ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+    report("Information 12/6 f64, one filter per four lanes", N, ms, rl.algorithmic_bytes("information", 12, 6), {"errors": int(np.count_nonzero(b.status()))},
+           moved=rl.moved_bytes("information", 12, 6))
+    del b
+    if "--with-statement" in sys.argv:
+        b = ga.FilterBatch.new_ldkf(k.INFORMATION, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_INFO_FROM_STATE | k.FLAG_STATEMENT_KERNELS)
+        ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N), K=3, warm=1)
+        report("Information 12/6 f64, statement kernel (KB_FLAG_STATEMENT_KERNELS)", N, ms, rl.algorithmic_bytes("information", 12, 6), {"errors": int(np.count_nonzero(b.status()))},
+               moved=rl.moved_bytes("information", 12, 6))
         del b
 
 if "vstrict" in which:
