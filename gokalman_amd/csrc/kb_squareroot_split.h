@@ -35,7 +35,11 @@ __device__ __forceinline__ T reflector(T alpha, T xnorm2, bool more_rows, T &u0,
     const bool refl = more_rows && (xnorm2 != T(0));
     const T beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
     u0 = alpha - beta;
+#ifdef KB_SQSPLIT_IEEE_DIV
     f = refl ? T(1) / (beta * u0) : T(0);
+#else
+    f = refl ? recip(beta * u0) : T(0);   // kb_device.h: within an ulp of the quotient, a third of its instructions (one per Householder step)
+#endif
     return refl ? beta : alpha;
 }
 
