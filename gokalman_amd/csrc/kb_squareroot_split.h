@@ -26,7 +26,7 @@ namespace kb {
 #define KB_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int NS, int NM>
-constexpr int sqsplit_lds_elems() { return tri(NS) + 2 * NS + 2 + NS + NM; }   // S / Uc packed | the reflector of one column step (u0, f, then <= 2 n rows; n + p <= 2 n)
+constexpr int sqsplit_lds_elems() { return (tri(NS) > NS * NM ? tri(NS) : NS * NM) + 2 * NS + 2 + NS + NM + NM * NM; }   // S / Uc packed | the reflector of one column step (u0, f, then <= 2 n rows; n + p <= 2 n)
 
 // Dlarfg for one column (kb_static.h sqr_r): given alpha = a[k][k] and the squared norm of the active entries below it, the
 // unnormalised reflector H = I + f u u^T, u = (u0, x); returns the new diagonal entry
@@ -47,8 +47,9 @@ template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT>
 __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "columns are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, PC = (NM + L - 1) / L, TR = tri(NS), TM = tri(NM), DD = NS + NM;
-    constexpr int BOFF = TR;   // LDS: [0, TR) S, later Uc, later Syy; [TR, TR + 2 NS + 2) the reflector of the current step;
-    constexpr int XOFF = TR + 2 * NS + 2;   // then x- (n) and H x- (p), gathered once and parked until the end of the step
+    constexpr int BOFF = TR > NS * NM ? TR : NS * NM;   // LDS: [0, BOFF) S, later Uc, later W (n x p, parked as its rows become final);
+    constexpr int XOFF = BOFF + 2 * NS + 2;   // [BOFF, XOFF) the reflector of the current step; then x- (n) and H x- (p), parked until the end;
+    constexpr int SYOFF = XOFF + NS + NM;    // then Syy^T (p x p), written entry by entry as the measurement columns become final
     typedef __attribute__((address_space(1))) T *gptr;
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
@@ -384,39 +385,52 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
                 Ds[r][k] += fs * u0;
 #pragma unroll
                 for (int i = NM; i < DD; i++) { Ds[r][i] += fs * u[i]; pin(Ds[r][i]); }
-                pin(Ds[r][k]);
+                // row k of the state columns is final (W[j_r][k] = UD[k][p + j_r]): it waits in LDS for the gain, not in a register
+                lf[((L * r) * NM + k) * FPW + q * NM * FPW] = Ds[r][k];
             }
+            // ... and so is row k of the measurement columns c >= k (Syy[c][k] = UD[k][c]): slot NM c + k of the Syy region
+#pragma unroll
+            for (int r2 = rk; r2 < PC; r2++)
+                if (mcol[r2] && (r2 > rk || q >= qk)) lf[(SYOFF + NM * (L * r2) + k) * FPW + NM * q * FPW] = Dm[r2][k];
         }
         wave_lds_fence();
         KB_SB();
     });
-    // the measurement columns are final: their top parts (Syy^T) go to LDS now (the Uc region is free), and their registers are free for (b)
-#pragma unroll
-    for (int r2 = 0; r2 < PC; r2++)
-#pragma unroll
-        for (int j = 0; j < NM; j++)
-            if (mcol[r2] && j < L * r2 + L) lf[(NM * (L * r2) + j) * FPW + NM * q * FPW] = Dm[r2][j];   // slot NM c + j, c = q + L r2
     // ---- Syy = UD[:p,:p]^T gathered through LDS, K = W Syy^-1 (squareroot.go:225-252; the inverse's error is never looked at).  W^T is
     // the top part of the own state columns: W[j_r][k2] = UD[k2][p + j_r] = Ds[r][k2].  Both are FINAL once the measurement columns are
     // done, so the gain and x+ are formed here, before the state columns are factorised: W would otherwise wait in registers through (b)
     wave_lds_fence();
     T K[RP][NM];
     {
-        T Syy[NM * NM], SyyI[NM * NM];
+        // (the inverse column by column -- lu_factor_any / lu_inverse_column, kb_vanilla_split.h -- so that it never exists as a whole
+        // next to its factors: the bottom parts of the state columns, 36 values, are waiting in registers for phase (b))
+        T Syy[NM * NM];
 #pragma unroll
         for (int i = 0; i < NM; i++)
 #pragma unroll
-            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lf[(NM * i + j) * FPW] : T(0);   // Syy[i][j] = UD[j][i]
-        inverse_lu<T, NM>(Syy, SyyI, rp);
+            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lf[(SYOFF + NM * i + j) * FPW] : T(0);   // Syy[i][j] = UD[j][i]
+        unsigned swaps;
+        T anorm;
+        (void)lu_factor_any<T, NM>(Syy, swaps, anorm, rp);
+        T Wr[RP][NM];
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) {
+            for (int k2 = 0; k2 < NM; k2++) Wr[r][k2] = lf[((L * r) * NM + k2) * FPW + q * NM * FPW];   // W[j_r][k2], parked above
+        sfor<0, NM>([&](auto CC) __attribute__((always_inline)) {
+            constexpr int c = CC;
+            T v[NM];
+            lu_inverse_column<T, NM, c>(Syy, swaps, v);
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
                 T s = T(0);
 #pragma unroll
-                for (int k2 = 0; k2 < NM; k2++) s += Ds[r][k2] * SyyI[k2 * NM + c];
+                for (int k2 = 0; k2 < NM; k2++) s += Wr[r][k2] * v[k2];
                 K[r][c] = s;
+                pin(K[r][c]);
             }
+            KB_SB();
+        });
     }
     // ---- squareroot.go:255-268 x+ = x- + K (y - H x-) [+ Process(k)] -----------------------------------------------------------------
     T innov[NM], xn[RP];
@@ -433,13 +447,16 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         xn[r] = lq[(XOFF + L * r) * FPW] + s;   // x-[j_r], parked in LDS until here
         pin(xn[r]);
     }
-    if (full) {
+    if (full) {   // the Estimate's gain and innovation wait in LDS (W's and Syy's slots: both consumed) for the end of the step
+        wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) pin(K[r][c]);
+            for (int c = 0; c < NM; c++) lf[((L * r) * NM + c) * FPW + q * NM * FPW] = K[r][c];
+        if (q == 0) {
 #pragma unroll
-        for (int c = 0; c < NM; c++) pin(innov[c]);
+            for (int c = 0; c < NM; c++) lf[(SYOFF + c) * FPW] = innov[c];
+        }
     }
     KB_SB();
     // (b) the state columns k = p + kk: all rows below the diagonal are active; the last column makes no reflection (Dgeqr2: M - i > 1)
@@ -560,11 +577,11 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (colok[r] && c < rp) __builtin_nontemporal_store(K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
+                    if (colok[r] && c < rp) __builtin_nontemporal_store(lf[((L * r) * NM + c) * FPW + q * NM * FPW], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
             if (q == 0) {
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (c < rp) __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
+                    if (c < rp) __builtin_nontemporal_store(lf[(SYOFF + c) * FPW], ep(es, a.L.es_innov, c) + us);
             }
         }
     }
