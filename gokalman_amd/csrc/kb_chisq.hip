@@ -49,13 +49,15 @@ __global__ void __launch_bounds__(256, (NS <= 4 ? 2 : 1)) chisq_kernel(const Chi
     // truth model
     T xt[NS], Ft[NS * NS];
     // the truth model's H, chol(Q), chol(R) are read once per step: they wait in LDS ((NM NS + TR + TM) x 2 KB per workgroup)
-    constexpr int NPARK = NM * NS + TR + TM;
+    // with a control input the two G (read once per step as well) wait there too: registers are what this kernel is short of
+    constexpr int NPARK = NM * NS + TR + TM + 2 * NS * NC;
     __shared__ T park[NPARK * 256];
     T *pk = park + threadIdx.x;
 #define Ht(e) pk[(e) * 256]
 #define LQ(e) pk[(NM * NS + (e)) * 256]
 #define LR(e) pk[(NM * NS + TR + (e)) * 256]
-    [[maybe_unused]] T Gt[NC > 0 ? NS * NC : 1], Gk[NC > 0 ? NS * NC : 1];
+#define Gt(e) pk[(NM * NS + TR + TM + (e)) * 256]
+#define Gk(e) pk[(NM * NS + TR + TM + NS * NC + (e)) * 256]
 #pragma unroll
     for (int i = 0; i < NS; i++) xt[i] = ldt(ts, a.tL.st_vec + i);
 #pragma unroll
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256, (NS <= 4 ? 2 : 1)) chisq_kernel(const Chi
     for (int e = 0; e < TM; e++) R[e] = ldt(km, a.kL.mo_R + e);
     if constexpr (NC > 0) {
 #pragma unroll
-        for (int e = 0; e < NS * NC; e++) { Gt[e] = ldt(tm, a.tL.mo_G + e); Gk[e] = ldt(km, a.kL.mo_G + e); }
+        for (int e = 0; e < NS * NC; e++) { Gt(e) = ldt(tm, a.tL.mo_G + e); Gk(e) = ldt(km, a.kL.mo_G + e); }
     }
     const uint64_t gfi = (uint64_t)(a.first_run + fi);
     double *my = a.sums + (size_t)(tile % CHI_REPL) * a.nsteps * 2;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256, (NS <= 4 ? 2 : 1)) chisq_kernel(const Chi
             if constexpr (NC > 0) {
                 T g = T(0);
 #pragma unroll
-                for (int c = 0; c < NC; c++) g += Gt[i * NC + c] * u[c];
+                for (int c = 0; c < NC; c++) g += Gt(i * NC + c) * u[c];
                 s = s + g;
             }
 #pragma unroll
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(256, (NS <= 4 ? 2 : 1)) chisq_kernel(const Chi
             if constexpr (NC > 0) {
                 T g = T(0);
 #pragma unroll
-                for (int c = 0; c < NC; c++) g += Gk[i * NC + c] * u[c];
+                for (int c = 0; c < NC; c++) g += Gk(i * NC + c) * u[c];
                 s = s + g;
             }
             xm[i] = s;

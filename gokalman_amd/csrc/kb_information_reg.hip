@@ -284,7 +284,20 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
         // vector addresses are formed up there, carried through the 6 x 6 inverse and spilled (180 B of scratch, one wait per reload)
         const int64_t tile_u = (int64_t)blockIdx.x * INFO_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // the tile index as a scalar
         const T *const mo_u = SHARED ? (const T *)a.model : (const T *)a.model + tile_u * a.mo_ts;
+        if constexpr (STASH) {   // the previous i sits out the inverse where zk sat out the solve
+#pragma unroll
+            for (int i = 0; i < NS; i++) lds[so + i * 64] = iprev[i];
+            asm volatile("" ::: "memory");
+        }
         const bool bad = inverse_lu<T, NS>(Iprev, Pp, rn);
+#pragma unroll
+        for (int e = 0; e < NS * NS; e++) pin(Pp[e]);
+        if constexpr (STASH) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NS; i++) iprev[i] = lds[so + i * 64];
+        }   // (the lane index below is a volatile asm: only other asm statements hold it behind the inverse)
+        __builtin_amdgcn_sched_barrier(0);
         const unsigned mo_lane = (SHARED || a.mo_ts == 0) ? 0u : (late_lane() & 63u);   // (formed behind the inverse, not carried through it)
         auto late_mo = [&](int rt, int c) __attribute__((always_inline)) {
             const auto gp = anchored(mo_u, rt, c) + mo_lane;
@@ -311,8 +324,9 @@ __global__ void __launch_bounds__(64 * INFO_WPB, INFO_WAVES) information_reg_ker
 #pragma unroll
             for (int r = 0; r < NM; r++) pin(yhat[r]);
             __builtin_amdgcn_sched_barrier(0);
-            const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
-            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
+            const int64_t fi_u = tile_u * KB_TILE + (late_lane() & 63u);   // (the filter index formed again: carried from the top it is a spilled pair)
+            const uint64_t gfi = (uint64_t)(a.first_filter + fi_u);
+            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[fi_u] : 0u);   // kf.step of this filter
             T z1[NM], v[NM];
             draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
 #pragma unroll

@@ -9,6 +9,7 @@ bool launch_information_split(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || m > 2 || a.rinv_p != a.p || a.nsteps != 1) return false;
     if (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) return false;
     if (a.noise_kind == KB_NOISE_BATCH) return false;
+    if (launch_information_split8(b, a)) return true;
     if (a.n == 12 && a.p == 6 && m == 0)
         hipLaunchKernelGGL((information_split_kernel<double, 12, 6, 0, 4, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     else if (a.n <= 12)

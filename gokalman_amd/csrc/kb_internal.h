@@ -174,11 +174,14 @@ int launch_squareroot_gen(const Batch &b, const StepArgs &a);
 int launch_information(const Batch &b, const StepArgs &a);   // kb_information_reg.hip (falls back to _gen)
 int launch_information_gen(const Batch &b, const StepArgs &a);
 bool launch_information_split(const Batch &b, const StepArgs &a);       // kb_information_split12.hip: 6 < n <= 16, one filter over four / eight lanes
+bool launch_information_split8(const Batch &b, const StepArgs &a);      // kb_information_split8.hip: n <= 8, p <= 4 (called by launch_information_split)
 int launch_srif_gen(const Batch &b, const StepArgs &a);
 int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)
 bool launch_squareroot_split12(const Batch &b, const StepArgs &a);      // kb_squareroot_split12.hip: 6 < n <= 12, one filter over four lanes
 bool launch_squareroot_split16(const Batch &b, const StepArgs &a);      // kb_squareroot_split16.hip: 12 < n <= 16, eight lanes
+bool launch_squareroot_split12_plain(const Batch &b, const StepArgs &a);   // kb_squareroot_split12p.hip / 16p.hip: padded shapes, Noiseless, state only
+bool launch_squareroot_split16_plain(const Batch &b, const StepArgs &a);
 int launch_srif(const Batch &b, const StepArgs &a);
 int launch_hybrid(const Batch &b, const StepArgs &a);
 int launch_batch_ls(const Batch &b, const StepArgs &a);

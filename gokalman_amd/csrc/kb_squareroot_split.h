@@ -43,7 +43,9 @@ __device__ __forceinline__ T reflector(T alpha, T xnorm2, bool more_rows, T &u0,
     return refl ? beta : alpha;
 }
 
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT>
+// GEN: run-time dimensions n <= NS, p <= NM, m <= NC (zero padding); RT (GEN only): FULL and the Noise come from the launch arguments
+// as well -- one instantiation per NS for everything, at one wave per SIMD; RT = false: Noiseless, FULL as given (kb_vanilla_split.h)
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN>
 __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "columns are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, PC = (NM + L - 1) / L, TR = tri(NS), TM = tri(NM), DD = NS + NM;
@@ -52,8 +54,8 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     constexpr int SYOFF = XOFF + NS + NM;    // then Syy^T (p x p), written entry by entry as the measurement columns become final
     typedef __attribute__((address_space(1))) T *gptr;
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
-    const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
-    const bool awgn = GEN && a.noise_kind == KB_NOISE_AWGN;
+    const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
+    const bool awgn = RT && a.noise_kind == KB_NOISE_AWGN;
     const unsigned lane = threadIdx.x;
     const int q = (int)((lane / FPW) & (L - 1)), f = (int)(lane & (FPW - 1));
     const int64_t tile = gw / L;
@@ -502,7 +504,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     [[maybe_unused]] T vown[PC];
 #pragma unroll
     for (int r2 = 0; r2 < PC; r2++) vown[r2] = T(0);
-    if constexpr (GEN) {
+    if constexpr (RT) {
         if (awgn) {   // noise.go:109-164: Process(k) into x+ (which = 2), Measurement(k) into yhat (which = 1, FULL only); the factors are read again
             const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + (unsigned)slot;
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + slot] : 0u);   // kf.step of this filter
@@ -596,10 +598,10 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     (void)TM;
 }
 
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT>
-__global__ void __launch_bounds__(64, GEN ? 1 : 2) squareroot_split_kernel(const StepArgs a) {
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN>
+__global__ void __launch_bounds__(64, (RT || NM > 6) ? 1 : 2) squareroot_split_kernel(const StepArgs a) {
     __shared__ T lds[sqsplit_lds_elems<NS, NM>() * (64 / L)];
-    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT>(a, blockIdx.x, lds);
+    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT, RT>(a, blockIdx.x, lds);
 }
 #undef KB_SB
 

@@ -13,6 +13,7 @@ bool launch_squareroot_split12(const Batch &b, const StepArgs &a) {
         else hipLaunchKernelGGL((squareroot_split_kernel<double, 12, 6, 0, 4, false, false>), grid, block, 0, b.stream, a);
         return true;
     }
+    if (launch_squareroot_split12_plain(b, a)) return true;
     hipLaunchKernelGGL((squareroot_split_kernel<double, 12, 8, 2, 4, true, false>), grid, block, 0, b.stream, a);
     return true;
 }

@@ -625,5 +625,7 @@ bool launch_vanilla_shared(const Batch &b, const StepArgs &a);
 // one filter split over L lanes (kb_vanilla_split.h): n <= 12, p <= 8, m <= 2 (kb_vanilla_split12.hip), fp64, one step per launch
 bool launch_vanilla_split12(const Batch &b, const StepArgs &a);
 bool launch_vanilla_split16(const Batch &b, const StepArgs &a);   // 13..16 states: eight lanes per filter
+bool launch_vanilla_split12_plain(const Batch &b, const StepArgs &a);   // kb_vanilla_split12p.hip / 16p.hip: padded shapes, Noiseless, state only
+bool launch_vanilla_split16_plain(const Batch &b, const StepArgs &a);
 
 }  // namespace kb

@@ -241,8 +241,10 @@ constexpr int split_waves_per_simd() { return (int)sizeof(T) * split_lds_elems<N
 #endif
 
 // GEN = false: the batch has exactly this shape, Noiseless, FULL / PREDICT as given.  GEN = true: any n <= NS, p <= NM, m <= NC
-// (zero padding as in kb_vanilla_reg.h PAD: zeros, and an identity block in R), FULL / PREDICT / Noise taken from the launch
-// arguments (wave-uniform branches): ONE instantiation per (NS, NM) carries every other member of the family.
+// (zero padding as in kb_vanilla_reg.h PAD: zeros, and an identity block in R).  RT = true (GEN only): FULL / PREDICT / Noise are
+// taken from the launch arguments (wave-uniform branches) -- ONE instantiation per NS carries every member of the family, at one
+// wave per SIMD and 100 KB of code; RT = false: Noiseless, FULL / PREDICT as given -- the padded shapes of the common case on the
+// exact kernel's schedule, one instantiation per (NS, NM in {4, 6, 8}).
 //
 // Scheduling.  The kernel is ~4000 instructions of straight-line code, and left alone the machine scheduler gathers loads (170
 // global, 600 LDS) far ahead of their uses: 2 KB of spills per lane.  So every phase is written as a PIPELINE over chunks -- the LDS
@@ -253,20 +255,20 @@ template <typename T, int NS, int NM, int L, bool GEN, bool FULLT>
 constexpr int split_lds_total() {
     constexpr int KP = (tri(NS) + L - 1) / L;
     constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;
-    return (XOFF + ((GEN || FULLT) ? 2 * NM + NS * NM : 0)) * (64 / L);
+    return (XOFF + ((GEN || FULLT || NS * NM > tri(NS)) ? 2 * NM + NS * NM : 0)) * (64 / L);   // (GEN here: run-time FULL, the kernel's RT)
 }
 // one wave's part of one tile: filters [64 tile + (gw % L) 64 / L, ... + 64 / L), gw = L tile + part
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN>
 __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "rows are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
     constexpr int HOFF = TR;                       // LDS element offset of H (later: K) next to the packed P-
     constexpr int KP = (TR + L - 1) / L;           // packed elements of P per lane
     constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;   // FULL: innovation and yhat wait here for the end of the step
-    constexpr int GOFF = (GEN || FULLT) ? XOFF + 2 * NM : 0;   // P- H^T for the Joseph form: over P-, unless P- is still to be stored (FULL)
+    constexpr int GOFF = (RT || FULLT || NS * NM > TR) ? XOFF + 2 * NM : 0;   // P- H^T for the Joseph form: over P-, unless P- is still to be stored (FULL) or n p elements reach into H behind it
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
-    const bool full = GEN ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
-    const bool predict = GEN ? a.predict != 0 : PREDT;
+    const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
+    const bool predict = RT ? a.predict != 0 : PREDT;
     const unsigned lane = threadIdx.x;
     const int q = (int)((lane / FPW) & (L - 1)), f = (int)(lane & (FPW - 1));
     const int64_t tile = gw / L;
@@ -467,12 +469,12 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         }
     }
 
-    // ---- Noise (GEN only; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
+    // ---- Noise (RT only; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
     // into x+ (:195), k = kf.step of THIS filter.  The normals of a draw are the filter's (kb_vanilla_reg.h draw_normals: Philox keyed
     // by the filter index), formed by each of its L lanes; the lane applies its own rows of chol(Q) (read from the model block: the
     // constructor's factor) to them.
     [[maybe_unused]] T wpost[RP], vmeas[NM];
-    if constexpr (GEN) {
+    if constexpr (RT) {
 #pragma unroll
         for (int r = 0; r < RP; r++) wpost[r] = T(0);
 #pragma unroll
@@ -672,8 +674,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int c = 0; c < NM; c++) {
                 T yh = part[NV + c];
-                if constexpr (GEN) yh += vmeas[c];   // Measurement(k), vanilla.go:157
-                if constexpr (GEN || FULLT) {
+                if constexpr (RT) yh += vmeas[c];   // Measurement(k), vanilla.go:157
+                if constexpr (RT || FULLT) {
                     if (q == 0) { lf[(XOFF + c) * FPW] = innov[c]; lf[(XOFF + NM + c) * FPW] = yh; }
                 }
             }
@@ -738,7 +740,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
             xn[r] = xm[r] + s;
-            if constexpr (GEN) xn[r] += wpost[r];   // vanilla.go:195: Process(k) a second time
+            if constexpr (RT) xn[r] += wpost[r];   // vanilla.go:195: Process(k) a second time
         }
         // ---- Joseph form (see the header): AP = (I - K H) P- = P- - K (P- H^T)^T for the own rows.  The own rows of P- are read
         // into AP, then P- H^T -- every row of it is needed -- goes to LDS: in P-'s place, or behind everything else when the
@@ -920,7 +922,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             if (q == 0) {
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if constexpr (GEN || FULLT) {
+                    if constexpr (RT || FULLT) {
                         if (c < rp) {
                             __builtin_nontemporal_store(lf[(XOFF + c) * FPW], ep(es, a.L.es_innov, c) + us);
                             __builtin_nontemporal_store(lf[(XOFF + NM + c) * FPW], ep(es, a.L.es_yhat, c) + us);
@@ -937,17 +939,17 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false>
-__global__ void __launch_bounds__(64, (GEN ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
-    __shared__ T lds[split_lds_total<T, NS, NM, L, GEN, FULLT>()];
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN>
+__global__ void __launch_bounds__(64, ((RT || NM > 6) ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
+    __shared__ T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
     if constexpr (PERSIST) {
         const int64_t nparts = a.ntiles * L;
         for (int64_t gw = blockIdx.x; gw < nparts; gw += gridDim.x) {
-            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT>(a, gw, lds);
+            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT>(a, gw, lds);
             wave_lds_fence();
         }
     } else {
-        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT>(a, blockIdx.x, lds);
+        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT>(a, blockIdx.x, lds);
     }
 }
 #undef KB_SB

@@ -1,6 +1,7 @@
 // kb_vanilla_split12.hip -- Vanilla.Update with one filter split over four lanes (kb_vanilla_split.h): 12 states.
 //   exact 12 / 6 / 0, Noiseless: the orbit-determination-sized shape the SRIF benchmark (config E) uses, per-filter models
-//   GEN <12, 8, 2>: every other shape with n <= 12, p <= 8, m <= 2 that has no one-filter-per-lane register kernel
+//   padded shapes, Noiseless, state only: kb_vanilla_split12p.hip
+//   GEN <12, 8, 2> with run-time FULL / PREDICT / Noise: every other batch with n <= 12, p <= 8, m <= 2 that has no one-filter-per-lane register kernel
 #include "kb_vanilla_split.h"
 
 namespace kb {
@@ -26,6 +27,7 @@ static bool split_exact(const Batch &b, const StepArgs &a) {
 bool launch_vanilla_split12(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n > 12 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
     if (split_exact<double, 12, 6, 0, 4>(b, a)) return true;
+    if (launch_vanilla_split12_plain(b, a)) return true;
     hipLaunchKernelGGL((vanilla_split_kernel<double, 12, 8, 2, 4, true, false, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     return true;
 }

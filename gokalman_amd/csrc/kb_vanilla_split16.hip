@@ -6,6 +6,7 @@ namespace kb {
 
 bool launch_vanilla_split16(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
+    if (launch_vanilla_split16_plain(b, a)) return true;
     hipLaunchKernelGGL((vanilla_split_kernel<double, 16, 8, 2, 8, true, false, false>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
     return true;
 }

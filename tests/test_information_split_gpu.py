@@ -47,7 +47,7 @@ def test_infsplit_12x6_at_4096_filters_20_steps_vs_oracle():
 
 
 @pytest.mark.parametrize("n,p,m", [(7, 2, 0), (8, 4, 1), (9, 5, 2), (10, 1, 0), (11, 7, 0), (12, 6, 0), (12, 8, 2), (12, 3, 1),
-                                   (13, 2, 0), (14, 8, 1), (15, 7, 2), (16, 8, 2), (16, 6, 0)])
+                                   (13, 2, 0), (14, 8, 1), (15, 7, 2), (16, 8, 2), (16, 6, 0), (8, 3, 2), (7, 4, 0), (8, 5, 0), (10, 4, 0), (16, 4, 1), (14, 6, 0)])
 def test_infsplit_padded_family_vs_oracle(n, p, m):
     N, steps = 150, 6
     d = _model(N, n, p, m, steps, 9000 + 100 * n + 10 * p + m)

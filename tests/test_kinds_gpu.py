@@ -412,6 +412,40 @@ def test_chisquare_nees_nis_vs_oracle_replay():
         ga.new_chi_square(kf, mc, controls[:2])
 
 
+@pytest.mark.parametrize("n,p,m", [(3, 1, 2), (4, 2, 1), (4, 2, 2), (6, 3, 1), (6, 3, 2)])
+def test_chisquare_with_control_inputs_vs_oracle_replay(n, p, m):
+    """NewChiSquare with controls (chisquare.go:40-44 hands controls[k] to every Update) on every shape chisq_kernel is
+    instantiated for with a control input: both G (the truth's and the filter's) wait in LDS, as H / chol(Q) / chol(R) of the truth do."""
+    rng = np.random.default_rng(100 * n + 10 * p + m)
+    F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); G = 0.3 * rng.standard_normal((n, m)); H = rng.standard_normal((p, n))
+    A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n)
+    B = 0.2 * rng.standard_normal((p, p)); R = B @ B.T + 1e-2 * np.eye(p)
+    x0, P0, mc_x0 = np.zeros(n), 1.5 * np.eye(n), 0.2 * rng.standard_normal(n)
+    runs, steps = 80, 12
+    controls = rng.standard_normal((steps, m))
+    truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=9)
+    kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, nfilters=runs)
+    mc = ga.new_monte_carlo_runs(runs, steps, p, controls, truth)
+    nis, nees = ga.new_chi_square(kf, mc, controls)
+    LQ, LR = orc.cholesky_lower(Q)[1], orc.cholesky_lower(R)[1]
+    ts, tm = np.zeros((runs, steps, n)), np.zeros((runs, steps, p))
+    for r in range(runs):
+        f = orc.Filter.ldkf(orc.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R)
+        for t in range(steps):
+            w = LQ @ truth.noise_sample(r, 0, t, 0, n); v = LR @ truth.noise_sample(r, 0, t, 1, p)
+            assert f.update(np.zeros(p), controls[t], w_pred=w, v_meas=v) == orc.OK
+            ts[r, t], tm[r, t] = f.state(), f.measurement()
+    assert synth.rel_frobenius(mc._states(), ts) <= 1e-12 and synth.rel_frobenius(mc._measurements(), tm) <= 1e-12
+
+    def factory():
+        f = orc.Filter.ldkf(orc.VANILLA, x0, P0, F, G, H, Q, R)
+        f._H, f._R = H, R
+        return f
+
+    onis, onees = orc.chisquare(factory, ts, tm, controls)
+    assert np.allclose(nis, onis, rtol=1e-8) and np.allclose(nees, onees, rtol=1e-8)
+
+
 @pytest.mark.parametrize("kind", [k.HYBRID, k.SRIF])
 def test_smooth_all_backward_sweep_vs_oracle(kind):
     """SmoothAll (hybrid.go:209-238, srif.go:165-192): x_k = S x_{k+1}, P_k = sym(S P_{k+1} S^T), S = inverse(Phi_{k+1})."""

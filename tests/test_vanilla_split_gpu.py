@@ -69,7 +69,7 @@ def test_split_12x6_at_4096_filters_20_steps_device_path_vs_oracle():
 
 
 SHAPES = [(9, 1, 0), (9, 4, 1), (10, 5, 2), (11, 7, 0), (12, 6, 0), (12, 8, 2), (12, 3, 1), (8, 6, 0), (7, 5, 2),
-          (13, 2, 0), (14, 8, 1), (15, 7, 2), (16, 8, 2), (16, 6, 0)]
+          (13, 2, 0), (14, 8, 1), (15, 7, 2), (16, 8, 2), (16, 6, 0), (10, 4, 0), (12, 6, 1), (16, 4, 1), (14, 6, 0)]
 
 
 @pytest.mark.parametrize("n,p,m", SHAPES)
