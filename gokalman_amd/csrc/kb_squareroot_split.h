@@ -52,6 +52,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     constexpr int BOFF = TR > NS * NM ? TR : NS * NM;   // LDS: [0, BOFF) S, later Uc, later W (n x p, parked as its rows become final);
     constexpr int XOFF = BOFF + 2 * NS + 2;   // [BOFF, XOFF) the reflector of the current step; then x- (n) and H x- (p), parked until the end;
     constexpr int SYOFF = XOFF + NS + NM;    // then Syy^T (p x p), written entry by entry as the measurement columns become final
+    constexpr bool XPARK = NS <= NM * NM;
     typedef __attribute__((address_space(1))) T *gptr;
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
@@ -111,6 +112,12 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
         for (int k = 0; k < KP; k++)
             if (L * k + L - 1 < TR || L * k + q < TR) lf[(L * k + q) * FPW] = Sp[k];
+        if constexpr (XPARK) {   // FULL: x_prev waits in Syy's slots (free until the second factorisation) for yhat = H x_prev
+            if (full) {
+#pragma unroll
+                for (int l = 0; l < NS; l++) lf[(SYOFF + l) * FPW] = x[l];   // (the L lanes of a filter write the same values)
+            }
+        }
     }
     wave_lds_fence();
     KB_SB();
@@ -277,14 +284,19 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
             for (int i = 0; i < NS; i++) Dm[r2][NM + i] = T(0);
         }
-        if (full) {   // squareroot.go:237-239 yhat = H x_prev: x is read a second time (a cache hit), not kept through the first factorisation
+        if (full) {   // squareroot.go:237-239 yhat = H x_prev: x_prev from its LDS slots (or read a second time: a cache hit), not kept through the first factorisation
 #pragma unroll
             for (int r2 = 0; r2 < PC; r2++) {
                 T s = T(0);
 #pragma unroll
-                for (int l = 0; l < NS; l++) s += Hrow[r2][l] * ((l < rn) ? *(ep(st, 0, l) + us) : T(0));
+                for (int l = 0; l < NS; l++) {
+                    if constexpr (XPARK) s += Hrow[r2][l] * lf[(SYOFF + l) * FPW];
+                    else s += Hrow[r2][l] * ((l < rn) ? *(ep(st, 0, l) + us) : T(0));
+                }
                 hxp[r2] = s;
+                pin(hxp[r2]);
             }
+            KB_SB();
         }
         // bottom rows, one column of Uc per chunk (column i of Uc is packed contiguously: Uc[l][i] at tri(i) + l)
         T col[2][NS];

@@ -255,7 +255,7 @@ template <typename T, int NS, int NM, int L, bool GEN, bool FULLT>
 constexpr int split_lds_total() {
     constexpr int KP = (tri(NS) + L - 1) / L;
     constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;
-    return (XOFF + ((GEN || FULLT || NS * NM > tri(NS)) ? 2 * NM + NS * NM : 0)) * (64 / L);   // (GEN here: run-time FULL, the kernel's RT)
+    return (XOFF + (NS * NM > tri(NS) ? NS * NM : 0)) * (64 / L);
 }
 // one wave's part of one tile: filters [64 tile + (gw % L) 64 / L, ... + 64 / L), gw = L tile + part
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN>
@@ -264,8 +264,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
     constexpr int HOFF = TR;                       // LDS element offset of H (later: K) next to the packed P-
     constexpr int KP = (TR + L - 1) / L;           // packed elements of P per lane
-    constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;   // FULL: innovation and yhat wait here for the end of the step
-    constexpr int GOFF = (RT || FULLT || NS * NM > TR) ? XOFF + 2 * NM : 0;   // P- H^T for the Joseph form: over P-, unless P- is still to be stored (FULL) or n p elements reach into H behind it
+    constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;
+    constexpr int GOFF = NS * NM > TR ? XOFF : 0;   // P- H^T for the Joseph form: over P-, unless its n p elements would reach into H behind it
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
     const bool predict = RT ? a.predict != 0 : PREDT;
@@ -350,7 +350,6 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 
     // ---- phase 1: x- = F x [+ G u], T = F P (own rows), one column of P per chunk -------------------------------------------
     T xm[RP], Tm[RP][NS];
-    [[maybe_unused]] T xo[RP];   // x_prev[i_r] (FULL: yhat = H x_prev, vanilla.go:155-157)
 #pragma unroll
     for (int r = 0; r < RP; r++) {
         T s = T(0);
@@ -358,11 +357,6 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         for (int l = 0; l < NS; l++) s += Fo[r][l] * x[l];
         xm[r] = s;
         pin(xm[r]);
-        xo[r] = T(0);
-        if (full) {
-#pragma unroll
-            for (int l = L * r; l < L * r + L; l++) xo[r] = (l % L == q) ? x[l] : xo[r];
-        }
     }
     T Pm[RP][NS];   // [r][j] for j >= L r; the other entries are never touched.  First Q, then P-
     unsigned utri[RP];   // um + 64 tri(i_r)
@@ -558,6 +552,21 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         for (int j = L * r; j < NS; j++) {
             if (j >= L * r + L - 1 || j >= q + L * r) lf[(j * (j + 1) / 2 + q + L * r) * FPW] = Pm[r][j];
         }
+    // FULL (vanilla.go:170-179, :216-218): every extra member of the Estimate leaves where it is formed -- P- here, yhat and the
+    // innovation behind the lane sums, K behind the inverse -- whether or not the step is applied in the end (a failed step has no
+    // Estimate: its slots are not read); kept for one store at the end they cost the kernel half of its waves (10 KB of LDS)
+    T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
+    if constexpr (RT || FULLT) {
+        if (full && active) {
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int j = L * r; j < NS; j++) {
+                    const gptr pe = ep(es, a.L.es_ppred, j * (j + 1) / 2 + L * r) + uq;   // (formed outside the lane-dependent branch)
+                    if (rowok[r] && j < rn && (j >= L * r + L - 1 || j >= q + L * r)) __builtin_nontemporal_store(Pm[r][j], pe);
+                }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NM; c++)
 #pragma unroll
@@ -582,7 +591,15 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
         for (int c = 0; c < NM; c++) PHt[r][c] = T(0);
     T R1[TM], y[NM];   // requested here, used behind the P- H^T loop
+    [[maybe_unused]] T xo[RP];   // x_prev[i_r] (FULL: yhat = H x_prev, vanilla.go:155-157): read a second time, not carried from the top
     auto request_Ry = [&]() {
+        if constexpr (RT || FULLT) {
+#pragma unroll
+            for (int r = 0; r < RP; r++) {
+                const T v = (full && rowany[r]) ? *(ep(st, 0, L * r) + (rowok[r] ? uq : us)) : T(0);
+                xo[r] = rowok[r] ? v : T(0);
+            }
+        }
         load_R(R1, std::false_type{});
         const T *yp = (const T *)a.y + tile * a.y_ts;
 #pragma unroll
@@ -645,9 +662,11 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             T s = T(0), s2 = T(0);
 #pragma unroll
             for (int r = 0; r < RP; r++) s += Hp[c][r] * xm[r];
-            if (full) {
+            if constexpr (RT || FULLT) {
+                if (full) {   // (H x_prev)[c], vanilla.go:155-157
 #pragma unroll
-                for (int r = 0; r < RP; r++) s2 += Hp[c][r] * xo[r];
+                    for (int r = 0; r < RP; r++) s2 += Hp[c][r] * xo[r];
+                }
             }
             part[TM + c] = s;
             part[NV + c] = s2;
@@ -676,7 +695,10 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 T yh = part[NV + c];
                 if constexpr (RT) yh += vmeas[c];   // Measurement(k), vanilla.go:157
                 if constexpr (RT || FULLT) {
-                    if (q == 0) { lf[(XOFF + c) * FPW] = innov[c]; lf[(XOFF + NM + c) * FPW] = yh; }
+                    if (q == 0 && active && c < rp) {
+                        __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
+                        __builtin_nontemporal_store(yh, ep(es, a.L.es_yhat, c) + us);
+                    }
                 }
             }
         }
@@ -721,6 +743,15 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             if (i < rp) inorm = (rows[i] > inorm || rows[i] != rows[i]) ? rows[i] : inorm;
         if (!(anorm * inorm <= T(1e16))) err = KB_ST_SINGULAR;
     }
+    if constexpr (RT || FULLT) {
+        if (full && active) {
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NM; c++)
+                    if (rowok[r] && c < rp) __builtin_nontemporal_store(K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
+        }
+    }
     KB_SB();
 
     T xn[RP];
@@ -743,8 +774,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             if constexpr (RT) xn[r] += wpost[r];   // vanilla.go:195: Process(k) a second time
         }
         // ---- Joseph form (see the header): AP = (I - K H) P- = P- - K (P- H^T)^T for the own rows.  The own rows of P- are read
-        // into AP, then P- H^T -- every row of it is needed -- goes to LDS: in P-'s place, or behind everything else when the
-        // Estimate's P- is still to be stored from there (FULL); two columns of AP per chunk
+        // into AP, then P- H^T -- every row of it is needed -- goes to LDS in P-'s place (behind everything else when its n p
+        // elements would not fit in front of H); two columns of AP per chunk
         T AP[RP][NS], R[TM];
 #pragma unroll
         for (int r = 0; r < RP; r++)
@@ -841,7 +872,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 }
             KB_SB();
         }
-        // K takes H's place in LDS (P- stays: the FULL estimate stores it from there), P+ = AP + V K^T, two rows of K per chunk
+        // K takes H's place in LDS, P+ = AP + V K^T, two rows of K per chunk
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < RP; r++)
@@ -907,29 +938,6 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             }
         };
         KB_WITH_STATE_POLICY(a, store_state);
-        if (full) {   // the Estimate's extras: P- (from LDS: the lane's share of the packed triangle), K (own rows), innovation, yhat
-            T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
-#pragma unroll
-            for (int k = 0; k < KP; k++) {
-                const int e = L * k + q;
-                if (e < tri(rn)) __builtin_nontemporal_store(lf[e * FPW], ep(es, a.L.es_ppred, L * k) + uq);
-            }
-#pragma unroll
-            for (int r = 0; r < RP; r++)
-#pragma unroll
-                for (int c = 0; c < NM; c++)
-                    if (rowok[r] && c < rp) __builtin_nontemporal_store(K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
-            if (q == 0) {
-#pragma unroll
-                for (int c = 0; c < NM; c++)
-                    if constexpr (RT || FULLT) {
-                        if (c < rp) {
-                            __builtin_nontemporal_store(lf[(XOFF + c) * FPW], ep(es, a.L.es_innov, c) + us);
-                            __builtin_nontemporal_store(lf[(XOFF + NM + c) * FPW], ep(es, a.L.es_yhat, c) + us);
-                        }
-                    }
-            }
-        }
     }
     // (the filter index is formed again from the lane number: kept from the top of the kernel it would occupy two registers all along)
     const unsigned lane_end = late_lane();
