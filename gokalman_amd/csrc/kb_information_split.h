@@ -1,6 +1,5 @@
-// kb_information_split.h -- Information.Update (information.go:153-227) for 6 < n <= 16 with ONE FILTER SPLIT OVER L LANES
-// (state-only outputs; KB_FLAG_FULL_ESTIMATE batches -- whose yhat needs State(prev) = I^-1 i, a second n x n inverse -- stay on the
-// statement kernel).  Mapping as kb_vanilla_split.h: a wave owns 64 / L filters, lane = q (64 / L) + f, lane q owns rows q, q + L, ...
+// kb_information_split.h -- Information.Update (information.go:153-227) for 6 < n <= 16 with ONE FILTER SPLIT OVER L LANES.
+// Mapping as kb_vanilla_split.h: a wave owns 64 / L filters, lane = q (64 / L) + f, lane q owns rows q, q + L, ...
 //
 //   M = F^-T I F^-1   (:163-165) two products "own rows x whole matrix": F^-1, then T1 = I F^-1, broadcast through LDS (one n x n
 //                     region, reused); the own COLUMNS of F^-1 (= rows of F^-T) are read back from that region.
@@ -12,6 +11,10 @@
 //                     the wave pivots) and the elimination are local again.  Back substitution needs all of U: row by row through LDS.
 //   I- = M + Z M^T, i- = (1 + Z)(F^-T i [+ M G u])  (:176-190) M broadcast through LDS; F^-T i gathered through LDS.
 //   i+ = H^T R^-1 y + i-, I+ = I- + H^T R^-1 H  (:197-212) own columns of H in registers, H broadcast through LDS.
+//   FULL (KB_FLAG_FULL_ESTIMATE): yhat = H State(prev) [+ Measurement(k)] (:192-194), State(prev) = inverse(I) i with the inverse
+//                     mirrored from its upper triangle, or zeros when gonum's Inverse reports a Condition error (:284-288): the SAME
+//                     distributed solve on I X = 1 at the top of the kernel, while every register and all of the LDS are free; the
+//                     inverse goes to LDS whole, each lane reads the mirrored rows it owns.  I- leaves for the Estimate as it is formed.
 // The sums run in the reference's order; LAPACK's pivot choice (first largest entry, one exchange per column).
 #pragma once
 #include "kb_vanilla_split.h"
@@ -23,10 +26,10 @@ namespace kb {
 template <int NS>
 constexpr int infsplit_lds_elems() { return NS * NS + NS + 4; }   // one n x n operand | the hand-over of one elimination / substitution step
 
-template <typename T, int NS, int NM, int NC, int L, bool GEN>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT = false>
 __device__ __forceinline__ void information_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "rows are dealt out cyclically");
-    constexpr int FPW = 64 / L, RP = NS / L, TM = tri(NM);
+    constexpr int FPW = 64 / L, RP = NS / L, TM = tri(NM), PC = (NM + L - 1) / L;
     constexpr int BOFF = NS * NS;   // LDS: [0, n^2) the broadcast operand of the phase; [n^2, n^2 + n + 4) hand-over buffer
     typedef __attribute__((address_space(1))) T *gptr;
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
@@ -62,6 +65,215 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         return l >= q + L * r ? base_q + (unsigned)((l * (l + 1) / 2 + L * r) * KB_TILE) : base + utri[r] + (unsigned)(l * KB_TILE);
     };
 
+    // The distributed pivoted LU solve Bm^T Y = Rm^T (used for Z, and for State(prev) with FULL): column c of the matrix is Bm (own row c
+    // of B), column c of the right-hand side is Rm; on return Rm[r][j] = Y[j][i_r].  zero_pivot: some pivot was exactly zero.
+    auto solve = [&](T (&Bm)[RP][NS], T (&Rm)[RP][NS], bool &zero_pivot) __attribute__((always_inline)) {
+        sfor<0, NS>([&](auto KK) __attribute__((always_inline)) {
+            constexpr int k = KK, rk = k / L, qk = k % L;
+            {   // the owner of column k: pivot (first largest |entry| among rows k..n-1, LAPACK idamax), reciprocal, multipliers
+                int piv = k;
+                T best = fabs(Bm[rk][k]);
+    #pragma unroll
+                for (int r2 = k + 1; r2 < NS; r2++) {
+                    const bool gt = fabs(Bm[rk][r2]) > best;
+                    best = gt ? fabs(Bm[rk][r2]) : best;
+                    piv = gt ? r2 : piv;
+                }
+                T pv = Bm[rk][k];
+    #pragma unroll
+                for (int r2 = k + 1; r2 < NS; r2++) pv = (piv == r2) ? Bm[rk][r2] : pv;
+                const T rpv = T(1) / pv;
+                if (q == qk) {
+                    lf[(BOFF + 0) * FPW] = (T)piv;
+                    lf[(BOFF + 1) * FPW] = pv;
+    #pragma unroll
+                    for (int r2 = k + 1; r2 < NS; r2++) {
+                        // the multiplier of row r2 AFTER the exchange: the entry that sits in row r2 then is the old row k's if r2 == piv
+                        const T e = (piv == r2) ? Bm[rk][k] : Bm[rk][r2];
+                        lf[(BOFF + 1 + r2) * FPW] = e * rpv;
+                    }
+                }
+            }
+            wave_lds_fence();
+            {
+                const int piv = (int)lf[(BOFF + 0) * FPW];
+                zero_pivot = zero_pivot || (lf[(BOFF + 1) * FPW] == T(0));
+                T mult[NS];
+    #pragma unroll
+                for (int r2 = k + 1; r2 < NS; r2++) mult[r2] = lf[(BOFF + 1 + r2) * FPW];
+                // rows k and piv change places in every column: entries k and piv of every own row of B and of M -- only when some filter of the
+                // wave pivots.  (sfor, not `#pragma unroll` loops: inside the conditional block those are unrolled too late for the arrays
+                // to be promoted to registers: 592 B of scratch per lane.)
+                if (__any(piv != k))
+                sfor<0, RP>([&](auto RR) __attribute__((always_inline)) {
+                    constexpr int r = RR;
+                    T bk = Bm[r][k], mk = Rm[r][k];
+                    T bp = bk, mp = mk;
+                    sfor<k + 1, NS>([&](auto R2) __attribute__((always_inline)) {
+                        constexpr int r2 = R2;
+                        const bool hit = piv == r2;
+                        bp = hit ? Bm[r][r2] : bp;
+                        mp = hit ? Rm[r][r2] : mp;
+                        Bm[r][r2] = hit ? bk : Bm[r][r2];
+                        Rm[r][r2] = hit ? mk : Rm[r][r2];
+                    });
+                    Bm[r][k] = bp;
+                    Rm[r][k] = mp;
+                });
+    #pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    const bool right = r > rk || (r == rk && q > qk);   // own column q + L r of the matrix lies right of k
+    #pragma unroll
+                    for (int r2 = k + 1; r2 < NS; r2++) {
+                        if (r >= rk) Bm[r][r2] -= (right ? mult[r2] : T(0)) * Bm[r][k];
+                        Rm[r][r2] -= mult[r2] * Rm[r][k];
+                    }
+                }
+    #pragma unroll
+                for (int r = 0; r < RP; r++)
+    #pragma unroll
+                    for (int c = 0; c < NS; c++) { pin(Bm[r][c]); pin(Rm[r][c]); }
+            }
+            wave_lds_fence();
+            KB_SB();
+        });
+        // back substitution, row i = n - 1 .. 0: U[i][c] for c >= i sits with the owners of columns c (Bm[.][i]); they hand row i over
+        sfor<0, NS>([&](auto II) __attribute__((always_inline)) {
+            constexpr int i = NS - 1 - II;
+    #pragma unroll
+            for (int r = 0; r < RP; r++)
+                if (L * r + L - 1 >= i) {
+                    if (q + L * r >= i) lq[(BOFF + L * r) * FPW] = Bm[r][i];   // slot c = q + L r holds U[i][c]
+                }
+            wave_lds_fence();
+            {
+                const T rd = T(1) / lf[(BOFF + i) * FPW];
+                T urow[NS];
+    #pragma unroll
+                for (int c = i + 1; c < NS; c++) urow[c] = lf[(BOFF + c) * FPW];
+    #pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    T s = Rm[r][i];
+    #pragma unroll
+                    for (int c = i + 1; c < NS; c++) s -= urow[c] * Rm[r][c];
+                    Rm[r][i] = s * rd;
+                    pin(Rm[r][i]);
+                }
+            }
+            wave_lds_fence();
+            KB_SB();
+        });
+    };
+
+    // ---- FULL: State(prev) = inverse(I) i (information.go:284-288), yhat = H State(prev) [+ Measurement(k)] (:192-194) -----------------------
+    [[maybe_unused]] T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
+    if constexpr (FULLT) {
+        T Ar[RP][NS], Er[RP][NS];   // own rows of I (mirrored; read again in phase 0: cache hits), own rows of the identity
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int l = 0; l < NS; l++) {
+                const bool okl = rowok[r] && l < rn, diag = (l % L == q && l / L == r);
+                const gptr pe = ep(st, rn, 0) + (okl ? sym_off(r, l, uq, us) : us);
+                const T v = (rowany[r] && l < rn) ? *pe : T(0);
+                Ar[r][l] = okl ? v : (diag ? T(1) : T(0));   // padding: an identity block
+                Er[r][l] = diag ? T(1) : T(0);
+            }
+        // |I|_inf (mat64's condition test, kb_device.h inverse_lu): the own row sums, gathered, the same running maximum in every lane
+        auto gathered_max = [&](const T (&rs)[RP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = rs[r];
+            wave_lds_fence();
+            T m = T(0);
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const T v = lf[(BOFF + i) * FPW];
+                if (i < rn) m = (v > m || v != v) ? v : m;
+            }
+            wave_lds_fence();
+            return m;
+        };
+        T rs[RP];
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            T sacc = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) sacc += fabs(Ar[r][l]);
+            rs[r] = sacc;
+        }
+        const T anorm = gathered_max(rs);
+        bool bad = false;
+        solve(Ar, Er, bad);
+        // Er[r][j] = X[j][i_r]: the own COLUMNS of the inverse.  All of it goes to LDS (slot j n + c), free at this point
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) lq[(j * NS + L * r) * FPW] = Er[r][j];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            T sacc = T(0);
+#pragma unroll
+            for (int c = 0; c < NS; c++) sacc += fabs(lqn[((L * r) * NS + c) * FPW]);
+            rs[r] = sacc;
+        }
+        const T inorm = gathered_max(rs);
+        bad = bad || !(anorm * inorm <= T(1e16));
+        T ivp[NS];   // the information vector: requested here (and again in phase 0), not carried through the solve
+#pragma unroll
+        for (int l = 0; l < NS; l++) ivp[l] = l < rn ? *(ep(st, 0, l) + us) : T(0);
+        // State(prev)[i_r] = sum_j P[i_r][j] i[j], P mirrored from the upper triangle of X (AsSymDense): X[i_r][j] right of the diagonal
+        // (own row: slot i_r n + j), X[j][i_r] left of it (slot j n + i_r)
+#pragma unroll
+        for (int r = 0; r < RP; r++) {
+            T sacc = T(0);
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                T pij;
+                if (j >= L * r + L - 1) pij = lqn[((L * r) * NS + j) * FPW];
+                else if (j < L * r) pij = lq[(j * NS + L * r) * FPW];
+                else pij = *(j >= q + L * r ? lqn + ((L * r) * NS + j) * FPW : lq + (j * NS + L * r) * FPW);
+                sacc += pij * ivp[j];
+            }
+            rs[r] = bad ? T(0) : sacc;   // (zeros: information.go:286-288)
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = rs[r];
+        wave_lds_fence();
+        // yhat: lane q forms the measurement rows c = q + L r2 (row c of H, and of chol(R) with AWGN) and stores them
+        [[maybe_unused]] T z1[NM];
+        const bool awgn = a.noise_kind == KB_NOISE_AWGN;
+        if (awgn) {
+            const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + (unsigned)slot;
+            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + slot] : 0u);   // kf.step of this filter
+            draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < PC; r2++) {
+            const int cbase = L * r2;
+            const bool real = (cbase + L - 1 < NM || q + cbase < NM) && q + cbase < rp;
+            const unsigned urow = real ? um + (unsigned)((q + cbase) * rn * KB_TILE) : um;
+            T sacc = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) sacc += ((cbase < rp && l < rn) ? ldg(mo, a.L.mo_H, l, urow) : T(0)) * lf[(BOFF + l) * FPW];
+            if (awgn) {
+                const unsigned utr = real ? um + (unsigned)(((q + cbase) * (q + cbase + 1) / 2) * KB_TILE) : um;
+                T v = T(0);
+#pragma unroll
+                for (int i = 0; i < NM; i++) {
+                    const bool in = real && i <= q + cbase;
+                    const T lr = (cbase < rp && i < cbase + L && i < rp) ? ldg(mo, a.L.mo_LR, i, utr) : T(0);
+                    v += (in ? lr : T(0)) * z1[i];
+                }
+                sacc += v;
+            }
+            const gptr pe = ep(es, a.L.es_yhat, cbase) + uq;   // (formed outside the lane-dependent branch)
+            if (real && active) __builtin_nontemporal_store(sacc, pe);
+        }
+        wave_lds_fence();
+        KB_SB();
+    }
     // ---- phase 0: F^-1 (own rows -> LDS), i (all), I (own rows) -------------------------------------------------------------------------
     T iv[NS], Ir[RP][NS];
     {
@@ -183,100 +395,8 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         for (int j = 0; j < NS; j++) lqn[((L * r) * NS + j) * FPW] = Mr[r][j];
     wave_lds_fence();
     KB_SB();
-    // (M + Q^-1)^T Y = M^T: column c of the matrix is Br (row c of B), column c of the right-hand side is Mr (row c of M)
-    sfor<0, NS>([&](auto KK) __attribute__((always_inline)) {
-        constexpr int k = KK, rk = k / L, qk = k % L;
-        {   // the owner of column k: pivot (first largest |entry| among rows k..n-1, LAPACK idamax), reciprocal, multipliers
-            int piv = k;
-            T best = fabs(Br[rk][k]);
-#pragma unroll
-            for (int r2 = k + 1; r2 < NS; r2++) {
-                const bool gt = fabs(Br[rk][r2]) > best;
-                best = gt ? fabs(Br[rk][r2]) : best;
-                piv = gt ? r2 : piv;
-            }
-            T pv = Br[rk][k];
-#pragma unroll
-            for (int r2 = k + 1; r2 < NS; r2++) pv = (piv == r2) ? Br[rk][r2] : pv;
-            const T rpv = T(1) / pv;
-            if (q == qk) {
-                lf[(BOFF + 0) * FPW] = (T)piv;
-#pragma unroll
-                for (int r2 = k + 1; r2 < NS; r2++) {
-                    // the multiplier of row r2 AFTER the exchange: the entry that sits in row r2 then is the old row k's if r2 == piv
-                    const T e = (piv == r2) ? Br[rk][k] : Br[rk][r2];
-                    lf[(BOFF + 1 + r2) * FPW] = e * rpv;
-                }
-            }
-        }
-        wave_lds_fence();
-        {
-            const int piv = (int)lf[(BOFF + 0) * FPW];
-            T mult[NS];
-#pragma unroll
-            for (int r2 = k + 1; r2 < NS; r2++) mult[r2] = lf[(BOFF + 1 + r2) * FPW];
-            // rows k and piv change places in every column: entries k and piv of every own row of B and of M -- only when some filter of the
-            // wave pivots.  (sfor, not `#pragma unroll` loops: inside the conditional block those are unrolled too late for the arrays
-            // to be promoted to registers: 592 B of scratch per lane.)
-            if (__any(piv != k))
-            sfor<0, RP>([&](auto RR) __attribute__((always_inline)) {
-                constexpr int r = RR;
-                T bk = Br[r][k], mk = Mr[r][k];
-                T bp = bk, mp = mk;
-                sfor<k + 1, NS>([&](auto R2) __attribute__((always_inline)) {
-                    constexpr int r2 = R2;
-                    const bool hit = piv == r2;
-                    bp = hit ? Br[r][r2] : bp;
-                    mp = hit ? Mr[r][r2] : mp;
-                    Br[r][r2] = hit ? bk : Br[r][r2];
-                    Mr[r][r2] = hit ? mk : Mr[r][r2];
-                });
-                Br[r][k] = bp;
-                Mr[r][k] = mp;
-            });
-#pragma unroll
-            for (int r = 0; r < RP; r++) {
-                const bool right = r > rk || (r == rk && q > qk);   // own column q + L r of the matrix lies right of k
-#pragma unroll
-                for (int r2 = k + 1; r2 < NS; r2++) {
-                    if (r >= rk) Br[r][r2] -= (right ? mult[r2] : T(0)) * Br[r][k];
-                    Mr[r][r2] -= mult[r2] * Mr[r][k];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < RP; r++)
-#pragma unroll
-                for (int c = 0; c < NS; c++) { pin(Br[r][c]); pin(Mr[r][c]); }
-        }
-        wave_lds_fence();
-        KB_SB();
-    });
-    // back substitution, row i = n - 1 .. 0: U[i][c] for c >= i sits with the owners of columns c (Br[.][i]); they hand row i over
-    sfor<0, NS>([&](auto II) __attribute__((always_inline)) {
-        constexpr int i = NS - 1 - II;
-#pragma unroll
-        for (int r = 0; r < RP; r++)
-            if (L * r + L - 1 >= i) {
-                if (q + L * r >= i) lq[(BOFF + L * r) * FPW] = Br[r][i];   // slot c = q + L r holds U[i][c]
-            }
-        wave_lds_fence();
-        {
-            const T rd = T(1) / lf[(BOFF + i) * FPW];
-            T urow[NS];
-#pragma unroll
-            for (int c = i + 1; c < NS; c++) urow[c] = lf[(BOFF + c) * FPW];
-#pragma unroll
-            for (int r = 0; r < RP; r++) {
-                T s = Mr[r][i];
-#pragma unroll
-                for (int c = i + 1; c < NS; c++) s -= urow[c] * Mr[r][c];
-                Mr[r][i] = s * rd;
-                pin(Mr[r][i]);
-            }
-        }
-        wave_lds_fence();
-        KB_SB();
-    });
+    bool ignored = false;   // (the reference ignores this inverse's error, :171)
+    solve(Br, Mr, ignored);
     // Mr[r][j] = Y[j][i_r] = (M B^-1)[i_r][j] = -Z[i_r][j]
     // ---- phase D: i- = (1 + Z)(F^-T i [+ M G u]) (:176-185), I- = M + Z M^T (:188-190; own rows, columns j >= L r) ---------------------------
     if constexpr (NC > 0) {
@@ -336,6 +456,15 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
                 }
             KB_SB();
         }
+    }
+    if constexpr (FULLT) {   // I- leaves at once (Estimate.PredCovariance, information.go:295-316 inverts it lazily), as in kb_information_reg.hip
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int j = L * r; j < NS; j++) {
+                const gptr pe = ep(es, a.L.es_ppred, j * (j + 1) / 2 + L * r) + uq;
+                if (active && rowok[r] && j < rn && (j >= L * r + L - 1 || j >= q + L * r)) __builtin_nontemporal_store(Im[r][j], pe);
+            }
     }
     // ---- phase E: H^T R^-1 (own rows), i+ = H^T R^-1 y + i-, I+ = I- + H^T R^-1 H (:197-212) ------------------------------------------------
     T Hp[NM][RP], Ri[TM], y[NM];
@@ -427,10 +556,10 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         atomicOr(a.status + tile * KB_TILE + (int64_t)((gw % L) * FPW + (lane_end & (FPW - 1))), (unsigned)KB_ST_NONFINITE);
 }
 
-template <typename T, int NS, int NM, int NC, int L, bool GEN>
-__global__ void __launch_bounds__(64, GEN ? 1 : 2) information_split_kernel(const StepArgs a) {
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT = false>
+__global__ void __launch_bounds__(64, 2) information_split_kernel(const StepArgs a) {
     __shared__ T lds[infsplit_lds_elems<NS>() * (64 / L)];
-    information_split_part<T, NS, NM, NC, L, GEN>(a, blockIdx.x, lds);
+    information_split_part<T, NS, NM, NC, L, GEN, FULLT>(a, blockIdx.x, lds);
 }
 #undef KB_SB
 

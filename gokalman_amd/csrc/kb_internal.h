@@ -175,6 +175,7 @@ int launch_information(const Batch &b, const StepArgs &a);   // kb_information_r
 int launch_information_gen(const Batch &b, const StepArgs &a);
 bool launch_information_split(const Batch &b, const StepArgs &a);       // kb_information_split12.hip: 6 < n <= 16, one filter over four / eight lanes
 bool launch_information_split8(const Batch &b, const StepArgs &a);      // kb_information_split8.hip: n <= 8, p <= 4 (called by launch_information_split)
+bool launch_information_split_full(const Batch &b, const StepArgs &a);  // kb_information_split12f.hip: the same with KB_FLAG_FULL_ESTIMATE
 int launch_srif_gen(const Batch &b, const StepArgs &a);
 int launch_hybrid_gen(const Batch &b, const StepArgs &a);
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused);   // kb_squareroot_reg.hip (falls back to _gen)

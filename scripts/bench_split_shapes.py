@@ -13,7 +13,7 @@ import gokalman_amd as ga
 from gokalman_amd import _capi as k
 
 N = 1 << 18
-KINDS, MAXN, FULL = None, 16, False
+KINDS, MAXN, MINN, FULL = None, 16, 0, False
 for a in sys.argv[1:]:
     if a.startswith("--n="):
         N = int(a[4:])
@@ -21,15 +21,17 @@ for a in sys.argv[1:]:
         KINDS = a[7:].split(",")
     if a == "--full":
         FULL = True
+    if a.startswith("--min-n="):
+        MINN = int(a[8:])
     if a.startswith("--max-n="):
         MAXN = int(a[8:])
 tri = lambda n: n * (n + 1) // 2
-SHAPES = [(7, 3), (8, 2), (8, 4), (9, 3), (10, 5), (12, 6), (12, 3), (14, 7), (16, 8)]
+SHAPES = [(7, 3), (8, 2), (8, 4), (9, 3), (10, 5), (12, 6), (12, 3), (14, 7), (16, 4), (16, 8)]
 for kind, name in ((k.VANILLA, "vanilla"), (k.SQUAREROOT, "squareroot"), (k.INFORMATION, "information")):
     if KINDS is not None and name not in KINDS:
         continue
     for (n, p) in SHAPES:
-        if n > MAXN:
+        if n > MAXN or n < MINN:
             continue
         rng = np.random.default_rng(n)
         # per-filter models (every filter reads its own F, H, Q, R from HBM): one base model, scaled per filter
@@ -38,7 +40,7 @@ for kind, name in ((k.VANILLA, "vanilla"), (k.SQUAREROOT, "squareroot"), (k.INFO
         Q = sc * (1e-3 * np.eye(n)); R = sc * (1e-2 * np.eye(p))
         x0 = np.zeros((N, n)); P0 = np.broadcast_to(np.eye(n), (N, n, n))
         b = ga.FilterBatch.new_ldkf(kind, x0, P0, F, None, H, Q, R,
-                                    flags=k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else (k.FLAG_FULL_ESTIMATE if FULL else 0))
+                                    flags=(k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0) | (k.FLAG_FULL_ESTIMATE if FULL else 0))
         del F, Q
         y = torch.randn((p, N), dtype=torch.float64, device="cuda")
         s = torch.cuda.ExternalStream(b.stream())

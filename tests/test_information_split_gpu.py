@@ -75,3 +75,15 @@ def test_infsplit_pivoting_in_the_distributed_solve():
     fs = _oracle(d, steps, 0)
     assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs])) <= 1e-8
     assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs])) <= 1e-8
+
+
+@pytest.mark.parametrize("n,p,m,awgn,from_state", [(12, 6, 0, False, True), (12, 6, 0, True, True), (9, 3, 1, True, True), (8, 4, 2, False, True),
+                                                   (7, 2, 0, True, False), (16, 8, 2, False, True), (14, 5, 0, True, True), (12, 6, 0, False, False),
+                                                   (11, 7, 1, False, False)])
+def test_infsplit_full_estimate_vs_oracle(n, p, m, awgn, from_state):
+    """KB_FLAG_FULL_ESTIMATE on the split kernels: I- and yhat = H State(prev) [+ Measurement(k)] (information.go:188-194), State(prev)
+    from the distributed inverse of I (zeros while I is singular: the from_state = False cases start at i0 = 0, I0 = 0) -- the checks of
+    the one-filter-per-lane kernels' test, shape for shape (yhat within the asymmetry of the oracle's own inverse, I-, I+, the
+    lazily inverted PredCovariance, State())."""
+    from tests.test_kinds_gpu import test_information_full_estimate_on_the_register_kernels as full_case
+    full_case(n, p, m, awgn, from_state, state_rtol=1e-8)   # (State() = I^-1 i at 7..16 states: a second inverse on top of I+, as above)
