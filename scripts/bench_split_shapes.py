@@ -26,7 +26,7 @@ for a in sys.argv[1:]:
     if a.startswith("--max-n="):
         MAXN = int(a[8:])
 tri = lambda n: n * (n + 1) // 2
-SHAPES = [(7, 3), (8, 2), (8, 4), (9, 3), (10, 5), (12, 6), (12, 3), (14, 7), (16, 4), (16, 8)]
+SHAPES = [(7, 3), (8, 2), (8, 4), (9, 3), (10, 5), (12, 6), (12, 3), (12, 8), (14, 7), (16, 4), (16, 8)]
 for kind, name in ((k.VANILLA, "vanilla"), (k.SQUAREROOT, "squareroot"), (k.INFORMATION, "information")):
     if KINDS is not None and name not in KINDS:
         continue
