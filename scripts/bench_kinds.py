@@ -205,8 +205,9 @@ if "srif" in which:
     rng = np.random.default_rng(5)
     x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
     R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
-    for dt, nm, w in ((k.F32, "E: SRIF 12/6 f32", 4), (k.F64, "SRIF 12/6 f64", 8)):
-        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dt)
+    srif_flags = k.FLAG_FULL_ESTIMATE if "--srif-full" in sys.argv else 0   # (with the Estimate's extras: R-bar, yhat, the pre-fit residual, the innovation)
+    for dt, nm, w in ((k.F32, "E: SRIF 12/6 f32" + (" FULL" if srif_flags else ""), 4), (k.F64, "SRIF 12/6 f64" + (" FULL" if srif_flags else ""), 8)):
+        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dt, flags=srif_flags)
         b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
         tdt = torch.float32 if dt == k.F32 else torch.float64
         Phi = (torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=tdt, device="cuda")).contiguous()
