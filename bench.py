@@ -166,8 +166,28 @@ def _leg_parity(ga, k, synth, leg):
     from oracle import oracle as orc
     N, T = 4096, 20
     out = {"filters": N, "steps": T, "against": "oracle/gokalman_oracle.c"}
-    if leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6"):
-        nn, pp = (12, 6) if leg in ("vanilla_12x6", "squareroot_12x6") else (N_STATE, N_MEAS)
+    if leg == "information_12x6":
+        # Information carries (i, I): those are compared (RAW_VEC / RAW_MAT), filter by filter against the oracle's
+        # NewInformationFromState filters -- the first 512 of the 4096 (State() / Covariance() are inverses on top: cond x 1e-9)
+        d = synth.linear_batch(N, 12, 6, T, seed=synth.SEED + 77)
+        b = ga.FilterBatch.new_ldkf(k.INFORMATION, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_INFO_FROM_STATE)
+        y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+        for t in range(T):
+            b.update_dev(y[t].data_ptr(), N)
+        b.synchronize()
+        M = 512
+        fs = [orc.Filter.information_from_state(d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]) for i in range(M)]
+        nerr = 0
+        for f_, i in zip(fs, range(M)):
+            for t in range(T):
+                nerr += f_.update(d["y"][t, i]) != orc.OK
+        ei = synth.rel_frobenius(b.get(k.RAW_VEC, 0, M), np.array([f_.raw_vec() for f_ in fs]))
+        eI = synth.rel_frobenius(b.get(k.RAW_MAT, 0, M), np.array([f_.raw_mat() for f_ in fs]))
+        out.update({"oracle_filters": M, "max_rel_frobenius_information_vector": ei, "max_rel_frobenius_information_matrix": eI, "tolerance": 1e-9,
+                    "ok": bool(ei <= 1e-9 and eI <= 1e-9 and nerr == 0 and not b.status().any())})
+        return out
+    if leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "vanilla_10x4"):
+        nn, pp = (12, 6) if leg in ("vanilla_12x6", "squareroot_12x6") else ((10, 4) if leg == "vanilla_10x4" else (N_STATE, N_MEAS))
         d = synth.linear_batch(N, nn, pp, T, seed=synth.SEED + 77)
         if leg == "shared_model":
             for f in ("F", "H", "Q", "R"):
@@ -175,7 +195,7 @@ def _leg_parity(ga, k, synth, leg):
             b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"][0], None, d["H"][0], d["Q"][0], d["R"][0], nfilters=N)
             okind = orc.VANILLA
         else:
-            kind, okind = (k.VANILLA, orc.VANILLA) if leg == "vanilla_12x6" else (k.SQUAREROOT, orc.SQUAREROOT)
+            kind, okind = (k.VANILLA, orc.VANILLA) if leg in ("vanilla_12x6", "vanilla_10x4") else (k.SQUAREROOT, orc.SQUAREROOT)
             b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
         y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
         for t in range(T):
@@ -661,6 +681,30 @@ def main():
                                                                 *rl.load_traffic(ROOT, "squareroot_split_kernel<double, 12, 6, 0, 4, false, false")),
                                     "filters_with_error_status": qbad2}
         del qb, yq
+        # ... Information at the same size (kb_information_split.h: the pivoted LU solve distributed over four lanes)
+        dq = synth.linear_batch(M, 12, 6, 1, seed=synth.SEED + 5000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)
+        ib = ga.FilterBatch.new_ldkf(k.INFORMATION, dq["x0"], dq["P0"], dq["F"], None, dq["H"], dq["Q"], dq["R"], device=local_rank, flags=k.FLAG_INFO_FROM_STATE)
+        i_s, ims, ibad = timed_leg(ib, lambda: ib.update_dev(yq.data_ptr(), M), K6)
+        extra["information_12x6"] = {"config": "%d Information 12/6 fp64 filters per GPU, per-filter models (kb_information_split.h: one filter per four lanes)" % M,
+                                     "filters_total": world * M, "steps": K6, "value": world * M * K6 / i_s,
+                                     "unit": "filter-update steps/s (whole job)", "kernel_ms": ims,
+                                     "roofline": rl.hbm_roofline(ims, M, rl.algorithmic_bytes("information", 12, 6), rl.moved_bytes("information", 12, 6),
+                                                                 *rl.load_traffic(ROOT, "information_split_kernel<double, 12, 6, 0, 4, false")),
+                                     "filters_with_error_status": ibad}
+        del ib, yq
+        # ... and a member of the padded family: Vanilla 10 / 4 on the 12-state / 4-measurement instantiation (run-time dimensions)
+        dq = synth.linear_batch(M, 10, 4, 1, seed=synth.SEED + 6000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)
+        pb = ga.FilterBatch.new_ldkf(k.VANILLA, dq["x0"], dq["P0"], dq["F"], None, dq["H"], dq["Q"], dq["R"], device=local_rank)
+        p_s, pms, pbad = timed_leg(pb, lambda: pb.update_dev(yq.data_ptr(), M), K6)
+        extra["vanilla_10x4"] = {"config": "%d Vanilla 10/4 fp64 filters per GPU, per-filter models (padded: vanilla_split_kernel<double, 12, 4, 2, 4, GEN>)" % M,
+                                 "filters_total": world * M, "steps": K6, "value": world * M * K6 / p_s,
+                                 "unit": "filter-update steps/s (whole job)", "kernel_ms": pms,
+                                 "roofline": rl.hbm_roofline(pms, M, rl.algorithmic_bytes("vanilla", 10, 4), rl.moved_bytes("vanilla", 10, 4),
+                                                             *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 12, 4, 2, 4, true, false, false")),
+                                 "filters_with_error_status": pbad}
+        del pb, yq
     if args.srif_filters > 0:
         M = args.srif_filters
         sn, sp = 12, 6
@@ -746,7 +790,7 @@ def main():
                                 "note": "%d MB of host measurements per call: H2D copy + pack + step + synchronise" % (N * p * 8 // 1000000)}
         if not args.no_parity:
             out["parity"] = _parity(ga, k, synth)
-            for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
+            for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6", "vanilla_10x4", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
                 if leg in extra:
                     extra[leg]["parity"] = _leg_parity(ga, k, synth, leg)
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones

@@ -75,7 +75,7 @@ def test_two_ranks_self_launched_over_gloo_on_one_gpu():
     for a, b in zip(e1["stddev_last"], e2["stddev_last"]):
         assert abs(a - b) <= 1e-9 * abs(a)
     # every leg proves itself against the oracle on rank 0 (4096 filters x 20 steps), the fp32 SRIF leg reports its achieved error
-    for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "hybrid_ekf", "srif_fp32"):
+    for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6", "vanilla_10x4", "hybrid_ekf", "srif_fp32"):
         assert one["extra"][leg]["parity"]["ok"], (leg, one["extra"][leg]["parity"])
     assert one["extra"]["srif_fp32"]["parity"]["achieved_max_rel_frobenius_R"] <= one["extra"]["srif_fp32"]["parity"]["tolerance"]
     assert two["extra"]["vanilla_12x6"]["filters_total"] == 2 * 8192 and two["extra"]["vanilla_12x6"]["filters_with_error_status"] == 0
