@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vsplit", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hstrict", "mc"]
+which = args or ["vsplit", "vpad", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -103,6 +103,22 @@ if "vsplit" in which:
         report("Vanilla 12/6 f64, statement kernel (KB_FLAG_STATEMENT_KERNELS)", N, ms, rl.algorithmic_bytes("vanilla", 12, 6), {"errors": int(np.count_nonzero(b.status()))},
                moved=rl.moved_bytes("vanilla", 12, 6))
         del b
+
+if "vpad" in which:
+    # members of the padded family on the split kernels' run-time-dimension instantiations (Noiseless, state only): Vanilla 10 / 4 on
+    # <12, 4>, SquareRoot 8 / 4 on <8, 4>, Information 8 / 4 on <8, 4>, Vanilla 16 / 4 on <16, 4> (eight lanes per filter); and the 12 / 6
+    # Vanilla with KB_FLAG_FULL_ESTIMATE (the Estimate's extras leave where they are formed)
+    N = Nopt or (1 << 18)
+    for kind, kname, n, p, flags in ((k.VANILLA, "Vanilla", 10, 4, 0), (k.SQUAREROOT, "SquareRoot", 8, 4, 0), (k.INFORMATION, "Information", 8, 4, k.FLAG_INFO_FROM_STATE),
+                                     (k.VANILLA, "Vanilla", 16, 4, 0), (k.VANILLA, "Vanilla FULL", 12, 6, k.FLAG_FULL_ESTIMATE)):
+        d = synth.linear_batch(N, n, p, 1)
+        y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=flags)
+        ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
+        fam = "vanilla_full" if flags & k.FLAG_FULL_ESTIMATE else kname.split()[0].lower()
+        report("%s %d/%d f64, split-lane kernel" % (kname, n, p), N, ms, rl.algorithmic_bytes(fam if fam != "vanilla_full" else "vanilla", n, p),
+               {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes(fam, n, p))
+        del b, d, y
 
 if "sqsplit" in which:
     # SquareRoot beyond 6 states: 12 / 6 at config E's batch size, per-filter models (kb_squareroot_split.h: one filter over four lanes,
