@@ -559,7 +559,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT = false>
 __global__ void __launch_bounds__(64, 2) information_split_kernel(const StepArgs a) {
     __shared__ T lds[infsplit_lds_elems<NS>() * (64 / L)];
-    information_split_part<T, NS, NM, NC, L, GEN, FULLT>(a, blockIdx.x, lds);
+    information_split_part<T, NS, NM, NC, L, GEN, FULLT>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);   // (kb_vanilla_split.h: XCD-aware for L = 8)
 }
 #undef KB_SB
 

@@ -613,7 +613,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN>
 __global__ void __launch_bounds__(64, ((RT || NM > 6) && L == 4) ? 1 : 2) squareroot_split_kernel(const StepArgs a) {
     __shared__ T lds[sqsplit_lds_elems<NS, NM>() * (64 / L)];
-    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT, RT>(a, blockIdx.x, lds);
+    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT, RT>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);   // (kb_vanilla_split.h: XCD-aware for L = 8)
 }
 #undef KB_SB
 

@@ -945,6 +945,18 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         fail_step(a, tile * KB_TILE + (int64_t)((gw % L) * FPW + (lane_end & (FPW - 1))), err);   // vanilla.go:164-167, :207-215 return before kf.step++ (:218)
 }
 
+// Which part a workgroup takes.  With L = 8 a part is 8 filters: 64 bytes of every 512-byte element row, HALF a 128-byte line; its
+// neighbour (the other half of every line) would be the next workgroup -- on the next XCD (workgroups are dealt round-robin over
+// the 8 XCDs, each with its own L2): every line fetched twice (FETCH_SIZE: 11.7 KB per filter-step at 16 / 4 against 6.2 KB packed).
+// So within each run of 16 workgroups, workgroups b and b + 8 (same XCD, dispatched back to back) take neighbouring parts.
+template <int L>
+__device__ __forceinline__ int64_t split_part_of_block(unsigned b, unsigned nblocks) {
+    if constexpr (L != 8) return b;
+    if (b >= (nblocks & ~15u)) return b;
+    const unsigned r = b & 15u;
+    return (int64_t)((b & ~15u) + ((r & 7u) << 1) + (r >> 3));
+}
+
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN>
@@ -957,7 +969,7 @@ __global__ void __launch_bounds__(64, (((RT || NM > 6) && L == 4) ? 1 : split_wa
             wave_lds_fence();
         }
     } else {
-        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT>(a, blockIdx.x, lds);
+        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
     }
 }
 #undef KB_SB
