@@ -215,7 +215,11 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count);
  * pred_covariance / gain / measurement (and innovation of the Vanilla / SquareRoot / Hybrid kinds) need a batch created
  * with KB_FLAG_FULL_ESTIMATE.  status receives the per-filter status bits; with clear_status != 0 the words are read AND
  * cleared in one atomic step, which gives a host shim the reference's per-call error: an Update that fails for a filter
- * leaves that filter's previous estimate in place and does not poison the next call (vanilla.go:164-167). */
+ * leaves that filter's state and covariance as they were and does not poison the next call (vanilla.go:164-167).  The reference
+ * returns NO estimate for such an Update ((nil, err)): the other members of a failed filter's slot (pred_covariance, gain,
+ * innovation, measurement) are unspecified for that step -- some kernels write them as they are formed, before the step is
+ * known to succeed (SquareRoot / Information: I-, yhat; the split-lane kernels for 8 < n <= 16: all four) -- and the host
+ * mirrors hand out no Estimate for a filter whose status is set. */
 typedef struct kb_estimate_view {
     double *state;           /* [count][n]                                                          */
     double *covariance;      /* [count][n][n]                                                       */
