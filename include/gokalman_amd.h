@@ -218,8 +218,8 @@ int kb_get(kb_batch *b, int field, double *host, int64_t first, int64_t count);
  * leaves that filter's state and covariance as they were and does not poison the next call (vanilla.go:164-167).  The reference
  * returns NO estimate for such an Update ((nil, err)): the other members of a failed filter's slot (pred_covariance, gain,
  * innovation, measurement) are unspecified for that step -- some kernels write them as they are formed, before the step is
- * known to succeed (SquareRoot / Information: I-, yhat; the split-lane kernels for 8 < n <= 16: all four) -- and the host
- * mirrors hand out no Estimate for a filter whose status is set. */
+ * known to succeed (SquareRoot / Information: I-, yhat; the split-lane kernels for 8 < n <= 16: all four) -- and the
+ * single-filter host mirrors (Go, C++) turn a set status word into the reference's (nil, err); batch callers check status. */
 typedef struct kb_estimate_view {
     double *state;           /* [count][n]                                                          */
     double *covariance;      /* [count][n][n]                                                       */
