@@ -243,3 +243,24 @@ def test_split_shared_model_one_filter_batches_and_measurement_dimension_changes
         assert synth.rel_frobenius(est.gain().reshape(1, -1), f.gain().reshape(1, -1)) <= TOL, t
         assert np.max(np.abs(est.innovation().ravel() - f.innovation())) <= 1e-9 and np.max(np.abs(est.measurement().ravel() - f.measurement())) <= 1e-9
     assert one.step() == steps
+
+
+@pytest.mark.parametrize("kind", [k.VANILLA, k.SQUAREROOT, k.INFORMATION])
+@pytest.mark.parametrize("n,p", [(12, 6), (16, 4), (14, 7), (10, 4)])
+def test_split_sharded_batch_is_bit_equal_to_the_unsharded_batch(kind, n, p):
+    """Filters share nothing (vanilla.go:216-218): the same 4099 filters as ONE batch and as three shards (kb_sharded_*: ragged
+    boundaries [g N / G, (g + 1) N / G), so parts and -- with eight lanes per filter -- the XCD-aware part mapping
+    (split_part_of_block) fall differently in each) are the same bits, and every filter was stepped exactly once per call."""
+    N, steps, shards = 4099, 4, 3
+    d = _model(N, n, p, 0, steps, 4242 + n)
+    flags = k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0
+    one = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=flags)
+    sh = ga.ShardedBatch(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], N, devices=[0] * shards, flags=flags)
+    for t in range(steps):
+        one.update(d["y"][t], snapshot=False)
+        sh.update(d["y"][t])
+    raw_v, raw_m = (k.RAW_VEC, k.RAW_MAT) if kind == k.INFORMATION else (k.STATE, k.COVAR)
+    assert np.array_equal(sh.get(raw_v, (n,)), one.get(raw_v))
+    assert np.array_equal(sh.get(raw_m, (n, n)), one.get(raw_m))
+    assert not sh.status().any() and not one.status().any()
+    assert all(one.filter_step(i) == steps for i in (0, 63, 64, 2047, 4098))
