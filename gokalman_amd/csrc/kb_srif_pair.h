@@ -624,6 +624,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
 template <typename T, int NS>
 constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 * 2 <= 160 * 1024 ? 2 : 1; }
 
+#ifndef KB_SRIF_FULL_ONE_WAVE
+#define KB_SRIF_FULL_ONE_WAVE 1   // KB_FLAG_FULL_ESTIMATE variants: one wave per SIMD.  They need ~300 registers at their peak (251 without
+                                  // the Estimate's stores); at two waves that is 216 B of scratch and a load phase in which every y is
+                                  // spilled as it arrives: fp32 166-169 us against 140-144 us at one wave (A/B, profiles/NOTES.md)
+#endif
 #ifndef KB_PAIR_WPB
 #define KB_PAIR_WPB 1   // waves per workgroup.  They share nothing; with 4 per workgroup a finished wave's slot and LDS stay
                         // reserved until its three companions are done: 89.8 us against 86.7 us (fp32, 256k filters)
@@ -632,7 +637,7 @@ constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 *
 // with a dense R (they failed the Update that followed a Predict()); the dense kernel marked their half-tiles in a.srif_dense, and
 // those are left to srif_pair_dense_kernel, which the host launches right behind this kernel for as long as that can be the case.
 template <typename T, int NS, int NM, bool FULL, bool EXT>
-__global__ void __launch_bounds__(64 * KB_PAIR_WPB, (srif_pair_waves_per_simd<T, NS>())) srif_pair_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64 * KB_PAIR_WPB, ((KB_SRIF_FULL_ONE_WAVE && FULL) ? 1 : srif_pair_waves_per_simd<T, NS>())) srif_pair_kernel(const StepArgs a) {
     __shared__ T lds[KB_PAIR_WPB * NS * NS * 32];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: all bases become scalar
