@@ -460,6 +460,20 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             }
         }
     }
+    // FULL: RBar leaves for the Estimate INSIDE each branch of the permutation test below.  Behind the join every entry of the panel is
+    // a phi of the two branches, and a consumer of all 72 of them there costs ~50 registers at the kernel's peak (216 B of scratch in
+    // fp32, 532 B in fp64, every y spilled as it arrives: 166 us against 88 us state-only) -- the Householder does not, it takes them
+    // column by column.  Found by bisection (profiles/NOTES.md).
+    auto store_rbar = [&]() __attribute__((always_inline)) {
+        if constexpr (FULL) {
+            if (ok) {
+#pragma unroll
+                for (int s = 0; s < HS; s++)
+#pragma unroll
+                    for (int j = 0; j < NS; j++) __builtin_nontemporal_store(A.get(s, j), es + ((unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow));
+            }
+        }
+    };
     // bBar = RBar xBar (srif.go:119), same products in pivoted order; then the row permutation is undone
     if (anyswap) {   // cold: some lane pivoted.  Register arrays cannot be indexed per lane: select chains
         T xp[NS];
@@ -488,6 +502,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             for (int c = 0; c < NS; c++) A.set(s, c, row[c]);
             A.set(s, NS, bb);
         }
+        store_rbar();
     } else {
 #pragma unroll
         for (int s = 0; s < HS; s++) {
@@ -496,14 +511,11 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             for (int r = 0; r < NS; r++) bb += A.get(s, r) * xbar[r];
             A.set(s, NS, bb);
         }
+        store_rbar();
     }
     if constexpr (MEAS_LATE) { __builtin_amdgcn_sched_barrier(0); whiten(); }
     if constexpr (FULL) {
         if (ok) {
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-#pragma unroll
-                for (int j = 0; j < NS; j++) __builtin_nontemporal_store(A.get(s, j), es + ((unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow));
 #pragma unroll
             for (int t = 0; t < HM; t++) {
                 __builtin_nontemporal_store(yown[t], es + ((unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl));
@@ -625,9 +637,8 @@ template <typename T, int NS>
 constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 * 2 <= 160 * 1024 ? 2 : 1; }
 
 #ifndef KB_SRIF_FULL_ONE_WAVE
-#define KB_SRIF_FULL_ONE_WAVE 1   // KB_FLAG_FULL_ESTIMATE variants: one wave per SIMD.  They need ~300 registers at their peak (251 without
-                                  // the Estimate's stores); at two waves that is 216 B of scratch and a load phase in which every y is
-                                  // spilled as it arrives: fp32 166-169 us against 140-144 us at one wave (A/B, profiles/NOTES.md)
+#define KB_SRIF_FULL_ONE_WAVE 0   // (1: the KB_FLAG_FULL_ESTIMATE variants at one wave per SIMD -- what helped while RBar was stored behind
+                                  // the join of the permutation test, see store_rbar)
 #endif
 #ifndef KB_PAIR_WPB
 #define KB_PAIR_WPB 1   // waves per workgroup.  They share nothing; with 4 per workgroup a finished wave's slot and LDS stay
