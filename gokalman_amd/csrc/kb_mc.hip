@@ -161,12 +161,130 @@ static bool mc_try(const Batch &b, const StepArgs &a, const void *d_controls, in
     return false;
 }
 
+// Any other state dimension up to 16 (montecarlo.go:92-119 is shape-generic).  The ensemble is ONE filter fanned out (kb_replicate), so
+// the model is the same for every run: F, G, chol(Q), H, chol(R) are read once per workgroup into LDS (run 0's copy) and every lane
+// reads them from there as broadcast operands -- per lane only x and the noise-free trajectory c live in registers (2 n doubles;
+// with the model per lane, as in mc_kernel, 12 states would need 250).  Same sums in the same order as mc_kernel; zero padding to NS.
+template <typename T, int NS>
+__global__ void __launch_bounds__(256) mc_gen_kernel(const StepArgs a, const T *__restrict__ controls, int ncontrols,
+                                                     double *__restrict__ sums /* [REPL][steps][2][n] */, double *__restrict__ shift /* [steps][n] */,
+                                                     T *__restrict__ traj, int64_t traj_ld) {
+    constexpr int TQ = tri(NS), PM = 8, TP = tri(PM);   // (p <= 8: the engine's envelope for n <= 16)
+    __shared__ T sF[NS * NS], sLQ[TQ], sG[NS * 2], sH[PM * NS], sLR[TP];
+    const int n = a.n, p = a.p, nc = a.need_ctrl ? a.m : 0;
+    {   // run 0's model block: element e of a field at mo0[(field + e) * KB_TILE]
+        const T *mo0 = (const T *)a.model;
+        for (int e = threadIdx.x; e < NS * NS; e += blockDim.x) { const int i = e / NS, l = e % NS; sF[e] = (i < n && l < n) ? ldt(mo0, a.L.mo_F + i * n + l) : T(0); }
+        for (int e = threadIdx.x; e < TQ; e += blockDim.x) sLQ[e] = e < tri(n) ? ldt(mo0, a.L.mo_LQ + e) : T(0);   // (packed by rows of the lower triangle: the index does not depend on n)
+        for (int e = threadIdx.x; e < NS * 2; e += blockDim.x) { const int i = e / 2, c = e % 2; sG[e] = (i < n && c < nc) ? ldt(mo0, a.L.mo_G + i * nc + c) : T(0); }
+        if (traj) {
+            for (int e = threadIdx.x; e < PM * NS; e += blockDim.x) { const int r = e / NS, l = e % NS; sH[e] = (r < p && l < n) ? ldt(mo0, a.L.mo_H + r * n + l) : T(0); }
+            for (int e = threadIdx.x; e < TP; e += blockDim.x) sLR[e] = e < tri(p) ? ldt(mo0, a.L.mo_LR + e) : T(0);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    const T *st = (const T *)a.state + tile * ((int64_t)KB_TILE * a.L.st_elems) + lane;
+    T x[NS], c[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { x[i] = i < n ? ldt(st, a.L.st_vec + i) : T(0); c[i] = x[i]; }
+    double *my = sums + (size_t)(tile % MC_REPL) * a.nsteps * 2 * n;
+    const uint64_t gfi = (uint64_t)(a.first_filter + fi);
+    for (int t = 0; t < a.nsteps; t++) {
+        asm volatile("" ::: "memory");   // the model is re-read from LDS every step, not hoisted into (hundreds of) registers
+        if (traj && active) {   // Measurement() = H x_prev + L_R z (vanilla.go:155-157), Noise.Measurement(k)
+            for (int r = 0; r < p; r++) {
+                T s = T(0);
+#pragma unroll
+                for (int l = 0; l < NS; l++) s += sH[r * NS + l] * x[l];
+                T v = T(0);
+                for (int k = 0; k <= r; k++) v += sLR[symi(k, r)] * (T)normal_at(a.seed, gfi, (uint32_t)(a.step0 + t), (uint32_t)(a.epoch * 4 + 1), k);
+                traj[((int64_t)t * (n + p) + n + r) * traj_ld + fi] = s + v;
+            }
+        }
+        T xn[NS], cn[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0), sc = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) { const T f = sF[i * NS + l]; s += f * x[l]; sc += f * c[l]; }
+            xn[i] = s; cn[i] = sc;
+        }
+        if (nc > 0) {
+            const T *u = controls + (ncontrols == 1 ? 0 : (int64_t)t * nc);
+            const T u0 = ncontrols == 1 ? T(0) : u[0], u1 = (ncontrols == 1 || nc < 2) ? T(0) : u[1];
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                T s = T(0);
+                s += sG[i * 2 + 0] * u0;
+                s += sG[i * 2 + 1] * u1;
+                xn[i] = xn[i] + s; cn[i] = cn[i] + s;
+            }
+        }
+        T z[NS];   // Noise.Process(k): w = L_Q z (noise.go:133-136)
+#pragma unroll
+        for (int k = 0; k < NS; k += 2) {
+            z[k] = T(0);
+            if (k + 1 < NS) z[k + 1] = T(0);
+            if (k < n) {   // (wave-uniform)
+                uint32_t r[4];
+                Philox::gen(a.seed, gfi, (uint32_t)(a.step0 + t), ((uint32_t)(a.epoch * 4 + 0) << 8) | (uint32_t)(k >> 1), r);
+                double z0, z1;
+                box_muller(r, z0, z1);
+                z[k] = (T)z0;
+                if (k + 1 < NS) z[k + 1] = (T)z1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k <= i; k++) s += sLQ[symi(k, i)] * z[k];
+            x[i] = xn[i] + s;
+            c[i] = cn[i];
+        }
+        if (traj && active) {
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+                if (i < n) traj[((int64_t)t * (n + p) + i) * traj_ld + fi] = x[i];
+        }
+        constexpr int V = NS <= 8 ? 16 : 32;   // 2 NS values, padded to a power of two
+        double acc[V];
+#pragma unroll
+        for (int i = 0; i < V / 2; i++) {
+            const double dlt = (i < NS && active) ? (double)x[i < NS ? i : 0] - (double)c[i < NS ? i : 0] : 0.0;
+            acc[2 * i] = dlt;
+            acc[2 * i + 1] = dlt * dlt;
+        }
+        wave_sum_multi<V>(acc, lane);
+        if (lane < 2 * n) atomicAdd(my + ((size_t)t * 2 + (lane & 1)) * n + (lane >> 1), acc[0]);
+        if (tile == 0 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NS; i++)
+                if (i < n) shift[(size_t)t * n + i] = (double)c[i];
+        }
+    }
+}
+
+template <typename T, int NS>
+static bool mc_gen_try(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift, void *traj, int64_t traj_ld) {
+    if (a.n > NS || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
+    hipLaunchKernelGGL((mc_gen_kernel<T, NS>), tile_grid(a.ntiles), dim3(256), 0, b.stream, a, (const T *)d_controls, ncontrols, d_sums, d_shift, (T *)traj, traj_ld);
+    return true;
+}
+
 template <typename T>
 static int launch_mc_t(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, double *d_shift, void *traj, int64_t traj_ld) {
     const bool ok = mc_try<T, 2>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) || mc_try<T, 3>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) ||
-                    mc_try<T, 4>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) || mc_try<T, 6>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld);
+                    mc_try<T, 4>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) || mc_try<T, 6>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) ||
+                    mc_gen_try<T, 8>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) || mc_gen_try<T, 12>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld) ||
+                    mc_gen_try<T, 16>(b, a, d_controls, ncontrols, d_sums, d_shift, traj, traj_ld);
     if (!ok) {
-        set_error("kb_mc_run: no Monte-Carlo kernel for n=%d, m=%d (built: n in {2,3,4,6}, m <= 2)", a.n, a.need_ctrl ? a.m : 0);
+        set_error("kb_mc_run: no Monte-Carlo kernel for n=%d, p=%d, m=%d (built: n <= 16, p <= 8, m <= 2)", a.n, a.p, a.need_ctrl ? a.m : 0);
         return KB_ERR_UNSUPPORTED;
     }
     KB_HIP(hipGetLastError());

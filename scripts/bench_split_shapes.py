@@ -1,7 +1,7 @@
 """Throughput of the split-lane kernels (one filter over 4 / 8 lanes: kb_vanilla_split.h, kb_squareroot_split.h,
 kb_information_split.h) across the shapes between 7 and 16 states, 262 144 filters, fp64: microseconds per step, filter-steps/s
 and the fraction of 8 TB/s the packed bytes of a step (state in + out, F, H, Q, R, y) amount to.
-usage: python scripts/bench_split_shapes.py [--n=N] [--kind=vanilla,squareroot,information] [--max-n=8] [--full]"""
+usage: python scripts/bench_split_shapes.py [--n=N] [--kind=vanilla,squareroot,information] [--max-n=8] [--full] [--awgn]"""
 import json
 import sys
 
@@ -13,7 +13,7 @@ import gokalman_amd as ga
 from gokalman_amd import _capi as k
 
 N = 1 << 18
-KINDS, MAXN, MINN, FULL = None, 16, 0, False
+KINDS, MAXN, MINN, FULL, AWGN = None, 16, 0, False, False
 for a in sys.argv[1:]:
     if a.startswith("--n="):
         N = int(a[4:])
@@ -21,6 +21,8 @@ for a in sys.argv[1:]:
         KINDS = a[7:].split(",")
     if a == "--full":
         FULL = True
+    if a == "--awgn":
+        AWGN = True
     if a.startswith("--min-n="):
         MINN = int(a[8:])
     if a.startswith("--max-n="):
@@ -40,7 +42,8 @@ for kind, name in ((k.VANILLA, "vanilla"), (k.SQUAREROOT, "squareroot"), (k.INFO
         Q = sc * (1e-3 * np.eye(n)); R = sc * (1e-2 * np.eye(p))
         x0 = np.zeros((N, n)); P0 = np.broadcast_to(np.eye(n), (N, n, n))
         b = ga.FilterBatch.new_ldkf(kind, x0, P0, F, None, H, Q, R,
-                                    flags=(k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0) | (k.FLAG_FULL_ESTIMATE if FULL else 0))
+                                    flags=(k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0) | (k.FLAG_FULL_ESTIMATE if FULL else 0),
+                                    noise=k.NOISE_AWGN if AWGN else k.NOISE_NOISELESS, seed=7)
         del F, Q
         y = torch.randn((p, N), dtype=torch.float64, device="cuda")
         s = torch.cuda.ExternalStream(b.stream())
@@ -57,4 +60,4 @@ for kind, name in ((k.VANILLA, "vanilla"), (k.SQUAREROOT, "squareroot"), (k.INFO
         us = e0.elapsed_time(e1) / K * 1e3
         packed = 8 * (2 * (n + tri(n)) + n * n + p * n + tri(n) + tri(p) + p)
         print(json.dumps({"kind": name, "shape": [n, p], "us": round(us, 1), "filter_steps_per_s": round(N / (us * 1e-6) / 1e9, 3),
-                          "packed_B": packed, "frac_of_8TBps": round(N * packed / (us * 1e-6) / 8e12, 3), "full": FULL, "errors": int(b.status().any())}), flush=True)
+                          "packed_B": packed, "frac_of_8TBps": round(N * packed / (us * 1e-6) / 8e12, 3), "full": FULL, "awgn": AWGN, "errors": int(b.status().any())}), flush=True)

@@ -412,6 +412,38 @@ def test_chisquare_nees_nis_vs_oracle_replay():
         ga.new_chi_square(kf, mc, controls[:2])
 
 
+@pytest.mark.parametrize("n,p,m", [(5, 2, 0), (7, 3, 1), (8, 4, 2), (9, 3, 0), (12, 6, 2), (16, 8, 1), (13, 1, 0)])
+def test_monte_carlo_any_state_dimension_vs_oracle_replay(n, p, m):
+    """NewMonteCarloRuns (montecarlo.go:92-119) is shape-generic: state dimensions without a one-run-per-lane register kernel
+    (mc_kernel: n in {2, 3, 4, 6}) run mc_gen_kernel (model in LDS, any n <= 16, p <= 8, m <= 2).  Every run is replayed through the
+    oracle with the device's draws: Runs[r].Estimates[k].State() / Measurement(), Mean(k), StdDev(k)."""
+    rng = np.random.default_rng(500 + 10 * n + m)
+    F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); G = 0.3 * rng.standard_normal((n, m)) if m else None; H = rng.standard_normal((p, n))
+    A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n)
+    B = 0.2 * rng.standard_normal((p, p)); R = B @ B.T + 1e-2 * np.eye(p)
+    P0, mc_x0 = 1.5 * np.eye(n), rng.standard_normal(n)
+    runs, steps = 70, 9
+    controls = rng.standard_normal((steps, m)) if m else np.zeros((1, 1))
+    truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=21)
+    mc = ga.new_monte_carlo_runs(runs, steps, p, controls, truth)
+    LQ, LR = orc.cholesky_lower(Q)[1], orc.cholesky_lower(R)[1]
+    ts, tm = np.zeros((runs, steps, n)), np.zeros((runs, steps, p))
+    for r in range(runs):
+        f = orc.Filter.ldkf(orc.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R)
+        for t in range(steps):
+            w = LQ @ truth.noise_sample(r, 0, t, 0, n); v = LR @ truth.noise_sample(r, 0, t, 1, p)
+            assert f.update(np.zeros(p), controls[t] if m else None, w_pred=w, v_meas=v) == orc.OK
+            ts[r, t], tm[r, t] = f.state(), f.measurement()
+    assert synth.rel_frobenius(mc._states(), ts) <= 1e-12 and synth.rel_frobenius(mc._measurements(), tm) <= 1e-12
+    for t in range(steps):
+        assert np.allclose(mc.mean(t), ts[:, t].mean(axis=0), rtol=1e-9, atol=1e-12)
+        assert np.allclose(mc.stddev(t), ts[:, t].std(axis=0, ddof=1), rtol=1e-9, atol=1e-12)
+    # statistics only (no Runs kept): the same numbers
+    truth2 = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=21)
+    mc2 = ga.new_monte_carlo_runs(runs, steps, p, controls, truth2, keep_runs=False)
+    assert np.allclose(mc2.mean(steps - 1), mc.mean(steps - 1), rtol=1e-13) and np.allclose(mc2.stddev(steps - 1), mc.stddev(steps - 1), rtol=1e-12)
+
+
 @pytest.mark.parametrize("n,p,m", [(3, 1, 2), (4, 2, 1), (4, 2, 2), (6, 3, 1), (6, 3, 2)])
 def test_chisquare_with_control_inputs_vs_oracle_replay(n, p, m):
     """NewChiSquare with controls (chisquare.go:40-44 hands controls[k] to every Update) on every shape chisq_kernel is
