@@ -317,6 +317,177 @@ __global__ void __launch_bounds__(256, (NS <= 4 ? 2 : 1)) chisq_kernel(const Chi
     }
 }
 
+// Every other shape up to n = 16, p = 8, m = 2 (chisquare.go:16-95 is shape-generic): the same computation with run-time dimensions on
+// lane-private arrays of leading dimension LD (scratch memory: 10-30 KB per lane at LD = 16, as the statement kernels) -- a
+// functional path, two orders of magnitude below the fused register kernels; the consistency test of a 9- or 12-state filter design
+// is a few thousand runs, not the benchmark.  Same draws, same sums, same order of operations as chisq_kernel.
+template <typename T, int LD>
+__global__ void __launch_bounds__(64) chisq_gen_kernel(const ChiArgs a, int n, int p, int nc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    const T *ts = (const T *)a.t_state + tile * ((int64_t)KB_TILE * a.tL.st_elems) + lane;
+    const T *tm = (const T *)a.t_model + tile * ((int64_t)KB_TILE * a.tL.mo_elems) + lane;
+    const T *ks = (const T *)a.k_state + tile * ((int64_t)KB_TILE * a.kL.st_elems) + lane;
+    const T *km = (const T *)a.k_model + tile * ((int64_t)KB_TILE * a.kL.mo_elems) + lane;
+    T xt[LD], x[LD], P[LD * LD];
+    for (int i = 0; i < n; i++) { xt[i] = ldt(ts, a.tL.st_vec + i); x[i] = ldt(ks, a.kL.st_vec + i); }
+    for (int i = 0; i < n; i++)
+        for (int j = i; j < n; j++) { const T v = ldt(ks, a.kL.st_mat + symi(i, j)); P[i * LD + j] = v; P[j * LD + i] = v; }
+    const uint64_t gfi = (uint64_t)(a.first_run + fi);
+    double *my = a.sums + (size_t)(tile % CHI_REPL) * a.nsteps * 2;
+    for (int t = 0; t < a.nsteps; t++) {
+        T u[2] = {T(0), T(0)};
+        if (nc > 0 && a.ncontrols != 1) {
+            const T *up = (const T *)a.controls + (int64_t)t * nc;
+            for (int c = 0; c < nc; c++) u[c] = up[c];
+        }
+        // ---- truth: yhat_k = H x_{k-1} + v_k ; x_k = F x_{k-1} [+ G u_k] + w_k  (vanilla.go:138-157, predictionOnly)
+        T y[LD], xtn[LD];
+        for (int r2 = 0; r2 < p; r2++) {
+            T sacc = T(0), v = T(0);
+            for (int l = 0; l < n; l++) sacc += ldt(tm, a.tL.mo_H + r2 * n + l) * xt[l];
+            for (int k2 = 0; k2 <= r2; k2++) v += ldt(tm, a.tL.mo_LR + symi(k2, r2)) * (T)normal_at(a.seed, gfi, (uint32_t)t, (uint32_t)(a.epoch * 4 + 1), k2);
+            y[r2] = sacc + v;
+        }
+        for (int i = 0; i < n; i++) {
+            T sacc = T(0), w = T(0);
+            for (int l = 0; l < n; l++) sacc += ldt(tm, a.tL.mo_F + i * n + l) * xt[l];
+            if (nc > 0) {
+                T g = T(0);
+                for (int c = 0; c < nc; c++) g += ldt(tm, a.tL.mo_G + i * nc + c) * u[c];
+                sacc = sacc + g;
+            }
+            for (int k2 = 0; k2 <= i; k2++) w += ldt(tm, a.tL.mo_LQ + symi(k2, i)) * (T)normal_at(a.seed, gfi, (uint32_t)t, (uint32_t)(a.epoch * 4 + 0), k2);
+            xtn[i] = sacc + w;
+        }
+        for (int i = 0; i < n; i++) xt[i] = xtn[i];
+        // ---- filter: Vanilla.Update(y, u), Noiseless (vanilla.go:128-220)
+        T xm[LD], FP[LD * LD], Pm[LD * LD];
+        for (int i = 0; i < n; i++) {
+            T sacc = T(0);
+            for (int l = 0; l < n; l++) sacc += ldt(km, a.kL.mo_F + i * n + l) * x[l];
+            if (nc > 0) {
+                T g = T(0);
+                for (int c = 0; c < nc; c++) g += ldt(km, a.kL.mo_G + i * nc + c) * u[c];
+                sacc = sacc + g;
+            }
+            xm[i] = sacc;
+        }
+        for (int i = 0; i < n; i++)
+            for (int k2 = 0; k2 < n; k2++) {
+                T sacc = T(0);
+                for (int l = 0; l < n; l++) sacc += ldt(km, a.kL.mo_F + i * n + l) * P[l * LD + k2];
+                FP[i * LD + k2] = sacc;
+            }
+        for (int i = 0; i < n; i++)
+            for (int j = i; j < n; j++) {
+                T sacc = T(0);
+                for (int k2 = 0; k2 < n; k2++) sacc += FP[i * LD + k2] * ldt(km, a.kL.mo_F + j * n + k2);
+                const T v = sacc + ldt(km, a.kL.mo_Q + symi(i, j));
+                Pm[i * LD + j] = v; Pm[j * LD + i] = v;   // (the upper triangle, mirrored: what chisq_kernel's packed Pm is)
+            }
+        T PHt[LD * 8], S[8 * 8], Si[8 * 8], K[LD * 8];
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < p; c++) {
+                T sacc = T(0);
+                for (int l = 0; l < n; l++) sacc += Pm[i * LD + l] * ldt(km, a.kL.mo_H + c * n + l);
+                PHt[i * 8 + c] = sacc;
+            }
+        for (int r2 = 0; r2 < p; r2++)
+            for (int c = 0; c < p; c++) {
+                T sacc = T(0);
+                for (int i = 0; i < n; i++) sacc += ldt(km, a.kL.mo_H + r2 * n + i) * PHt[i * 8 + c];
+                S[r2 * 8 + c] = sacc + ldt(km, a.kL.mo_R + symi(r2 < c ? r2 : c, r2 < c ? c : r2));
+            }
+        {
+            T Sw[8 * 8];
+            for (int e = 0; e < 64; e++) Sw[e] = S[e];
+            (void)inverse_lu_rt<T, 8>(p, Sw, Si);
+        }
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < p; c++) {
+                T sacc = T(0);
+                for (int k2 = 0; k2 < p; k2++) sacc += PHt[i * 8 + k2] * Si[k2 * 8 + c];
+                K[i * 8 + c] = sacc;
+            }
+        T innov[8];
+        for (int r2 = 0; r2 < p; r2++) {
+            T sacc = T(0);
+            for (int l = 0; l < n; l++) sacc += ldt(km, a.kL.mo_H + r2 * n + l) * xm[l];
+            innov[r2] = y[r2] - sacc;
+        }
+        for (int i = 0; i < n; i++) {
+            T sacc = T(0);
+            for (int c = 0; c < p; c++) sacc += K[i * 8 + c] * innov[c];
+            x[i] = xm[i] + sacc;
+        }
+        // Joseph form: P+ = A P- A^T + K R K^T, A = I - K H (upper triangle, mirrored)
+        T A[LD * LD], AP[LD * LD];
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                T sacc = T(0);
+                for (int c = 0; c < p; c++) sacc += K[i * 8 + c] * ldt(km, a.kL.mo_H + c * n + j);
+                A[i * LD + j] = (i == j ? T(1) : T(0)) - sacc;
+            }
+        for (int i = 0; i < n; i++)
+            for (int k2 = 0; k2 < n; k2++) {
+                T sacc = T(0);
+                for (int l = 0; l < n; l++) sacc += A[i * LD + l] * Pm[l * LD + k2];
+                AP[i * LD + k2] = sacc;
+            }
+        for (int i = 0; i < n; i++) {
+            T kr[8];
+            for (int c = 0; c < p; c++) {
+                T sacc = T(0);
+                for (int k2 = 0; k2 < p; k2++) sacc += K[i * 8 + k2] * ldt(km, a.kL.mo_R + symi(k2 < c ? k2 : c, k2 < c ? c : k2));
+                kr[c] = sacc;
+            }
+            for (int j = i; j < n; j++) {
+                T sacc = T(0), s2 = T(0);
+                for (int k2 = 0; k2 < n; k2++) sacc += AP[i * LD + k2] * A[j * LD + k2];
+                for (int c = 0; c < p; c++) s2 += kr[c] * K[j * 8 + c];
+                const T v = sacc + s2;
+                P[i * LD + j] = v; P[j * LD + i] = v;
+            }
+        }
+        // ---- statistics (chisquare.go:46-77)
+        double nis = 0.0, nees = 0.0;
+        if (a.with_nis) {
+            T sacc = T(0);
+            for (int r2 = 0; r2 < p; r2++) {
+                T v = T(0);
+                for (int c = 0; c < p; c++) v += Si[r2 * 8 + c] * innov[c];
+                sacc += innov[r2] * v;
+            }
+            nis = (double)sacc;
+        }
+        if (a.with_nees) {
+            T Pw[LD * LD], Pi[LD * LD], dlt[LD];
+            for (int i = 0; i < n; i++) {
+                dlt[i] = xt[i] - x[i];
+                for (int j = 0; j < n; j++) Pw[i * LD + j] = P[i * LD + j];
+            }
+            (void)inverse_lu_rt<T, LD>(n, Pw, Pi);
+            T sacc = T(0);
+            for (int i = 0; i < n; i++) {
+                T v = T(0);
+                for (int j = 0; j < n; j++) v += Pi[i * LD + j] * dlt[j];
+                sacc += dlt[i] * v;
+            }
+            nees = (double)sacc;
+        }
+        const double v0 = active ? nis : 0.0, v1 = active ? nees : 0.0;
+        const bool odd = (lane & 1) != 0;
+        double acc = (odd ? v1 : v0) + __shfl_xor(odd ? v0 : v1, 1, 64);
+#pragma unroll
+        for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane < 2) atomicAdd(my + (size_t)t * 2 + lane, acc);
+    }
+}
+
 template <typename T, int NS, int NM>
 static bool chi_try(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
     if (n != NS || p != NM) return false;
@@ -336,8 +507,14 @@ int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
     if (tb.dtype == KB_F64)
         ok = chi_try<double, 2, 1>(tb, a, n, p, nc) || chi_try<double, 3, 1>(tb, a, n, p, nc) || chi_try<double, 4, 2>(tb, a, n, p, nc) ||
              chi_try<double, 6, 3>(tb, a, n, p, nc);
+    if (!ok && tb.dtype == KB_F64 && n <= 16 && p <= 8 && nc <= 2) {   // every other shape: run-time dimensions on lane-private arrays
+        const HeavyScope hs(tb, n > 8);   // LD = 16: scratch-heavy, see kb_internal.h
+        if (n <= 8) hipLaunchKernelGGL((chisq_gen_kernel<double, 8>), dim3((unsigned)a.ntiles), dim3(64), 0, hs.stream, a, n, p, nc);
+        else hipLaunchKernelGGL((chisq_gen_kernel<double, 16>), dim3((unsigned)a.ntiles), dim3(64), 0, hs.stream, a, n, p, nc);
+        ok = true;
+    }
     if (!ok) {
-        set_error("kb_chisquare: no kernel for n=%d p=%d m=%d (built, fp64: (2,1) (3,1) (4,2) (6,3), m <= 2)", n, p, nc);
+        set_error("kb_chisquare: no kernel for n=%d p=%d m=%d (fp64, n <= 16, p <= 8, m <= 2)", n, p, nc);
         return KB_ERR_UNSUPPORTED;
     }
     KB_HIP(hipGetLastError());

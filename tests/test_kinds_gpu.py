@@ -444,17 +444,19 @@ def test_monte_carlo_any_state_dimension_vs_oracle_replay(n, p, m):
     assert np.allclose(mc2.mean(steps - 1), mc.mean(steps - 1), rtol=1e-13) and np.allclose(mc2.stddev(steps - 1), mc.stddev(steps - 1), rtol=1e-12)
 
 
-@pytest.mark.parametrize("n,p,m", [(3, 1, 2), (4, 2, 1), (4, 2, 2), (6, 3, 1), (6, 3, 2)])
+@pytest.mark.parametrize("n,p,m", [(3, 1, 2), (4, 2, 1), (4, 2, 2), (6, 3, 1), (6, 3, 2), (5, 2, 0), (6, 2, 1), (8, 4, 2), (9, 3, 0), (12, 6, 1), (16, 8, 2)])
 def test_chisquare_with_control_inputs_vs_oracle_replay(n, p, m):
     """NewChiSquare with controls (chisquare.go:40-44 hands controls[k] to every Update) on every shape chisq_kernel is
-    instantiated for with a control input: both G (the truth's and the filter's) wait in LDS, as H / chol(Q) / chol(R) of the truth do."""
+    instantiated for with a control input: both G (the truth's and the filter's) wait in LDS, as H / chol(Q) / chol(R) of the truth do.
+    The shapes without a fused register kernel -- everything but (2,1), (3,1), (4,2), (6,3) up to n = 16, p = 8 -- run chisq_gen_kernel
+    (run-time dimensions, the same draws and sums): NewChiSquare is shape-generic in the reference."""
     rng = np.random.default_rng(100 * n + 10 * p + m)
-    F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); G = 0.3 * rng.standard_normal((n, m)); H = rng.standard_normal((p, n))
+    F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); G = 0.3 * rng.standard_normal((n, m)) if m else None; H = rng.standard_normal((p, n))
     A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n)
     B = 0.2 * rng.standard_normal((p, p)); R = B @ B.T + 1e-2 * np.eye(p)
     x0, P0, mc_x0 = np.zeros(n), 1.5 * np.eye(n), 0.2 * rng.standard_normal(n)
     runs, steps = 80, 12
-    controls = rng.standard_normal((steps, m))
+    controls = rng.standard_normal((steps, m)) if m else np.zeros((1, 1))
     truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=9)
     kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, nfilters=runs)
     mc = ga.new_monte_carlo_runs(runs, steps, p, controls, truth)
@@ -465,7 +467,7 @@ def test_chisquare_with_control_inputs_vs_oracle_replay(n, p, m):
         f = orc.Filter.ldkf(orc.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R)
         for t in range(steps):
             w = LQ @ truth.noise_sample(r, 0, t, 0, n); v = LR @ truth.noise_sample(r, 0, t, 1, p)
-            assert f.update(np.zeros(p), controls[t], w_pred=w, v_meas=v) == orc.OK
+            assert f.update(np.zeros(p), controls[t] if m else None, w_pred=w, v_meas=v) == orc.OK
             ts[r, t], tm[r, t] = f.state(), f.measurement()
     assert synth.rel_frobenius(mc._states(), ts) <= 1e-12 and synth.rel_frobenius(mc._measurements(), tm) <= 1e-12
 
@@ -474,7 +476,7 @@ def test_chisquare_with_control_inputs_vs_oracle_replay(n, p, m):
         f._H, f._R = H, R
         return f
 
-    onis, onees = orc.chisquare(factory, ts, tm, controls)
+    onis, onees = orc.chisquare(factory, ts, tm, controls if m else None)
     assert np.allclose(nis, onis, rtol=1e-8) and np.allclose(nees, onees, rtol=1e-8)
 
 
