@@ -45,7 +45,7 @@ __device__ __forceinline__ T reflector(T alpha, T xnorm2, bool more_rows, T &u0,
 
 // GEN: run-time dimensions n <= NS, p <= NM, m <= NC (zero padding); RT (GEN only): FULL and the Noise come from the launch arguments
 // as well -- one instantiation per NS for everything, at one wave per SIMD; RT = false: Noiseless, FULL as given (kb_vanilla_split.h)
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN, bool NOISET = false>
 __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "columns are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, PC = (NM + L - 1) / L, TR = tri(NS), TM = tri(NM), DD = NS + NM;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     typedef __attribute__((address_space(1))) T *gptr;
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
-    const bool awgn = RT && a.noise_kind == KB_NOISE_AWGN;
+    const bool awgn = NOISET || (RT && a.noise_kind == KB_NOISE_AWGN);   // (NOISET: AWGN at compile time, kb_vanilla_split.h)
     const unsigned lane = threadIdx.x;
     const int q = (int)((lane / FPW) & (L - 1)), f = (int)(lane & (FPW - 1));
     const int64_t tile = gw / L;
@@ -516,13 +516,36 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     [[maybe_unused]] T vown[PC];
 #pragma unroll
     for (int r2 = 0; r2 < PC; r2++) vown[r2] = T(0);
-    if constexpr (RT) {
+    if constexpr (RT || NOISET) {
         if (awgn) {   // noise.go:109-164: Process(k) into x+ (which = 2), Measurement(k) into yhat (which = 1, FULL only); the factors are read again
             const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + (unsigned)slot;
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + slot] : 0u);   // kf.step of this filter
+            // the L lanes of a filter share its Box-Muller blocks and gather the vector through LDS (kb_vanilla_split.h draw_coop; the
+            // reflector buffer at BOFF is free by now: 2 n + 2 >= n slots)
+            auto draw_coop = [&](auto NVC, uint32_t which, auto &zv) __attribute__((always_inline)) {
+                constexpr int NV = decltype(NVC)::value, NB = (NV + 1) / 2, IT = (NB + L - 1) / L;
+                wave_lds_fence();
+#pragma unroll
+                for (int it = 0; it < IT; it++) {
+                    const int blk = q + L * it;
+                    uint32_t rr[4];
+                    Philox::gen(a.seed, gfi, stepno, ((uint32_t)(a.epoch * 4 + which) << 8) | (uint32_t)blk, rr);
+                    double z0, z1;
+                    box_muller(rr, z0, z1);
+                    if (L * it + L - 1 < NB || blk < NB) {
+                        lf[(BOFF + 2 * blk) * FPW] = (T)z0;
+                        if (2 * (L * it + L - 1) + 1 < NV || 2 * blk + 1 < NV) lf[(BOFF + 2 * blk + 1) * FPW] = (T)z1;
+                    }
+                    KB_SB();
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int kk = 0; kk < NV; kk++) zv[kk] = lf[(BOFF + kk) * FPW];
+                wave_lds_fence();
+            };
             {
                 T z[NS];
-                draw_normals<T, NS>(a, gfi, stepno, 2u, z);
+                draw_coop(std::integral_constant<int, NS>{}, 2u, z);
 #pragma unroll
                 for (int r = 0; r < RP; r++) {
                     T sacc = T(0);
@@ -537,7 +560,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
             }
             if (full) {
                 T z1[NM];
-                draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+                draw_coop(std::integral_constant<int, NM>{}, 1u, z1);
 #pragma unroll
                 for (int r2 = 0; r2 < PC; r2++) {
                     const int cbase = L * r2;
@@ -610,10 +633,10 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     (void)TM;
 }
 
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN, bool NOISET = false>
 __global__ void __launch_bounds__(64, ((RT || NM > 6) && L == 4) ? 1 : 2) squareroot_split_kernel(const StepArgs a) {
     __shared__ T lds[sqsplit_lds_elems<NS, NM>() * (64 / L)];
-    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT, RT>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);   // (kb_vanilla_split.h: XCD-aware for L = 8)
+    squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT, RT, NOISET>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);   // (kb_vanilla_split.h: XCD-aware for L = 8)
 }
 #undef KB_SB
 

@@ -258,7 +258,7 @@ constexpr int split_lds_total() {
     return (XOFF + (NS * NM > tri(NS) ? NS * NM : 0)) * (64 / L);
 }
 // one wave's part of one tile: filters [64 tile + (gw % L) 64 / L, ... + 64 / L), gw = L tile + part
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN, bool NOISET = false>
 __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "rows are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
@@ -463,20 +463,45 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         }
     }
 
-    // ---- Noise (RT only; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
+    // ---- Noise (RT, or NOISET: AWGN at compile time; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
     // into x+ (:195), k = kf.step of THIS filter.  The normals of a draw are the filter's (kb_vanilla_reg.h draw_normals: Philox keyed
     // by the filter index), formed by each of its L lanes; the lane applies its own rows of chol(Q) (read from the model block: the
     // constructor's factor) to them.
     [[maybe_unused]] T wpost[RP], vmeas[NM];
-    if constexpr (RT) {
+    if constexpr (RT || NOISET) {
 #pragma unroll
         for (int r = 0; r < RP; r++) wpost[r] = T(0);
 #pragma unroll
         for (int c = 0; c < NM; c++) vmeas[c] = T(0);
-        if (a.noise_kind != KB_NOISE_NOISELESS) {
+        if (NOISET || a.noise_kind != KB_NOISE_NOISELESS) {
             const uint64_t gfi = (uint64_t)(a.first_filter + fi);
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[fi] : 0u);   // kf.step of this filter
-            if (a.noise_kind == KB_NOISE_AWGN) {
+            if (NOISET || a.noise_kind == KB_NOISE_AWGN) {
+                // The NV standard normals of a draw are the FILTER's (Philox keyed by the filter index, two per Box-Muller block).  Its L
+                // lanes share the work: lane q forms blocks q, q + L, ... -- the same instructions in every lane, a different counter --
+                // and the vector is gathered through LDS (the first NV slots: F, which sat there, is consumed): a quarter / an eighth of
+                // the logarithms and sines of every lane drawing all of them; the same bits.
+                auto draw_coop = [&](auto NVC, uint32_t which, auto &zv) __attribute__((always_inline)) {
+                    constexpr int NV = decltype(NVC)::value, NB = (NV + 1) / 2, IT = (NB + L - 1) / L;
+                    wave_lds_fence();
+#pragma unroll
+                    for (int it = 0; it < IT; it++) {
+                        const int blk = q + L * it;
+                        uint32_t rr[4];
+                        Philox::gen(a.seed, gfi, stepno, ((uint32_t)(a.epoch * 4 + which) << 8) | (uint32_t)blk, rr);
+                        double z0, z1;
+                        box_muller(rr, z0, z1);
+                        if (L * it + L - 1 < NB || blk < NB) {
+                            lf[(2 * blk) * FPW] = (T)z0;
+                            if (2 * (L * it + L - 1) + 1 < NV || 2 * blk + 1 < NV) lf[(2 * blk + 1) * FPW] = (T)z1;
+                        }
+                        KB_SB();   // one Box-Muller at a time (kb_vanilla_reg.h draw_normals)
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int kk = 0; kk < NV; kk++) zv[kk] = lf[kk * FPW];
+                    wave_lds_fence();
+                };
                 auto own_rows_of_LQ_times = [&](const T (&z)[NS], T (&w)[RP]) {
 #pragma unroll
                     for (int r = 0; r < RP; r++) {
@@ -491,13 +516,13 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                     }
                 };
                 T z[NS], w[RP];
-                draw_normals<T, NS>(a, gfi, stepno, 0u, z);
+                draw_coop(std::integral_constant<int, NS>{}, 0u, z);
                 own_rows_of_LQ_times(z, w);
 #pragma unroll
                 for (int r = 0; r < RP; r++) { xm[r] += w[r]; pin(xm[r]); }
                 KB_SB();
                 if (!predict) {
-                    draw_normals<T, NS>(a, gfi, stepno, 2u, z);
+                    draw_coop(std::integral_constant<int, NS>{}, 2u, z);
                     own_rows_of_LQ_times(z, wpost);
 #pragma unroll
                     for (int r = 0; r < RP; r++) pin(wpost[r]);
@@ -505,7 +530,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 }
                 if (full) {
                     T z1[NM];
-                    draw_normals<T, NM>(a, gfi, stepno, 1u, z1);
+                    draw_coop(std::integral_constant<int, NM>{}, 1u, z1);
 #pragma unroll
                     for (int c = 0; c < NM; c++) {
                         T sacc = T(0);
@@ -516,7 +541,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                     }
                     KB_SB();
                 }
-            } else {   // BatchNoise: the recorded vectors of step k (noise.go:72-86)
+            } else if constexpr (RT) {   // BatchNoise: the recorded vectors of step k (noise.go:72-86)
                 const T *bp = (const T *)a.bn_proc + (int64_t)stepno * rn;
 #pragma unroll
                 for (int r = 0; r < RP; r++) {
@@ -693,7 +718,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int c = 0; c < NM; c++) {
                 T yh = part[NV + c];
-                if constexpr (RT) yh += vmeas[c];   // Measurement(k), vanilla.go:157
+                if constexpr (RT || NOISET) yh += vmeas[c];   // Measurement(k), vanilla.go:157
                 if constexpr (RT || FULLT) {
                     if (q == 0 && active && c < rp) {
                         __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
@@ -771,7 +796,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
             xn[r] = xm[r] + s;
-            if constexpr (RT) xn[r] += wpost[r];   // vanilla.go:195: Process(k) a second time
+            if constexpr (RT || NOISET) xn[r] += wpost[r];   // vanilla.go:195: Process(k) a second time
         }
         // ---- Joseph form (see the header): AP = (I - K H) P- = P- - K (P- H^T)^T for the own rows.  The own rows of P- are read
         // into AP, then P- H^T -- every row of it is needed -- goes to LDS in P-'s place (behind everything else when its n p
@@ -959,17 +984,17 @@ __device__ __forceinline__ int64_t split_part_of_block(unsigned b, unsigned nblo
 
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, bool NOISET = false>
 __global__ void __launch_bounds__(64, (((RT || NM > 6) && L == 4) ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
     __shared__ T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
     if constexpr (PERSIST) {
         const int64_t nparts = a.ntiles * L;
         for (int64_t gw = blockIdx.x; gw < nparts; gw += gridDim.x) {
-            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT>(a, gw, lds);
+            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT, NOISET>(a, gw, lds);
             wave_lds_fence();
         }
     } else {
-        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
+        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT, NOISET>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
     }
 }
 #undef KB_SB

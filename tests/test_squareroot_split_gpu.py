@@ -58,7 +58,8 @@ def test_sqsplit_padded_family_vs_oracle(n, p, m, full):
         assert np.max(np.abs(est.measurement() - np.array([f.measurement() for f in fs]))) <= 1e-8
 
 
-@pytest.mark.parametrize("n,p,m,full", [(12, 6, 0, False), (12, 6, 0, True), (9, 3, 1, True), (11, 8, 2, False), (16, 8, 2, True), (14, 5, 0, False)])
+@pytest.mark.parametrize("n,p,m,full", [(12, 6, 0, False), (12, 6, 0, True), (9, 3, 1, True), (11, 8, 2, False), (16, 8, 2, True), (14, 5, 0, False),
+                                        (8, 4, 0, False), (7, 2, 1, True), (16, 4, 0, False), (10, 4, 2, True), (15, 6, 1, True)])
 def test_sqsplit_awgn_replayed_through_the_oracle(n, p, m, full):
     """AWGN: Measurement(k) into yhat (squareroot.go:239), Process(k) into x+ (:268); the device's draws replayed through the oracle."""
     N, steps = 150, 5

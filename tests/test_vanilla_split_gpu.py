@@ -152,7 +152,8 @@ def test_split_batches_keep_the_other_kernels_bits_for_small_shapes():
 
 
 @pytest.mark.parametrize("n,p,m,full,predict", [(12, 6, 0, False, False), (12, 6, 0, True, False), (9, 2, 1, True, False), (11, 8, 2, False, False),
-                                                (16, 8, 2, True, False), (14, 5, 0, False, False), (13, 3, 1, True, True), (12, 4, 0, False, True)])
+                                                (16, 8, 2, True, False), (14, 5, 0, False, False), (13, 3, 1, True, True), (12, 4, 0, False, True),
+                                                (16, 4, 1, False, False), (10, 4, 0, True, False), (15, 6, 2, True, False), (12, 6, 1, False, False)])
 def test_split_awgn_replayed_through_the_oracle(n, p, m, full, predict):
     """AWGN (noise.go:109-164) on the split kernels: the device's draws (kb_noise_sample: the standard normals of (filter, epoch,
     kf.step, which)) replayed through the oracle in the reference's call order -- Process(k) into x-, Measurement(k) into yhat,
