@@ -3,298 +3,19 @@
 // x and packed P read and rewritten, SNC (PreparePNT, q <= 3) and Predict() as wave-uniform branches.
 // Algorithmic bytes per filter-step: x 6 + P 36 + Phi 36 + Htilde 12 + R 4 + real 2 + computed 2
 // read, x 6 + P 36 written = 1120 B.
-#include "kb_internal.h"
-#include "kb_static.h"
+#include "kb_hybrid_reg.h"
 
 namespace kb {
 
 
-#ifndef HYB_WPB
-#define HYB_WPB 1   // waves per workgroup: a finished wave frees its slot at once (4 per workgroup: 137.7 us, 1: 128.5 us at 1M filters)
-#endif
-// SNCP: the instantiation that also handles SNC (PreparePNT) and Predict(); the plain update stays free of their
-// branches and registers (it is the D(ii) benchmark path).
-template <typename T, int NS, int NM, bool EKF, bool FULL, bool EXT, bool SNCP = false>
-__global__ void __launch_bounds__(64 * HYB_WPB, (SNCP && FULL) ? 1 : 2) hybrid_reg_kernel(const StepArgs a) {
-    constexpr int TR = tri(NS);
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * HYB_WPB + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
-    const bool active = tile * KB_TILE + lane < a.N;
-    T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + TR)) + lane;
-    const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + lane;
-    const T *yr = (const T *)a.y + tile * a.y_ts + lane;
-    const T *yc = (const T *)a.y2 + tile * a.y2_ts + lane;
-    T x[NS], P[TR], F[NS * NS];
-    const int64_t fi = tile * KB_TILE + lane;
-    const T *ephi = EXT ? (const T *)a.ext_phi + (active ? fi : 0) : nullptr;
-    const T *eh = EXT ? (const T *)a.ext_h + (active ? fi : 0) : nullptr;
-    // Request order "slowest first" (kb_vanilla_reg.h): Phi, Htilde, R and the observations are HBM streams, x and P are
-    // Infinity-Cache hits and go last.  (The SNC / Predict instantiation reads Htilde, R and the observations where it needs them.)
-#pragma unroll
-    for (int e = 0; e < NS * NS; e++) F[e] = EXT ? __builtin_nontemporal_load(ephi + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_F + e);
-    T H[NM * NS], R[tri(NM)], real[NM], yv[NM];
-    if constexpr (!SNCP) {
-#pragma unroll
-        for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
-#pragma unroll
-        for (int e = 0; e < tri(NM); e++) R[e] = ldnt(mo, a.L.mo_R + e);
-#pragma unroll
-        for (int r = 0; r < NM; r++) {
-            real[r] = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
-            const T cv = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
-            yv[r] = real[r] - cv;
-        }
-    }
-    auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
-        constexpr bool nt = decltype(NT)::value;
-#pragma unroll
-        for (int i = 0; i < NS; i++) x[i] = ldp<nt>(st, i);
-#pragma unroll
-        for (int e = 0; e < TR; e++) P[e] = ldp<nt>(st, NS + e);
-    };
-    KB_WITH_STATE_POLICY(a, load_state);
-    __builtin_amdgcn_sched_barrier(0);
-    // :114-116 PBar = Phi P Phi^T (upper triangle)
-    T Pm[TR];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        T fp[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += F[i * NS + l] * P[symi(l, k)];
-            fp[k] = s;
-        }
-#pragma unroll
-        for (int j = i; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
-            Pm[symi(i, j)] = s;
-        }
-    }
-    if (SNCP && a.snc) {   // :117-123 PBar += Gamma Q Gamma^T (PreparePNT was called for this step; wave-uniform), q <= 3
-        constexpr int NQ = 3;
-        const int q = a.L.nq;
-        T Gm[NS * NQ], Qs[tri(NQ)], GQ[NS * NQ];
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int c = 0; c < NQ; c++) Gm[i * NQ + c] = (c < q) ? ldnt(mo, a.L.mo_G + i * q + c) : T(0);
-#pragma unroll
-        for (int c = 0; c < NQ; c++)
-#pragma unroll
-            for (int l = 0; l <= c; l++) Qs[symi(l, c)] = (c < q) ? ldnt(mo, a.L.mo_Q + symi(l, c)) : T(0);
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int c = 0; c < NQ; c++) {
-                T s2 = T(0);
-#pragma unroll
-                for (int l = 0; l < NQ; l++) s2 += Gm[i * NQ + l] * Qs[symi(l, c)];
-                GQ[i * NQ + c] = s2;
-            }
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i; j < NS; j++) {
-                T s2 = T(0);
-#pragma unroll
-                for (int c = 0; c < NQ; c++) s2 += GQ[i * NQ + c] * Gm[j * NQ + c];
-                Pm[symi(i, j)] += s2;
-            }
-    }
-    [[maybe_unused]] T xb[NS];
-    if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
-    if (SNCP && a.predict) {   // Predict() (hybrid.go:125-143, wave-uniform): estimate = {xBar (CKF) or the hard-coded zero vector (EKF), PBar}
-        T chk0 = T(0);
-#pragma unroll
-        for (int e = 0; e < TR; e++) chk0 += Pm[e] * T(0);
-        if (chk0 != chk0) { if (active) fail_step(a, tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE); return; }
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                if constexpr (EKF) stt(st, i, T(0)); else stt(st, i, xb[i]);
-            }
-#pragma unroll
-            for (int e = 0; e < TR; e++) stt(st, NS + e, Pm[e]);
-            if constexpr (FULL) {
-                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
-#pragma unroll
-                for (int e = 0; e < TR; e++) stnt(es, a.L.es_ppred + e, Pm[e]);
-#pragma unroll
-                for (int i = 0; i < NS; i++)
-#pragma unroll
-                    for (int c = 0; c < NM; c++) stnt(es, a.L.es_gain + i * a.pmax + c, T(0));
-#pragma unroll
-                for (int r = 0; r < NM; r++) { stnt(es, a.L.es_innov + r, T(0)); stnt(es, a.L.es_yhat + r, T(0)); stnt(es, a.L.es_dobs + r, T(0)); }
-            }
-        }
-        return;
-    }
-    if constexpr (SNCP) {
-#pragma unroll
-        for (int e = 0; e < NM * NS; e++) H[e] = EXT ? __builtin_nontemporal_load(eh + (int64_t)e * a.ext_ld) : ldnt(mo, a.L.mo_H + e);
-#pragma unroll
-        for (int e = 0; e < tri(NM); e++) R[e] = ldnt(mo, a.L.mo_R + e);
-    }
-    // :146-153 K = PBar H^T (H PBar H^T + R)^-1
-    T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int c = 0; c < NM; c++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += Pm[symi(i, l)] * H[c * NS + l];
-            PHt[i * NM + c] = s;
-        }
-#pragma unroll
-    for (int r = 0; r < NM; r++)
-#pragma unroll
-        for (int c = 0; c < NM; c++) {
-            T s = T(0);
-#pragma unroll
-            for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
-            S[r * NM + c] = s + R[symi(r, c)];
-        }
-    unsigned err = inverse_lu<T, NM>(S, Si) ? KB_ST_SINGULAR : 0u;
-    smm_nn<T, NS, NM, NM>(PHt, Si, K);
-    // :156-173
-    T innov[NM], xn[NS];
-#pragma unroll
-    for (int r = 0; r < NM; r++) {
-        if constexpr (SNCP) {
-            real[r] = active ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
-            const T cv = active ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
-            yv[r] = real[r] - cv;
-        }
-        innov[r] = T(0);
-    }
-    if constexpr (EKF) {
-        smv<T, NS, NM>(K, yv, xn);
-    } else {
-#pragma unroll
-        for (int r = 0; r < NM; r++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += H[r * NS + l] * xb[l];
-            innov[r] = yv[r] - s;
-        }
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            T s = T(0);
-#pragma unroll
-            for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
-            xn[i] = xb[i] + s;
-        }
-    }
-    // :174-182 Joseph form (upper): K R K^T + A PBar A^T
-    T Pn[TR];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        T kr[NM];
-#pragma unroll
-        for (int c = 0; c < NM; c++) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
-            kr[c] = s;
-        }
-#pragma unroll
-        for (int j = i; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
-            Pn[symi(i, j)] = s;
-        }
-    }
-    T A[NS * NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
-            A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
-        }
-    T chk = T(0);
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        T ap[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
-            ap[k] = s;
-        }
-#pragma unroll
-        for (int j = i; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
-            Pn[symi(i, j)] = s + Pn[symi(i, j)];
-            chk += Pn[symi(i, j)] * T(0);
-        }
-        chk += xn[i] * T(0);
-    }
-    if (chk != chk) err |= KB_ST_NONFINITE;
-    if (active && !err) {
-        auto store_state = [&](auto NT) {
-            constexpr bool nt = decltype(NT)::value;
-#pragma unroll
-            for (int i = 0; i < NS; i++) stp<nt>(st, i, xn[i]);
-#pragma unroll
-            for (int e = 0; e < TR; e++) stp<nt>(st, NS + e, Pn[e]);
-        };
-        KB_WITH_STATE_POLICY(a, store_state);
-        if constexpr (FULL) {
-            T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
-#pragma unroll
-            for (int e = 0; e < TR; e++) stnt(es, a.L.es_ppred + e, Pm[e]);
-#pragma unroll
-            for (int i = 0; i < NS; i++)
-#pragma unroll
-                for (int c = 0; c < NM; c++) stnt(es, a.L.es_gain + i * a.pmax + c, K[i * NM + c]);
-#pragma unroll
-            for (int r = 0; r < NM; r++) { stnt(es, a.L.es_innov + r, innov[r]); stnt(es, a.L.es_yhat + r, real[r]); stnt(es, a.L.es_dobs + r, yv[r]); }
-        }
-    }
-    if (active && err) fail_step(a, tile * KB_TILE + lane, err);   // hybrid.go:150-152 returns before kf.step++
-}
-
-static bool hybrid_shape_ok(const StepArgs &a, int NS, int NM) {
-    if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
-    return a.n == NS && a.p == NM && (!a.snc || a.L.nq <= 3) && !(a.flags & KB_FLAG_STRICT_SYMCHECK);
-}
-
-template <typename T, int NS, int NM>
-static bool hybrid_try(const Batch &b, const StepArgs &a) {
-    if (!hybrid_shape_ok(a, NS, NM)) return false;
-    const dim3 grid((unsigned)((a.ntiles + HYB_WPB - 1) / HYB_WPB)), block(64 * HYB_WPB);
-    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
-    const bool sncp = a.snc || a.predict;
-#define KB_H(E_, F_) do { if (sncp) { if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true, true>), grid, block, 0, b.stream, a); \
-                                      else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false, true>), grid, block, 0, b.stream, a); } \
-                          else if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true>), grid, block, 0, b.stream, a); \
-                          else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false>), grid, block, 0, b.stream, a); } while (0)
-    if (a.ekf) { if (full) KB_H(true, true); else KB_H(true, false); }
-    else       { if (full) KB_H(false, true); else KB_H(false, false); }
-#undef KB_H
-    return true;
-}
-
 bool hybrid_reg_ok(const Batch &b, const StepArgs &a) {
-    return b.dtype == KB_F64 && (hybrid_shape_ok(a, 6, 2) || hybrid_shape_ok(a, 6, 3) || hybrid_shape_ok(a, 6, 1));
+    return b.dtype == KB_F64 && (hybrid_shape_ok(a, 6, 2) || hybrid_shape_ok(a, 6, 3) || hybrid_shape_ok(a, 6, 1) || hybrid_shape_ok(a, 8, 4, true));
 }
 
 int launch_hybrid(const Batch &b, const StepArgs &a) {
     bool done = false;
-    if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a) || hybrid_try<double, 6, 1>(b, a);
+    if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a) || hybrid_try<double, 6, 1>(b, a) ||
+                                  launch_hybrid_padded(b, a) || launch_hybrid_padded8(b, a);   // kb_hybrid_pad.hip, kb_hybrid_pad8.hip: any n <= 8, p <= 4
     if (!done && (a.flags & KB_FLAG_STRICT_SYMCHECK) && !(a.flags & KB_FLAG_STATEMENT_KERNELS)) done = launch_hybrid_strict(b, a);   // kb_hybrid_strict.hip
     if (!done) return launch_hybrid_gen(b, a);
     KB_HIP(hipGetLastError());

@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vsplit", "vpad", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hstrict", "mc"]
+which = args or ["vsplit", "vpad", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hpad", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -255,6 +255,28 @@ if "hybrid" in which:
     ms = timed(b, step, K=10)
     report("D(ii): Hybrid EKF 6/2 f64 (prepare_dev + update_nl_dev)", N, ms, 1120, {"errors": int(np.count_nonzero(b.status()))}, moved=rl.moved_bytes("hybrid", 6, 2))
     del b
+
+if "hpad" in which:
+    # HybridKF shapes without an exact register kernel on the padded ones (kb_hybrid_reg.h PAD: any n <= 8, p <= 4), EKF, zero-copy Phi / Htilde
+    N = Nopt or (1 << 20)
+    for (n, p) in ((5, 2), (7, 3), (8, 4), (4, 2)):
+        rng = np.random.default_rng(6)
+        x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+        for flags, nm in ((0, "padded register kernel"), (k.FLAG_STATEMENT_KERNELS, "statement kernel")):
+            if flags and "--with-statement" not in sys.argv:
+                continue
+            b = ga.FilterBatch(k.HYBRID, n, p, 0, N, flags=flags)
+            b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, np.diag(np.full(p, 1e-4)), 2, p_rows=p); b.init(); b.enable_ekf()
+            Phi = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=torch.float64, device="cuda")).contiguous()
+            Ht = torch.randn(p * n, N, dtype=torch.float64, device="cuda")
+            real = torch.randn(p, N, dtype=torch.float64, device="cuda"); comp = real + 1e-3 * torch.randn(p, N, dtype=torch.float64, device="cuda")
+            def step():
+                k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
+                k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
+            ms = timed(b, step, K=10 if not flags else 3, warm=3 if not flags else 1)
+            report("Hybrid EKF %d/%d f64, %s (prepare_dev + update_nl_dev)" % (n, p, nm), N, ms, rl.algorithmic_bytes("hybrid", n, p), {"errors": int(np.count_nonzero(b.status()))},
+                   moved=rl.moved_bytes("hybrid", n, p))
+            del b
 
 if "hstrict" in which:
     # Hybrid CKF under KB_FLAG_STRICT_SYMCHECK: kb_hybrid_strict.hip (registers) against hybrid_gen_kernel (KB_FLAG_STATEMENT_KERNELS);

@@ -312,7 +312,60 @@ def test_awgn_moments_and_vanilla_awgn_replay():
                                 noise=k.NOISE_AWGN)
 
 
-@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32)])
+@pytest.mark.parametrize("ekf", [False, True])
+@pytest.mark.parametrize("n,p,q", [(3, 1, 1), (4, 2, 2), (5, 3, 3), (5, 4, 2), (6, 4, 3), (7, 3, 3), (8, 4, 3), (8, 2, 1), (2, 1, 1)])
+def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
+    """HybridKF (hybrid.go:104-204) on the padded register kernels (kb_hybrid_reg.h PAD: any n <= 8, p <= 4 without an exact
+    instantiation): CKF / EKF, SNC on the odd steps, a Predict() in between, every Estimate member -- the checks of
+    test_hybrid_vs_oracle on a well-conditioned R."""
+    TOL = 1e-9
+    rng = np.random.default_rng(100 * n + 10 * p + q)
+    N, steps = 130, 6
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.tile(np.diag(np.full(p, 1e-2)), (N, 1, 1))
+    Aq = rng.standard_normal((N, q, q)); Q = 1e-6 * (np.einsum("nij,nkj->nik", Aq, Aq) + np.eye(q))
+    Gam = rng.standard_normal((steps, N, n, q))
+    Phi, Ht, real, comp = _nl_models(N, n, p, steps, rng)
+    b = ga.FilterBatch(k.HYBRID, n, p, q, N, flags=k.FLAG_FULL_ESTIMATE)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.set(k.Q, Q, 2); b.init()
+    if ekf:
+        b.enable_ekf()
+    for t in range(steps):
+        b.prepare(Phi[t], Ht[t])
+        if t % 2 == 1:
+            b.prepare_pnt(Gam[t])
+        est = b.predict_nl() if t == 3 else b.update_nl(real[t], comp[t])
+    xs, Ps, Pm, Ks = [], [], [], []
+    for i in range(N):
+        f = orc.Filter.hybrid(x0[i], P0[i], Q[i], R[i], p)
+        f.enable_ekf(ekf)
+        for t in range(steps):
+            f.prepare(Phi[t, i], Ht[t, i])
+            if t % 2 == 1:
+                f.prepare_pnt(Gam[t, i])
+            assert (f.predict_nl() if t == 3 else f.update_nl(real[t, i], comp[t, i])) == orc.OK
+        xs.append(f.state()); Ps.append(f.covariance()); Pm.append(f.pred_covariance()); Ks.append(f.gain())
+    assert synth.rel_frobenius(est.state(), np.array(xs)) <= TOL
+    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= TOL
+    assert synth.rel_frobenius(est.pred_covariance(), np.array(Pm)) <= TOL
+    assert synth.rel_frobenius(est.gain(), np.array(Ks)) <= TOL
+    assert not b.status().any() and b.step() == steps
+    # the same shapes on the statement kernel: agreement to rounding (different summation order)
+    s2 = ga.FilterBatch(k.HYBRID, n, p, q, N, flags=k.FLAG_FULL_ESTIMATE | k.FLAG_STATEMENT_KERNELS)
+    s2.set(k.X, x0, 1); s2.set(k.P, P0, 2); s2.set(k.R, R, 2, p_rows=p); s2.set(k.Q, Q, 2); s2.init()
+    if ekf:
+        s2.enable_ekf()
+    for t in range(steps):
+        s2.prepare(Phi[t], Ht[t])
+        if t % 2 == 1:
+            s2.prepare_pnt(Gam[t])
+        e2 = s2.predict_nl() if t == 3 else s2.update_nl(real[t], comp[t])
+    assert synth.rel_frobenius(est.covariance(), e2.covariance()) <= 1e-10
+
+
+@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64),
+                                            (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
     import torch
