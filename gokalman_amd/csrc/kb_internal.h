@@ -193,6 +193,10 @@ bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_str
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip
+bool launch_srif_pair_f32b(const Batch &b, const StepArgs &a);  // kb_srif_pair32b.hip / 64b.hip: 8 / 10 states, p = 2 / 4
+bool launch_srif_pair_f64b(const Batch &b, const StepArgs &a);
+bool launch_srif_pair_f32c(const Batch &b, const StepArgs &a);  // kb_srif_pair32c.hip / 64c.hip: 12 states, p = 2 / 4
+bool launch_srif_pair_f64c(const Batch &b, const StepArgs &a);
 // traj != nullptr: keep every run's State() and Measurement() per step (Batch::d_traj layout)
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, void *traj, int64_t traj_ld);
 int mc_repl();

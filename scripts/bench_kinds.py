@@ -14,7 +14,7 @@ from gokalman_amd import _capi as k, synth
 from gokalman_amd import roofline as rl
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["vsplit", "vpad", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "hybrid", "hpad", "hstrict", "mc"]
+which = args or ["vsplit", "vpad", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "srifpad", "hybrid", "hpad", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
     if a.startswith("--n="):
@@ -238,6 +238,29 @@ if "srif" in which:
         report(nm + " (prepare_dev + update_nl_dev)", N, ms, 576 * w, {"errors": int(np.count_nonzero(b.status()))}, dtype="f32" if dt == k.F32 else "f64",
                moved=rl.moved_bytes("srif_pair", n, p, w))
         del b
+
+if "srifpad" in which:
+    # further SRIF shapes of the two-lanes-per-filter kernel (kb_srif_pair*b.hip, *c.hip), fp64, against the statement kernel
+    N = Nopt or (1 << 18)
+    for (n, p) in ((8, 2), (10, 4), (12, 2)):
+        rng = np.random.default_rng(5)
+        x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+        R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+        for flags, nm in ((0, "two lanes per filter"), (k.FLAG_STATEMENT_KERNELS, "statement kernel")):
+            if flags and "--with-statement" not in sys.argv:
+                continue
+            b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=k.F64, flags=flags)
+            b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+            Phi = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=torch.float64, device="cuda")).contiguous()
+            Ht = torch.randn(p * n, N, dtype=torch.float64, device="cuda")
+            real = torch.randn(p, N, dtype=torch.float64, device="cuda"); comp = real + 1e-2 * torch.randn(p, N, dtype=torch.float64, device="cuda")
+            def step():
+                k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
+                k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
+            ms = timed(b, step, K=10 if not flags else 3, warm=3 if not flags else 1)
+            report("SRIF %d/%d f64, %s (prepare_dev + update_nl_dev)" % (n, p, nm), N, ms, rl.algorithmic_bytes("srif", n, p), {"errors": int(np.count_nonzero(b.status()))},
+                   moved=rl.moved_bytes("srif", n, p))
+            del b
 
 if "hybrid" in which:
     N = Nopt or (1 << 20)
