@@ -125,7 +125,10 @@ struct Panel {
 // triangular, structural zeros skipped at compile time).  The two variants are separate KERNELS (srif_pair_kernel,
 // srif_pair_dense_kernel): inside one kernel the dense variant's 144-register copy of R set the allocation of both (104 B of
 // scratch per lane in the code object although the steady-state path never touched it).
-template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE>
+// PADM: the batch has p = NM - 1 measurements (p = 1 on a two-row, 3 on a four-row, 5 on a six-row instantiation): the missing row is
+// a zero row of Htilde with a zero residual and a unit entry in chol(R) -- its whitened row is zero, the Householder steps add exact
+// zeros for it, so every real entry of the result has the same bits as without the row; loads and Estimate stores skip it.
+template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE, bool PADM = false>
 __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, int half, int lane, T *lds_lu) {
     static_assert(NS % 2 == 0 && NM % 2 == 0, "rows are split by parity");
     constexpr int COLS = NS + 1, HS = NS / 2, HM = NM / 2, SL = HS + HM, ROWE = NS * KB_TILE;
@@ -177,6 +180,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     // ---- every operand is requested up front: ONE exposed memory latency per wave (the partner wave on the SIMD computes
     // meanwhile).  ~230 values in flight; the measurement operands (99) stay in registers until the factors of Phi have gone
     // to LDS, which is what the 256-register budget allows (whitening first would need 39 more accumulators on top).
+    const int rp = PADM ? a.p : NM;
     T Hc[NM * HS], Lw[tri(NM)], yv[NM];   // Htilde, this half's columns: Hc[m * HS + cs] = Htilde[m][2 cs + l]
     [[maybe_unused]] T yreal[NM], yown[HM];
     auto load_meas = [&]() {
@@ -186,16 +190,21 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             for (int m = 0; m < NM; m++)
 #pragma unroll
                 for (int cs = 0; cs < HS; cs++) {
+                    if (PADM && m >= rp) { Hc[m * HS + cs] = T(0); continue; }
                     if constexpr (EXT) { Hc[m * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
                     else Hc[m * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
                 }
         }
 #pragma unroll
-        for (int e = 0; e < tri(NM); e++) Lw[e] = ld_mo(a.L.mo_LR + e);   // QUIRK srif.go:48: chol_L(R), not its inverse
+        for (int c = 0; c < NM; c++)
+#pragma unroll
+            for (int m = 0; m <= c; m++)   // QUIRK srif.go:48: chol_L(R), not its inverse
+                Lw[symi(m, c)] = (PADM && c >= rp) ? (m == c ? T(1) : T(0)) : ld_mo(a.L.mo_LR + symi(m, c));
         {
             UniformCursor<T> cr(yr), cc(yc);
 #pragma unroll
             for (int r = 0; r < NM; r++) {
+                if (PADM && r >= rp) { yv[r] = T(0); if constexpr (FULL) yreal[r] = T(0); continue; }
                 const T re = cr.load_nt(bx), co = cc.load_nt(bx);
                 cr.advance(a.y_es); cc.advance(a.y2_es);
                 yv[r] = re - co;   // srif.go:143-144
@@ -518,6 +527,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         if (ok) {
 #pragma unroll
             for (int t = 0; t < HM; t++) {
+                if (PADM && 2 * t + (is_hi ? 1 : 0) >= rp) continue;   // (the padded row has no slot in the Estimate)
                 __builtin_nontemporal_store(yown[t], es + ((unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl));
                 __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl));
             }
@@ -616,7 +626,10 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     if constexpr (FULL) {
         if (ok) {
 #pragma unroll
-            for (int t = 0; t < HM; t++) __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl));
+            for (int t = 0; t < HM; t++) {
+                if (PADM && 2 * t + (is_hi ? 1 : 0) >= rp) continue;
+                __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl));
+            }
         }
     }
     if constexpr (DENSE) {
@@ -647,7 +660,7 @@ constexpr int srif_pair_waves_per_simd() { return sizeof(T) * NS * NS * 32 * 4 *
 // Steady state: every R of the batch is upper triangular (Batch::srif_tri).  With a.srif_leftover the batch may still hold filters
 // with a dense R (they failed the Update that followed a Predict()); the dense kernel marked their half-tiles in a.srif_dense, and
 // those are left to srif_pair_dense_kernel, which the host launches right behind this kernel for as long as that can be the case.
-template <typename T, int NS, int NM, bool FULL, bool EXT>
+template <typename T, int NS, int NM, bool FULL, bool EXT, bool PADM = false>
 __global__ void __launch_bounds__(64 * KB_PAIR_WPB, ((KB_SRIF_FULL_ONE_WAVE && FULL) ? 1 : srif_pair_waves_per_simd<T, NS>())) srif_pair_kernel(const StepArgs a) {
     __shared__ T lds[KB_PAIR_WPB * NS * NS * 32];
     const int lane = threadIdx.x & 63;
@@ -658,13 +671,13 @@ __global__ void __launch_bounds__(64 * KB_PAIR_WPB, ((KB_SRIF_FULL_ONE_WAVE && F
     const int64_t first = tile * KB_TILE + half * 32;
     if (first >= a.N) return;
     if (a.srif_leftover && a.srif_dense[gw] != 0u) return;   // srif_pair_dense_kernel's (launched right behind this one)
-    srif_pair_tile<T, NS, NM, FULL, EXT, false>(a, tile, half, lane, lds + wv * (NS * NS * 32));
+    srif_pair_tile<T, NS, NM, FULL, EXT, false, PADM>(a, tile, half, lane, lds + wv * (NS * NS * 32));
 }
 
 // The Update right after a Predict() (a.srif_tri == 0: every R is the dense RBar the Predict() kernel stored), or the half-tiles
 // the steady-state kernel skipped (a.srif_tri != 0: only half-tiles marked in a.srif_dense).  One wave per SIMD: the
 // register-resident copy of R needs the 512-register budget.
-template <typename T, int NS, int NM, bool FULL, bool EXT>
+template <typename T, int NS, int NM, bool FULL, bool EXT, bool PADM = false>
 __global__ void __launch_bounds__(64, 1) srif_pair_dense_kernel(const StepArgs a) {
     __shared__ T lds[NS * NS * 32];
     const int lane = threadIdx.x & 63;
@@ -674,20 +687,20 @@ __global__ void __launch_bounds__(64, 1) srif_pair_dense_kernel(const StepArgs a
     const int64_t first = tile * KB_TILE + half * 32;
     if (first >= a.N) return;
     if (a.srif_tri && a.srif_dense[gw] == 0u) return;
-    srif_pair_tile<T, NS, NM, FULL, EXT, true>(a, tile, half, lane, lds);
+    srif_pair_tile<T, NS, NM, FULL, EXT, true, PADM>(a, tile, half, lane, lds);
 }
 
-template <typename T, int NS, int NM>
+template <typename T, int NS, int NM, bool PADM = false>
 static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
-    if (a.n != NS || a.p != NM || a.predict) return false;
+    if (a.n != NS || (PADM ? (a.p != NM && a.p != NM - 1) : a.p != NM) || a.predict) return false;
     if (a.ext_phi && a.ext_ld >= (int64_t(1) << 28)) return false;   // the upper half's Phi offset (+ ld elements) is a 32-bit byte offset
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
     const dim3 grid((unsigned)((2 * a.ntiles + KB_PAIR_WPB - 1) / KB_PAIR_WPB)), block(64 * KB_PAIR_WPB);
     const dim3 dgrid((unsigned)(2 * a.ntiles)), dblock(64);
 #define KB_P(F_, E_)                                                                                                                         \
     do {                                                                                                                                     \
-        if (a.srif_tri) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_>), grid, block, 0, b.stream, a);                             \
-        if (!a.srif_tri || a.srif_leftover) hipLaunchKernelGGL((srif_pair_dense_kernel<T, NS, NM, F_, E_>), dgrid, dblock, 0, b.stream, a); \
+        if (a.srif_tri) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_, PADM>), grid, block, 0, b.stream, a);                             \
+        if (!a.srif_tri || a.srif_leftover) hipLaunchKernelGGL((srif_pair_dense_kernel<T, NS, NM, F_, E_, PADM>), dgrid, dblock, 0, b.stream, a); \
     } while (0)
     if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
     else      { if (ext) KB_P(false, true); else KB_P(false, false); }

@@ -187,7 +187,7 @@ static bool srif_shape_ok(const StepArgs &a, int NS, int NM) { return a.n == NS 
 
 template <typename T, int NS, int NM>
 static bool srif_try_predict(const Batch &b, const StepArgs &a) {
-    if (!srif_shape_ok(a, NS, NM) || !a.predict) return false;
+    if (a.n != NS || !a.predict) return false;   // (the time update does not see the measurement: any p)
     const dim3 grid = tile_grid(a.ntiles), block(256);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
 #define KB_T(F_, E_) hipLaunchKernelGGL((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a)
@@ -201,7 +201,7 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
 bool srif_reg_ok(const Batch &, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
-    return srif_shape_ok(a, 12, 6) || srif_shape_ok(a, 6, 2) || ((a.n == 8 || a.n == 10 || a.n == 12) && (a.p == 2 || a.p == 4));
+    return srif_shape_ok(a, 12, 6) || ((a.n == 6 || a.n == 8 || a.n == 10 || a.n == 12) && a.p >= 1 && a.p <= 4);
 }
 
 int launch_srif(const Batch &b, const StepArgs &a) {
