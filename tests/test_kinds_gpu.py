@@ -365,7 +365,8 @@ def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
 
 
 @pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64),
-                                            (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32)])
+                                            (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32), (k.SRIF, 8, 3, k.F64), (k.SRIF, 12, 1, k.F32), (k.SRIF, 10, 4, k.F64), (k.SRIF, 6, 1, k.F64),
+                                            (k.SRIF, 12, 3, k.F64)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
     import torch
