@@ -189,6 +189,8 @@ int launch_batch_ls(const Batch &b, const StepArgs &a);
 bool hybrid_reg_ok(const Batch &b, const StepArgs &a);
 bool launch_hybrid_padded(const Batch &b, const StepArgs &a);    // kb_hybrid_pad.hip: n <= 4 / p <= 2, n <= 6 / p <= 4
 bool launch_hybrid_padded8(const Batch &b, const StepArgs &a);   // kb_hybrid_pad8.hip: n <= 8 / p <= 4
+bool hybrid_split_ok(const Batch &b, const StepArgs &a);
+bool launch_hybrid_split(const Batch &b, const StepArgs &a);     // kb_hybrid_split.hip: 8 < n <= 16, p <= 6, on the split-lane Vanilla kernel (HYB)
 bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_strict.hip: KB_FLAG_STRICT_SYMCHECK on registers (6 / 1..3, fp64)
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered

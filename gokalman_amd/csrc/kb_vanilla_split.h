@@ -258,7 +258,10 @@ constexpr int split_lds_total() {
     return (XOFF + (NS * NM > tri(NS) ? NS * NM : 0)) * (64 / L);
 }
 // one wave's part of one tile: filters [64 tile + (gw % L) 64 / L, ... + 64 / L), gw = L tile + part
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN, bool NOISET = false>
+// HYB: the HybridKF measurement update (hybrid.go:104-204; CKF or EKF by StepArgs::ekf, no SNC, no Predict()) -- the same algebra on
+// Phi, Htilde, R of the model block (kb_prepare packs them there), no Q, the measurement as (real - computed), xBar = 0 for the EKF;
+// the Estimate's measurement is the real observation and it carries the prefit residual (es_dobs).
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN, bool NOISET = false, bool HYB = false>
 __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "rows are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
@@ -324,7 +327,13 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int l = 0; l < NS; l++) {
                 // (a lane whose row is padding reads lane-group 0's row, which is real whenever rowany[r])
-                const T v = (rowany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, rowok[r] ? uf : um) : T(0);
+                T v;
+                if (HYB && a.ext_phi) {   // zero copy (kb_prepare_dev): element e of filter i of the caller's planar array at ext[e ld + i]
+                    const T *ephi = (const T *)a.ext_phi + (active ? fi : tile * KB_TILE);
+                    v = (rowany[r] && l < rn) ? __builtin_nontemporal_load(ephi + (int64_t)(((rowok[r] ? q : 0) + L * r) * rn + l) * a.ext_ld) : T(0);
+                } else {
+                    v = (rowany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, rowok[r] ? uf : um) : T(0);
+                }
                 Fo[r][l] = rowok[r] ? v : T(0);
             }
         auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
@@ -355,7 +364,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         T s = T(0);
 #pragma unroll
         for (int l = 0; l < NS; l++) s += Fo[r][l] * x[l];
-        xm[r] = s;
+        xm[r] = (HYB && a.ekf) ? T(0) : s;   // (EKF: the state is the deviation from a trajectory that was just rectified, hybrid.go:166-173: x+ = K y)
         pin(xm[r]);
     }
     T Pm[RP][NS];   // [r][j] for j >= L r; the other entries are never touched.  First Q, then P-
@@ -363,6 +372,13 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
     for (int r = 0; r < RP; r++) utri[r] = um + (unsigned)(((q + L * r) * (q + L * r + 1) / 2) * KB_TILE);
     auto request_Q = [&]() {
+        if constexpr (HYB) {   // PBar = Phi P Phi^T: no Q (SNC batches stay on the other kernels)
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int j = 0; j < NS; j++) Pm[r][j] = T(0);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < RP; r++)
     #pragma unroll
@@ -434,7 +450,13 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         for (int c = 0; c < NM; c++)
 #pragma unroll
             for (int r = 0; r < RP; r++) {
-                const T v = (rowany[r] && c < rp) ? ldg(mo, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um) : T(0);
+                T v;
+                if (HYB && a.ext_phi) {
+                    const T *eh = (const T *)a.ext_h + (active ? fi : tile * KB_TILE);
+                    v = (rowany[r] && c < rp) ? __builtin_nontemporal_load(eh + (int64_t)(c * rn + (rowok[r] ? q : 0) + L * r) * a.ext_ld) : T(0);
+                } else {
+                    v = (rowany[r] && c < rp) ? ldg(mo, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um) : T(0);
+                }
                 Hp[c][r] = rowok[r] ? v : T(0);
             }
     };
@@ -616,6 +638,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
         for (int c = 0; c < NM; c++) PHt[r][c] = T(0);
     T R1[TM], y[NM];   // requested here, used behind the P- H^T loop
+    [[maybe_unused]] T yreal[HYB ? NM : 1];
     [[maybe_unused]] T xo[RP];   // x_prev[i_r] (FULL: yhat = H x_prev, vanilla.go:155-157): read a second time, not carried from the top
     auto request_Ry = [&]() {
         if constexpr (RT || FULLT) {
@@ -629,6 +652,14 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         const T *yp = (const T *)a.y + tile * a.y_ts;
 #pragma unroll
         for (int r = 0; r < NM; r++) y[r] = (!predict && active && r < rp) ? ldnt_at(&(yp + (int64_t)r * a.y_es)[us]) : T(0);
+        if constexpr (HYB) {   // y = real - computed observation (hybrid.go:156-158); the real one is the Estimate's Measurement()
+            const T *yc = (const T *)a.y2 + tile * a.y2_ts;
+#pragma unroll
+            for (int r = 0; r < NM; r++) {
+                yreal[r] = y[r];
+                y[r] = y[r] - ((active && r < rp) ? ldnt_at(&(yc + (int64_t)r * a.y2_es)[us]) : T(0));
+            }
+        }
     };
     if (!KB_SPLIT_R1LATE) request_Ry();
     {
@@ -721,8 +752,14 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 if constexpr (RT || NOISET) yh += vmeas[c];   // Measurement(k), vanilla.go:157
                 if constexpr (RT || FULLT) {
                     if (q == 0 && active && c < rp) {
-                        __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
-                        __builtin_nontemporal_store(yh, ep(es, a.L.es_yhat, c) + us);
+                        if constexpr (HYB) {   // {innovation (0 for the EKF: hybrid.go:166-168 never forms it), real observation, prefit residual}
+                            __builtin_nontemporal_store(a.ekf ? T(0) : innov[c], ep(es, a.L.es_innov, c) + us);
+                            __builtin_nontemporal_store(yreal[c], ep(es, a.L.es_yhat, c) + us);
+                            __builtin_nontemporal_store(y[c], ep(es, a.L.es_dobs, c) + us);
+                        } else {
+                            __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
+                            __builtin_nontemporal_store(yh, ep(es, a.L.es_yhat, c) + us);
+                        }
                     }
                 }
             }
@@ -984,17 +1021,17 @@ __device__ __forceinline__ int64_t split_part_of_block(unsigned b, unsigned nblo
 
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, bool NOISET = false>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, bool NOISET = false, bool HYB = false>
 __global__ void __launch_bounds__(64, (((RT || NM > 6) && L == 4) ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
     __shared__ T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
     if constexpr (PERSIST) {
         const int64_t nparts = a.ntiles * L;
         for (int64_t gw = blockIdx.x; gw < nparts; gw += gridDim.x) {
-            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT, NOISET>(a, gw, lds);
+            vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT, NOISET, HYB>(a, gw, lds);
             wave_lds_fence();
         }
     } else {
-        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT, NOISET>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
+        vanilla_split_part<T, NS, NM, NC, L, GEN, FULLT, PREDT, RT, NOISET, HYB>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
     }
 }
 #undef KB_SB

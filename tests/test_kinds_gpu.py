@@ -364,7 +364,51 @@ def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
     assert synth.rel_frobenius(est.covariance(), e2.covariance()) <= 1e-10
 
 
-@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64),
+@pytest.mark.parametrize("ekf", [False, True])
+@pytest.mark.parametrize("n,p,full", [(9, 3, True), (10, 2, False), (12, 6, True), (12, 4, True), (11, 5, False), (14, 5, True), (16, 6, True), (16, 1, True), (13, 4, False)])
+def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
+    """HybridKF (hybrid.go:104-204) beyond 8 states: the measurement update (CKF / EKF, no SNC) on the split-lane kernel
+    (kb_hybrid_split.hip: kb_vanilla_split.h in its HYB mode) against the oracle, every Estimate member with KB_FLAG_FULL_ESTIMATE;
+    a Predict() in between and an SNC step run on the statement kernel of the same batch and must fit in."""
+    TOL = 1e-9
+    rng = np.random.default_rng(1000 + 10 * n + p)
+    N, steps, q = 140, 6, 2
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.tile(np.diag(np.full(p, 1e-2)), (N, 1, 1))
+    Aq = rng.standard_normal((N, q, q)); Q = 1e-6 * (np.einsum("nij,nkj->nik", Aq, Aq) + np.eye(q))
+    Gam = rng.standard_normal((steps, N, n, q))
+    Phi, Ht, real, comp = _nl_models(N, n, p, steps, rng)
+    b = ga.FilterBatch(k.HYBRID, n, p, q, N, flags=k.FLAG_FULL_ESTIMATE if full else 0)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.set(k.Q, Q, 2); b.init()
+    if ekf:
+        b.enable_ekf()
+    fs = [orc.Filter.hybrid(x0[i], P0[i], Q[i], R[i], p) for i in range(N)]
+    for f in fs:
+        f.enable_ekf(ekf)
+    for t in range(steps):
+        b.prepare(Phi[t], Ht[t])
+        snc = t == 4
+        if snc:
+            b.prepare_pnt(Gam[t])
+        est = b.predict_nl() if t == 2 else b.update_nl(real[t], comp[t])
+        for i, f in enumerate(fs):
+            f.prepare(Phi[t, i], Ht[t, i])
+            if snc:
+                f.prepare_pnt(Gam[t, i])
+            assert (f.predict_nl() if t == 2 else f.update_nl(real[t, i], comp[t, i])) == orc.OK
+        if t in (1, 3, 5):
+            assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= TOL, t
+            assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= TOL, t
+    if full:
+        assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in fs])) <= TOL
+        assert synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) <= TOL
+        assert np.max(np.abs(est.innovation() - np.array([f.innovation() for f in fs]))) <= 1e-8
+        assert np.max(np.abs(est.measurement() - np.array([f.measurement() for f in fs]))) <= 1e-12
+    assert not b.status().any() and b.step() == steps
+
+
+@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64), (k.HYBRID, 12, 4, k.F64), (k.HYBRID, 9, 2, k.F64),
                                             (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32), (k.SRIF, 8, 3, k.F64), (k.SRIF, 12, 1, k.F32), (k.SRIF, 10, 4, k.F64), (k.SRIF, 6, 1, k.F64),
                                             (k.SRIF, 12, 3, k.F64)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
