@@ -1,6 +1,6 @@
 // kb_hybrid_split.hip -- HybridKF.fullUpdate (hybrid.go:104-204) beyond 8 states: the split-lane Vanilla kernel (kb_vanilla_split.h,
 // one filter over four / eight lanes) in its HYB mode -- CKF or EKF (StepArgs::ekf), Phi / Htilde from the model block (kb_prepare) or in place from
-// the caller's planar arrays (kb_prepare_dev: zero copy), R from the model block, no process noise compensation, no Predict(), p <= 6,
+// the caller's planar arrays (kb_prepare_dev: zero copy), R from the model block, SNC (PreparePNT, q <= 3), no Predict(), p <= 6,
 // with and without KB_FLAG_FULL_ESTIMATE.  Everything else beyond 8 states stays on hybrid_gen_kernel.
 #include "kb_vanilla_split.h"
 
@@ -14,7 +14,7 @@ static void hyb_go(const Batch &b, const StepArgs &a) {
 }
 
 bool hybrid_split_ok(const Batch &b, const StepArgs &a) {
-    if (b.dtype != KB_F64 || a.n <= 8 || a.n > 16 || a.p > 6 || a.snc || a.predict) return false;
+    if (b.dtype != KB_F64 || a.n <= 8 || a.n > 16 || a.p > 6 || (a.snc && a.L.nq > 3) || a.predict) return false;
     return !(a.flags & (KB_FLAG_STRICT_SYMCHECK | KB_FLAG_STATEMENT_KERNELS));
 }
 

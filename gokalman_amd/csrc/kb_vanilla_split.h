@@ -372,11 +372,50 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
     for (int r = 0; r < RP; r++) utri[r] = um + (unsigned)(((q + L * r) * (q + L * r + 1) / 2) * KB_TILE);
     auto request_Q = [&]() {
-        if constexpr (HYB) {   // PBar = Phi P Phi^T: no Q (SNC batches stay on the other kernels)
+        if constexpr (HYB) {   // PBar = Phi P Phi^T [+ Gamma Q Gamma^T: PreparePNT was called for this step, hybrid.go:117-123; q <= 3]
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int j = 0; j < NS; j++) Pm[r][j] = T(0);
+            if (a.snc) {
+                constexpr int NQ = 3;
+                const int nq = a.L.nq;
+                T Qs[tri(NQ)], GQ[RP][NQ];
+#pragma unroll
+                for (int c = 0; c < NQ; c++)
+#pragma unroll
+                    for (int l = 0; l <= c; l++) Qs[symi(l, c)] = (c < nq) ? ldg(mo, a.L.mo_Q, symi(l, c), um) : T(0);
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    T gam[NQ];   // Gamma[i_r][.]: the own row
+#pragma unroll
+                    for (int l = 0; l < NQ; l++) {
+                        const T v = (rowany[r] && l < nq) ? ldg(mo, a.L.mo_G + L * r * nq, l, rowok[r] ? um + (unsigned)(q * nq * KB_TILE) : um) : T(0);
+                        gam[l] = rowok[r] ? v : T(0);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NQ; c++) {
+                        T sacc = T(0);
+#pragma unroll
+                        for (int l = 0; l < NQ; l++) sacc += gam[l] * Qs[symi(l, c)];
+                        GQ[r][c] = sacc;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    T gj[NQ];   // Gamma[j][.]: the same for the L lanes of the filter
+#pragma unroll
+                    for (int c = 0; c < NQ; c++) gj[c] = (j < rn && c < nq) ? ldg(mo, a.L.mo_G + j * nq, c, um) : T(0);
+#pragma unroll
+                    for (int r = 0; r < RP; r++)
+                        if (L * r <= j) {
+                            T sacc = T(0);
+#pragma unroll
+                            for (int c = 0; c < NQ; c++) sacc += GQ[r][c] * gj[c];
+                            Pm[r][j] = sacc;
+                        }
+                }
+            }
             return;
         }
 #pragma unroll

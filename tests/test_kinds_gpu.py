@@ -369,7 +369,7 @@ def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
 def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
     """HybridKF (hybrid.go:104-204) beyond 8 states: the measurement update (CKF / EKF, no SNC) on the split-lane kernel
     (kb_hybrid_split.hip: kb_vanilla_split.h in its HYB mode) against the oracle, every Estimate member with KB_FLAG_FULL_ESTIMATE;
-    a Predict() in between and an SNC step run on the statement kernel of the same batch and must fit in."""
+    SNC (PreparePNT) on two of the steps; a Predict() in between runs on the statement kernel of the same batch and must fit in."""
     TOL = 1e-9
     rng = np.random.default_rng(1000 + 10 * n + p)
     N, steps, q = 140, 6, 2
@@ -388,7 +388,7 @@ def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
         f.enable_ekf(ekf)
     for t in range(steps):
         b.prepare(Phi[t], Ht[t])
-        snc = t == 4
+        snc = t in (1, 4)
         if snc:
             b.prepare_pnt(Gam[t])
         est = b.predict_nl() if t == 2 else b.update_nl(real[t], comp[t])
