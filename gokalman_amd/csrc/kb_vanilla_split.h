@@ -696,7 +696,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int r = 0; r < NM; r++) {
                 yreal[r] = y[r];
-                y[r] = y[r] - ((active && r < rp) ? ldnt_at(&(yc + (int64_t)r * a.y2_es)[us]) : T(0));
+                y[r] = y[r] - ((!predict && active && r < rp) ? ldnt_at(&(yc + (int64_t)r * a.y2_es)[us]) : T(0));
             }
         }
     };
@@ -791,10 +791,10 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 if constexpr (RT || NOISET) yh += vmeas[c];   // Measurement(k), vanilla.go:157
                 if constexpr (RT || FULLT) {
                     if (q == 0 && active && c < rp) {
-                        if constexpr (HYB) {   // {innovation (0 for the EKF: hybrid.go:166-168 never forms it), real observation, prefit residual}
-                            __builtin_nontemporal_store(a.ekf ? T(0) : innov[c], ep(es, a.L.es_innov, c) + us);
-                            __builtin_nontemporal_store(yreal[c], ep(es, a.L.es_yhat, c) + us);
-                            __builtin_nontemporal_store(y[c], ep(es, a.L.es_dobs, c) + us);
+                        if constexpr (HYB) {   // {innovation (0 for the EKF: hybrid.go:166-168 never forms it), real observation, prefit residual}; Predict(): zeros
+                            __builtin_nontemporal_store((a.ekf || predict) ? T(0) : innov[c], ep(es, a.L.es_innov, c) + us);
+                            __builtin_nontemporal_store(predict ? T(0) : yreal[c], ep(es, a.L.es_yhat, c) + us);
+                            __builtin_nontemporal_store(predict ? T(0) : y[c], ep(es, a.L.es_dobs, c) + us);
                         } else {
                             __builtin_nontemporal_store(innov[c], ep(es, a.L.es_innov, c) + us);
                             __builtin_nontemporal_store(yh, ep(es, a.L.es_yhat, c) + us);
@@ -843,6 +843,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         for (int i = 0; i < NM; i++)
             if (i < rp) inorm = (rows[i] > inorm || rows[i] != rows[i]) ? rows[i] : inorm;
         if (!(anorm * inorm <= T(1e16))) err = KB_ST_SINGULAR;
+        if (HYB && predict) err = 0;   // HybridKF.Predict() (hybrid.go:125-143) forms no gain: whatever S is, it cannot fail the step
     }
     if constexpr (RT || FULLT) {
         if (full && active) {
@@ -850,7 +851,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (rowok[r] && c < rp) __builtin_nontemporal_store(K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
+                    if (rowok[r] && c < rp) __builtin_nontemporal_store((HYB && predict) ? T(0) : K[r][c], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
         }
     }
     KB_SB();

@@ -369,7 +369,7 @@ def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
 def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
     """HybridKF (hybrid.go:104-204) beyond 8 states: the measurement update (CKF / EKF, no SNC) on the split-lane kernel
     (kb_hybrid_split.hip: kb_vanilla_split.h in its HYB mode) against the oracle, every Estimate member with KB_FLAG_FULL_ESTIMATE;
-    SNC (PreparePNT) on two of the steps; a Predict() in between runs on the statement kernel of the same batch and must fit in."""
+    SNC (PreparePNT) on two of the steps and a Predict() in between, all on the same kernels."""
     TOL = 1e-9
     rng = np.random.default_rng(1000 + 10 * n + p)
     N, steps, q = 140, 6, 2
@@ -397,9 +397,15 @@ def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
             if snc:
                 f.prepare_pnt(Gam[t, i])
             assert (f.predict_nl() if t == 2 else f.update_nl(real[t, i], comp[t, i])) == orc.OK
-        if t in (1, 3, 5):
-            assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= TOL, t
+        if t in (1, 2, 3, 5):
             assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= TOL, t
+            if t == 2 and ekf:   # Predict() of an EKF: the hard-coded zero state (hybrid.go:129-131)
+                assert not b.get(k.STATE).any() and not any(f.state().any() for f in fs)
+            else:
+                assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= TOL, t
+            if t == 2 and full:   # the Estimate of a Predict(): {xBar, PBar} and nothing else
+                assert not est.gain().any() and not est.innovation().any() and not est.measurement().any()
+                assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in fs])) <= TOL
     if full:
         assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in fs])) <= TOL
         assert synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) <= TOL
