@@ -303,6 +303,20 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     typedef __attribute__((address_space(1))) T *gptr;
     auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
     auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
+#ifndef KB_SPLIT_LATE_COND   // (A/B: 3-4 % at 9..12 states, 12 % at 12/8; issuing the FIRST burst this way as well costs more than it gains: profiles/NOTES.md)
+    // GEN, the loads BEHIND the first burst (Q, H, R): issued always -- from element 0 of the same field (which every shape has) when the
+    // shape does not have the element (the run-time part of the element index takes the stand-in: scalar-base form kept), the value
+    // masked after -- so that the s_waitcnt counters stay exact there (behind a branch the compiler assumes the worst at the join)
+    auto ldg_if = [&](bool need, const T *ubase, int field, int rt, int c, unsigned off, unsigned off_alt) {   // need: wave-uniform
+        if constexpr (!GEN) return need ? ldg(ubase, rt, c, off) : T(0);
+        else {
+            const T v = __builtin_nontemporal_load(ep(ubase, need ? rt : field - c, c) + (need ? off : off_alt));
+            return need ? v : T(0);
+        }
+    };
+#else
+    auto ldg_if = [&](bool need, const T *ubase, int, int rt, int c, unsigned off, unsigned) { return need ? ldg(ubase, rt, c, off) : T(0); };
+#endif
     auto ldst = [&](auto NT, int rt, int c, unsigned off) {   // state block, cache policy NT (kb_vanilla_reg.h)
         const gptr pe = ep(st, rt, c) + off;
         if constexpr (decltype(NT)::value) return __builtin_nontemporal_load(pe);
@@ -423,11 +437,10 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     #pragma unroll
             for (int j = L * r; j < NS; j++) {
                 // Q[i_r][j]: packed element (i_r, j) = tri(j) + i_r right of the diagonal, (j, i_r) = tri(i_r) + j left of it
-                T v = T(0);
-                if (rowany[r] && j < rn) {
-                    if (j >= L * r + L - 1) v = ldg(mo, a.L.mo_Q, j * (j + 1) / 2 + L * r, rowok[r] ? umq : um);
-                    else v = ldg(mo, a.L.mo_Q, 0, !rowok[r] ? um : (j >= q + L * r ? umq + (unsigned)((j * (j + 1) / 2 + L * r) * KB_TILE) : utri[r] + (unsigned)(j * KB_TILE)));
-                }
+                T v;
+                const bool need = rowany[r] && j < rn;
+                if (j >= L * r + L - 1) v = ldg_if(need, mo, a.L.mo_Q, a.L.mo_Q, j * (j + 1) / 2 + L * r, rowok[r] ? umq : um, um);
+                else v = ldg_if(need, mo, a.L.mo_Q, a.L.mo_Q, 0, !rowok[r] ? um : (j >= q + L * r ? umq + (unsigned)((j * (j + 1) / 2 + L * r) * KB_TILE) : utri[r] + (unsigned)(j * KB_TILE)), um);
                 Pm[r][j] = rowok[r] ? v : T(0);
             }
     };
@@ -494,7 +507,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                     const T *eh = (const T *)a.ext_h + (active ? fi : tile * KB_TILE);
                     v = (rowany[r] && c < rp) ? __builtin_nontemporal_load(eh + (int64_t)(c * rn + (rowok[r] ? q : 0) + L * r) * a.ext_ld) : T(0);
                 } else {
-                    v = (rowany[r] && c < rp) ? ldg(mo, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um) : T(0);
+                    v = ldg_if(rowany[r] && c < rp, mo, a.L.mo_H, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um, um);
                 }
                 Hp[c][r] = rowok[r] ? v : T(0);
             }
