@@ -201,7 +201,7 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
 bool srif_reg_ok(const Batch &, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
-    return srif_shape_ok(a, 12, 6) || ((a.n == 6 || a.n == 8 || a.n == 10 || a.n == 12) && a.p >= 1 && a.p <= 4);
+    return srif_shape_ok(a, 12, 6) || (a.n == 12 && a.p == 5) || ((a.n == 6 || a.n == 8 || a.n == 10 || a.n == 12) && a.p >= 1 && a.p <= 4);
 }
 
 int launch_srif(const Batch &b, const StepArgs &a) {

@@ -96,7 +96,8 @@ def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
                                            (8, 2, k.F64, 1e-9), (8, 4, k.F32, SRIF_F32_TOL), (10, 2, k.F64, 1e-9), (10, 4, k.F64, 1e-9), (10, 2, k.F32, SRIF_F32_TOL),
                                            (12, 2, k.F64, 1e-9), (12, 4, k.F32, SRIF_F32_TOL), (12, 4, k.F64, 1e-9),
                                            (6, 1, k.F64, 1e-9), (6, 3, k.F64, 1e-9), (6, 4, k.F32, SRIF_F32_TOL), (8, 1, k.F32, SRIF_F32_TOL), (8, 3, k.F64, 1e-9), (10, 3, k.F64, 1e-9),
-                                           (10, 1, k.F64, 1e-9), (12, 1, k.F64, 1e-9), (12, 3, k.F32, SRIF_F32_TOL), (12, 3, k.F64, 1e-9)])
+                                           (10, 1, k.F64, 1e-9), (12, 1, k.F64, 1e-9), (12, 3, k.F32, SRIF_F32_TOL), (12, 3, k.F64, 1e-9),
+                                           (12, 5, k.F64, 1e-9), (12, 5, k.F32, SRIF_F32_TOL)])
 def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
     """(5, 2) has no register kernel: the generic one must behave the same; 8 / 10 / 12 states with 2 / 4 measurements run further
     instantiations of the two-lanes-per-filter kernel (kb_srif_pair*b.hip, *c.hip) and of the Predict() kernel; an odd number of measurements runs
