@@ -282,7 +282,7 @@ if "hybrid" in which:
 if "hpad" in which:
     # HybridKF shapes without an exact register kernel on the padded ones (kb_hybrid_reg.h PAD: any n <= 8, p <= 4), EKF, zero-copy Phi / Htilde
     N = Nopt or (1 << 20)
-    for (n, p) in ((5, 2), (7, 3), (8, 4), (4, 2), (9, 2), (12, 4), (16, 6)):   # (beyond 8 states: kb_hybrid_split.hip)
+    for (n, p) in ((5, 2), (7, 3), (8, 4), (4, 2), (9, 2), (12, 4), (16, 6), (12, 8), (16, 8)):   # (beyond 8 states: kb_hybrid_split.hip)
         rng = np.random.default_rng(6)
         x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
         for flags, nm in ((0, "padded register kernel" if n <= 8 else "split-lane kernel"), (k.FLAG_STATEMENT_KERNELS, "statement kernel")):

@@ -365,7 +365,7 @@ def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
 
 
 @pytest.mark.parametrize("ekf", [False, True])
-@pytest.mark.parametrize("n,p,full", [(9, 3, True), (10, 2, False), (12, 6, True), (12, 4, True), (11, 5, False), (14, 5, True), (16, 6, True), (16, 1, True), (13, 4, False)])
+@pytest.mark.parametrize("n,p,full", [(9, 3, True), (10, 2, False), (12, 6, True), (12, 4, True), (11, 5, False), (14, 5, True), (16, 6, True), (16, 1, True), (13, 4, False), (12, 8, True), (10, 7, False), (16, 8, True), (15, 7, False), (9, 8, True)])
 def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
     """HybridKF (hybrid.go:104-204) beyond 8 states: the measurement update (CKF / EKF, no SNC) on the split-lane kernel
     (kb_hybrid_split.hip: kb_vanilla_split.h in its HYB mode) against the oracle, every Estimate member with KB_FLAG_FULL_ESTIMATE;
@@ -414,7 +414,7 @@ def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
     assert not b.status().any() and b.step() == steps
 
 
-@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64), (k.HYBRID, 12, 4, k.F64), (k.HYBRID, 9, 2, k.F64),
+@pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64), (k.HYBRID, 12, 4, k.F64), (k.HYBRID, 9, 2, k.F64), (k.HYBRID, 11, 7, k.F64), (k.HYBRID, 16, 8, k.F64),
                                             (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32), (k.SRIF, 8, 3, k.F64), (k.SRIF, 12, 1, k.F32), (k.SRIF, 10, 4, k.F64), (k.SRIF, 6, 1, k.F64),
                                             (k.SRIF, 12, 3, k.F64), (k.SRIF, 12, 5, k.F64), (k.SRIF, 12, 5, k.F32)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
