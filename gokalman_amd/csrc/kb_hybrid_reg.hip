@@ -16,7 +16,7 @@ int launch_hybrid(const Batch &b, const StepArgs &a) {
     bool done = false;
     if (b.dtype == KB_F64) done = hybrid_try<double, 6, 2>(b, a) || hybrid_try<double, 6, 3>(b, a) || hybrid_try<double, 6, 1>(b, a) ||
                                   launch_hybrid_padded(b, a) || launch_hybrid_padded8(b, a);   // kb_hybrid_pad.hip, kb_hybrid_pad8.hip: any n <= 8, p <= 4
-    if (!done) done = launch_hybrid_split(b, a);   // kb_hybrid_split.hip: 8 < n <= 16, p <= 6 (CKF / EKF update without SNC)
+    if (!done) done = launch_hybrid_split(b, a);   // kb_hybrid_split.hip: everything else up to 16 / 8
     if (!done && (a.flags & KB_FLAG_STRICT_SYMCHECK) && !(a.flags & KB_FLAG_STATEMENT_KERNELS)) done = launch_hybrid_strict(b, a);   // kb_hybrid_strict.hip
     if (!done) return launch_hybrid_gen(b, a);
     KB_HIP(hipGetLastError());

@@ -1,4 +1,4 @@
-// kb_hybrid_split.hip -- HybridKF.fullUpdate (hybrid.go:104-204) beyond 8 states: the split-lane Vanilla kernel (kb_vanilla_split.h,
+// kb_hybrid_split.hip -- HybridKF.fullUpdate (hybrid.go:104-204) beyond 8 states or 4 measurements (what the register kernels do not take): the split-lane Vanilla kernel (kb_vanilla_split.h,
 // one filter over four / eight lanes) in its HYB mode -- CKF or EKF (StepArgs::ekf), Phi / Htilde from the model block (kb_prepare) or in place from
 // the caller's planar arrays (kb_prepare_dev: zero copy), R from the model block, SNC (PreparePNT, q <= 3), Predict(), p <= 6,
 // with and without KB_FLAG_FULL_ESTIMATE; p = 7, 8 in kb_hybrid_split8.hip (the same template).  SNC with q > 3 and the strict symmetry
@@ -24,7 +24,7 @@ static void hyb_go(const Batch &b, const StepArgs &a) {
 }
 
 bool hybrid_split_ok(const Batch &b, const StepArgs &a) {
-    if (b.dtype != KB_F64 || a.n <= 8 || a.n > 16 || a.p > 8 || (a.snc && a.L.nq > 3)) return false;
+    if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || (a.snc && a.L.nq > 3)) return false;
     return !(a.flags & (KB_FLAG_STRICT_SYMCHECK | KB_FLAG_STATEMENT_KERNELS));
 }
 

@@ -365,7 +365,7 @@ def test_hybrid_padded_family_vs_oracle(n, p, q, ekf):
 
 
 @pytest.mark.parametrize("ekf", [False, True])
-@pytest.mark.parametrize("n,p,full", [(9, 3, True), (10, 2, False), (12, 6, True), (12, 4, True), (11, 5, False), (14, 5, True), (16, 6, True), (16, 1, True), (13, 4, False), (12, 8, True), (10, 7, False), (16, 8, True), (15, 7, False), (9, 8, True)])
+@pytest.mark.parametrize("n,p,full", [(9, 3, True), (10, 2, False), (12, 6, True), (12, 4, True), (11, 5, False), (14, 5, True), (16, 6, True), (16, 1, True), (13, 4, False), (12, 8, True), (10, 7, False), (16, 8, True), (15, 7, False), (9, 8, True), (6, 5, True), (8, 8, False), (7, 6, True)])
 def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
     """HybridKF (hybrid.go:104-204) beyond 8 states: the measurement update (CKF / EKF, no SNC) on the split-lane kernel
     (kb_hybrid_split.hip: kb_vanilla_split.h in its HYB mode) against the oracle, every Estimate member with KB_FLAG_FULL_ESTIMATE;
