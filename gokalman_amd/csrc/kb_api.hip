@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include <chrono>
@@ -62,11 +63,41 @@ static Layout make_layout(int kind, int n, int pmax, int m, unsigned flags) {
     return L;
 }
 
+// ---- dev_alloc / dev_free (kb_internal.h) -------------------------------------------------------------
+static bool fence_mode() {
+    static const bool on = [] { const char *e = getenv("KB_DEBUG_FENCE"); return e && *e && *e != '0'; }();
+    return on;
+}
+static std::mutex g_fence_mu;
+static std::unordered_map<void *, void *> g_fence_base;   // handed-out pointer -> hipMalloc'ed base
+
+hipError_t dev_alloc(void **p, size_t bytes) {
+    if (!fence_mode()) return hipMalloc(p, bytes);
+    const size_t G = size_t(2) << 20, rounded = (bytes + G - 1) / G * G;   // (scripts/diag_fence.hip: the first byte behind a 2 MB multiple faults, behind a 4 / 64 KB multiple not)
+    void *base = nullptr;
+    const hipError_t e = hipMalloc(&base, rounded);
+    if (e != hipSuccess) return e;
+    void *q = (char *)base + ((rounded - bytes) & ~size_t(255));
+    std::lock_guard<std::mutex> lk(g_fence_mu);
+    g_fence_base[q] = base;
+    *p = q;
+    return hipSuccess;
+}
+
+hipError_t dev_free(void *p) {
+    if (fence_mode()) {
+        std::lock_guard<std::mutex> lk(g_fence_mu);
+        const auto it = g_fence_base.find(p);
+        if (it != g_fence_base.end()) { p = it->second; g_fence_base.erase(it); }
+    }
+    return hipFree(p);
+}
+
 int ensure_stage(Batch &b, size_t bytes) {
     if (b.stage_bytes >= bytes) return KB_OK;
-    if (b.d_stage) KB_HIP(hipFree(b.d_stage));
+    if (b.d_stage) KB_HIP(dev_free(b.d_stage));
     b.d_stage = nullptr; b.stage_bytes = 0;
-    KB_HIP(hipMalloc(&b.d_stage, bytes));
+    KB_HIP(dev_alloc(&b.d_stage, bytes));
     b.stage_bytes = bytes;
     return KB_OK;
 }
@@ -87,7 +118,7 @@ int ensure_pin(Batch &b) {
 
 int ensure_xp(Batch &b) {
     if (b.d_xp) return KB_OK;
-    KB_HIP(hipMalloc(&b.d_xp, b.block_bytes(b.n + tri(b.n))));
+    KB_HIP(dev_alloc(&b.d_xp, b.block_bytes(b.n + tri(b.n))));
     return KB_OK;
 }
 
@@ -266,7 +297,7 @@ int stage_host_vec(Batch &b, const double *host, int rows, void **dblock, int sl
     if (rc) return rc;
     KB_HIP(hipMemcpyAsync(b.d_stage, host, bytes, hipMemcpyHostToDevice, b.stream));
     if (!*dblock) {
-        KB_HIP(hipMalloc(dblock, b.block_bytes(KB_MAX_DIM)));
+        KB_HIP(dev_alloc(dblock, b.block_bytes(KB_MAX_DIM)));
         KB_HIP(hipMemsetAsync(*dblock, 0, b.block_bytes(KB_MAX_DIM), b.stream));
     }
     int16_t map[KB_MAX_DIM * KB_MAX_DIM];
@@ -319,16 +350,16 @@ int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, i
     if ((rc = use_device(*b))) return fail(rc);
 #define KB_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call)); } while (0)
     KB_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    KB_TRY(hipMalloc(&b->d_state, b->block_bytes(b->L.st_elems)));
-    KB_TRY(hipMalloc(&b->d_state0, b->block_bytes(b->L.st_elems)));
-    KB_TRY(hipMalloc(&b->d_model, b->block_bytes(b->L.mo_elems)));
-    KB_TRY(hipMalloc((void **)&b->d_status, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
+    KB_TRY(dev_alloc(&b->d_state, b->block_bytes(b->L.st_elems)));
+    KB_TRY(dev_alloc(&b->d_state0, b->block_bytes(b->L.st_elems)));
+    KB_TRY(dev_alloc(&b->d_model, b->block_bytes(b->L.mo_elems)));
+    KB_TRY(dev_alloc((void **)&b->d_status, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
     if (b->ntiles == 1) {   // kf.step of a drop-in (one-tile) batch is read by the host without touching the device: pinned, device-mapped
         KB_TRY(hipHostMalloc((void **)&b->h_lag, KB_TILE * sizeof(uint32_t), hipHostMallocMapped));
         memset(b->h_lag, 0, KB_TILE * sizeof(uint32_t));
         KB_TRY(hipHostGetDevicePointer((void **)&b->d_lag, b->h_lag, 0));
     } else {
-        KB_TRY(hipMalloc((void **)&b->d_lag, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
+        KB_TRY(dev_alloc((void **)&b->d_lag, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t)));
         KB_TRY(hipMemsetAsync(b->d_lag, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));
     }
     KB_TRY(hipMemsetAsync(b->d_state, 0, b->block_bytes(b->L.st_elems), b->stream));
@@ -339,11 +370,11 @@ int kb_create(kb_batch **out, int kind, int n, int p, int m, int64_t nfilters, i
         KB_TRY(hipHostMalloc((void **)&b->h_srif_fail, sizeof(uint32_t), hipHostMallocMapped));
         *b->h_srif_fail = 0u;
         KB_TRY(hipHostGetDevicePointer((void **)&b->d_srif_fail, b->h_srif_fail, 0));
-        KB_TRY(hipMalloc((void **)&b->d_srif_dense, (size_t)b->ntiles * 2 * sizeof(uint32_t)));
+        KB_TRY(dev_alloc((void **)&b->d_srif_dense, (size_t)b->ntiles * 2 * sizeof(uint32_t)));
         KB_TRY(hipMemsetAsync(b->d_srif_dense, 0, (size_t)b->ntiles * 2 * sizeof(uint32_t), b->stream));
     }
     if (flags & KB_FLAG_FULL_ESTIMATE) {
-        KB_TRY(hipMalloc(&b->d_est, b->block_bytes(b->L.es_elems)));
+        KB_TRY(dev_alloc(&b->d_est, b->block_bytes(b->L.es_elems)));
         KB_TRY(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
     }
     KB_TRY(hipStreamSynchronize(b->stream));
@@ -360,7 +391,7 @@ void kb_destroy(kb_batch *b) {
                     b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
                     b->h_lag ? nullptr : (void *)b->d_lag, (void *)b->d_srif_dense};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     if (b->h_lag) (void)hipHostFree(b->h_lag);
     if (b->h_srif_fail) (void)hipHostFree(b->h_srif_fail);
     if (b->h_pin) (void)hipHostFree(b->h_pin);
@@ -894,7 +925,7 @@ int kb_is_within_nsigma(kb_batch *b, double nsigma, uint8_t *host, int64_t first
         if ((rc = launch_materialise(*b, b->d_state, false, tmp))) return rc;
         xp = tmp;
     }
-    if (!b->d_flags) KB_HIP(hipMalloc((void **)&b->d_flags, (size_t)b->ntiles * KB_TILE));
+    if (!b->d_flags) KB_HIP(dev_alloc((void **)&b->d_flags, (size_t)b->ntiles * KB_TILE));
     uint8_t *d_out = b->d_flags;
     hipError_t e = hipSuccess;
     rc = launch_within_nsigma(*b, xp, nsigma, d_out);

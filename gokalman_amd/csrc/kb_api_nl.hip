@@ -225,9 +225,9 @@ int kb_set_batch_noise(kb_batch *b, const double *process, int nproc, const doub
     if (rc) return rc;
     const int n = b->n, p = b->p;
     auto upload = [&](const double *src, size_t cnt, void **dst) -> int {
-        if (*dst) KB_HIP(hipFree(*dst));
+        if (*dst) KB_HIP(dev_free(*dst));
         *dst = nullptr;
-        KB_HIP(hipMalloc(dst, cnt * b->esize()));
+        KB_HIP(dev_alloc(dst, cnt * b->esize()));
         if (b->dtype == KB_F64) {
             KB_HIP(hipMemcpy(*dst, src, cnt * sizeof(double), hipMemcpyHostToDevice));
         } else {
@@ -319,9 +319,9 @@ int kb::mc_run_device(Batch &bb, int steps, const double *controls, int ncontrol
         const size_t cnt = (size_t)ncontrols * m;
         const size_t bytes = cnt * b->esize();
         if (b->ctrl_bytes < bytes) {
-            if (b->d_ctrl) KB_HIP(hipFree(b->d_ctrl));
+            if (b->d_ctrl) KB_HIP(dev_free(b->d_ctrl));
             b->d_ctrl = nullptr; b->ctrl_bytes = 0;
-            KB_HIP(hipMalloc(&b->d_ctrl, bytes));
+            KB_HIP(dev_alloc(&b->d_ctrl, bytes));
             b->ctrl_bytes = bytes;
         }
         if (b->dtype == KB_F64) {
@@ -338,9 +338,9 @@ int kb::mc_run_device(Batch &bb, int steps, const double *controls, int ncontrol
     const size_t nrep = (size_t)repl * steps * 2 * n;   // [repl][steps][2][n] | shift [steps][n] | folded [steps][2][n]
     const size_t ndbl = nrep + (size_t)steps * n + (size_t)steps * 2 * n;
     if (b->mc_bytes < ndbl * sizeof(double)) {
-        if (b->d_mc) KB_HIP(hipFree(b->d_mc));
+        if (b->d_mc) KB_HIP(dev_free(b->d_mc));
         b->d_mc = nullptr; b->mc_bytes = 0;
-        KB_HIP(hipMalloc((void **)&b->d_mc, ndbl * sizeof(double)));
+        KB_HIP(dev_alloc((void **)&b->d_mc, ndbl * sizeof(double)));
         b->mc_bytes = ndbl * sizeof(double);
     }
     KB_HIP(hipMemsetAsync(b->d_mc, 0, ndbl * sizeof(double), b->stream));
@@ -357,9 +357,9 @@ int kb::mc_run_device(Batch &bb, int steps, const double *controls, int ncontrol
             return KB_ERR_INVALID;
         }
         if (b->traj_bytes < bytes) {
-            if (b->d_traj) KB_HIP(hipFree(b->d_traj));
+            if (b->d_traj) KB_HIP(dev_free(b->d_traj));
             b->d_traj = nullptr; b->traj_bytes = 0;
-            KB_HIP(hipMalloc(&b->d_traj, bytes));
+            KB_HIP(dev_alloc(&b->d_traj, bytes));
             b->traj_bytes = bytes;
         }
         traj = b->d_traj;
@@ -425,7 +425,7 @@ int kb_replicate(kb_batch *src, int64_t filter, int64_t nfilters, unsigned flags
     d->noise_kind = src->noise_kind; d->seed = src->seed; d->epoch = src->epoch; d->ekf = src->ekf;
     if (src->noise_kind == KB_NOISE_BATCH) {   // BatchNoise: the recorded vectors are shared by every filter of a batch
         const size_t pb = (size_t)src->bn_nproc * src->n * src->esize(), mb = (size_t)src->bn_nmeas * src->bn_p * src->esize();
-        if ((e = hipMalloc(&d->d_bn_proc, pb)) != hipSuccess || (e = hipMalloc(&d->d_bn_meas, mb)) != hipSuccess ||
+        if ((e = dev_alloc(&d->d_bn_proc, pb)) != hipSuccess || (e = dev_alloc(&d->d_bn_meas, mb)) != hipSuccess ||
             (e = hipMemcpyAsync(d->d_bn_proc, src->d_bn_proc, pb, hipMemcpyDeviceToDevice, d->stream)) != hipSuccess ||
             (e = hipMemcpyAsync(d->d_bn_meas, src->d_bn_meas, mb, hipMemcpyDeviceToDevice, d->stream)) != hipSuccess)
             return fail(hip_fail(e, "kb_replicate (BatchNoise)"));

@@ -563,9 +563,9 @@ int kb::chisq_run_device(Batch &tb, Batch &kb_, int steps, const double *control
         if (!controls) { set_error("controls required (needCtrl)"); return KB_ERR_INVALID; }
         const size_t cnt = (size_t)ncontrols * m, bytes = cnt * truth->esize();
         if (truth->ctrl_bytes < bytes) {
-            if (truth->d_ctrl) KB_HIP(hipFree(truth->d_ctrl));
+            if (truth->d_ctrl) KB_HIP(dev_free(truth->d_ctrl));
             truth->d_ctrl = nullptr; truth->ctrl_bytes = 0;
-            KB_HIP(hipMalloc(&truth->d_ctrl, bytes));
+            KB_HIP(dev_alloc(&truth->d_ctrl, bytes));
             truth->ctrl_bytes = bytes;
         }
         KB_HIP(hipMemcpy(truth->d_ctrl, controls, bytes, hipMemcpyHostToDevice));  // fp64 only (see launch_chisq)
@@ -573,9 +573,9 @@ int kb::chisq_run_device(Batch &tb, Batch &kb_, int steps, const double *control
     const int repl = chi_repl();
     const size_t nrep = (size_t)repl * steps * 2, ndbl = nrep + (size_t)steps * 2;   // [repl][steps][2] | folded [steps][2]
     if (truth->mc_bytes < ndbl * sizeof(double)) {
-        if (truth->d_mc) KB_HIP(hipFree(truth->d_mc));
+        if (truth->d_mc) KB_HIP(dev_free(truth->d_mc));
         truth->d_mc = nullptr; truth->mc_bytes = 0;
-        KB_HIP(hipMalloc((void **)&truth->d_mc, ndbl * sizeof(double)));
+        KB_HIP(dev_alloc((void **)&truth->d_mc, ndbl * sizeof(double)));
         truth->mc_bytes = ndbl * sizeof(double);
     }
     KB_HIP(hipStreamSynchronize(kf->stream));

@@ -98,6 +98,11 @@ struct Batch {
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
+// Device memory of a batch.  Plain hipMalloc / hipFree -- unless the environment holds KB_DEBUG_FENCE=1 (tests/test_fence_gpu.py): then every
+// block is rounded up to the 2 MB the driver maps and handed out so that it ENDS where the mapping ends, and a kernel that reads or
+// writes behind its last tile (a padded shape's stand-in element, a tail tile's masked lane) takes a memory fault instead of going unseen.
+hipError_t dev_alloc(void **p, size_t bytes);
+hipError_t dev_free(void *p);
 #define KB_HIP(call)                                                          \
     do {                                                                      \
         hipError_t e__ = (call);                                              \

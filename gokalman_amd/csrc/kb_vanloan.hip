@@ -319,8 +319,8 @@ int kb_van_loan(int device, int dtype, int n, int q, int64_t N, const double *A,
     const size_t in_elems = eA * cA + eG * cG + eW * cW + cdt, out_elems = 2 * eA * (size_t)N;
     double *d = nullptr;
     uint32_t *d_st = nullptr;
-    KB_HIP(hipMalloc(&d, (in_elems + out_elems) * sizeof(double)));
-    if (hipMalloc(&d_st, (size_t)N * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d); set_error("out of device memory"); return KB_ERR_HIP; }
+    KB_HIP(dev_alloc((void **)&d, (in_elems + out_elems) * sizeof(double)));
+    if (dev_alloc((void **)&d_st, (size_t)N * sizeof(uint32_t)) != hipSuccess) { (void)dev_free(d); set_error("out of device memory"); return KB_ERR_HIP; }
     double *dA = d, *dG = dA + eA * cA, *dW = dG + eG * cG, *ddt = dW + eW * cW, *dF = ddt + cdt, *dQ = dF + eA * (size_t)N;
     hipError_t e = hipMemcpy(dA, A, eA * cA * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dG, Gamma, eG * cG * sizeof(double), hipMemcpyHostToDevice);
@@ -337,8 +337,8 @@ int kb_van_loan(int device, int dtype, int n, int q, int64_t N, const double *A,
     if (!rc && e == hipSuccess) e = hipMemcpy(F, dF, eA * (size_t)N * sizeof(double), hipMemcpyDeviceToHost);
     if (!rc && e == hipSuccess) e = hipMemcpy(Q, dQ, eA * (size_t)N * sizeof(double), hipMemcpyDeviceToHost);
     if (!rc && e == hipSuccess && status) e = hipMemcpy(status, d_st, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    (void)hipFree(d_st);
+    (void)dev_free(d);
+    (void)dev_free(d_st);
     if (!rc && e != hipSuccess) rc = hip_fail(e, "kb_van_loan");
     return rc;
 }
