@@ -40,6 +40,7 @@ struct Batch {
     hipStream_t stream = nullptr;
     void *d_state = nullptr, *d_state0 = nullptr;  // current / initial estimate
     void *d_est = nullptr;
+    mutable void *d_sh_state = nullptr, *d_sh_model = nullptr, *d_sh_est = nullptr;   // KB_SRIF with an odd n: the widened shadow blocks (kb_srif_odd.hip)
     void *d_model = nullptr;
     uint32_t *d_status = nullptr;
     // kf.step per filter.  The reference returns from a failed Update BEFORE `kf.step++` (vanilla.go:164-167 / :207-215 against
@@ -198,6 +199,9 @@ bool hybrid_split_ok(const Batch &b, const StepArgs &a);
 bool launch_hybrid_split(const Batch &b, const StepArgs &a);     // kb_hybrid_split.hip: 8 < n <= 16, p <= 6, on the split-lane Vanilla kernel (HYB)
 bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_strict.hip: KB_FLAG_STRICT_SYMCHECK on registers (6 / 1..3, fp64)
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
+bool srif_odd_ok(const Batch &b, const StepArgs &a);      // kb_srif_odd.hip: 5, 7, 9, 11 states on the next even instantiation
+int launch_srif_odd(const Batch &b, const StepArgs &a);
+Layout make_layout(int kind, int n, int pmax, int m, unsigned flags);   // kb_api.hip
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip
 bool launch_srif_pair_f32b(const Batch &b, const StepArgs &a);  // kb_srif_pair32b.hip / 64b.hip: 8 / 10 states, p = 2 / 4
