@@ -72,7 +72,7 @@ static std::mutex g_fence_mu;
 static std::unordered_map<void *, void *> g_fence_base;   // handed-out pointer -> hipMalloc'ed base
 
 hipError_t dev_alloc(void **p, size_t bytes) {
-    if (!fence_mode()) return hipMalloc(p, bytes);
+    if (!fence_mode() || bytes == 0) return hipMalloc(p, bytes);
     const size_t G = size_t(2) << 20, rounded = (bytes + G - 1) / G * G;   // (scripts/diag_fence.hip: the first byte behind a 2 MB multiple faults, behind a 4 / 64 KB multiple not)
     void *base = nullptr;
     const hipError_t e = hipMalloc(&base, rounded);
