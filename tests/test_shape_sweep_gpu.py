@@ -1,0 +1,142 @@
+"""Every shape of the north star's envelope once: n = 1..16 states x p = 1..8 measurements (m = 0, 1, 2 controls and
+KB_FLAG_FULL_ESTIMATE alternating with the shape), Vanilla / SquareRoot / Information / HybridKF / SRIF, a batch that ends inside a tile,
+three steps, against the CPU oracle.  The other GPU tests pick shapes per kernel; this one is about the DISPATCH -- whichever kernel a
+shape lands on (exact, padded, split-lane, widened, statement), the result is the reference's."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from gokalman_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+N, STEPS = 70, 3
+
+
+def _model(n, p, m, seed):
+    rng = np.random.default_rng(seed)
+    F = np.eye(n) + 0.05 * rng.standard_normal((N, n, n))
+    H = rng.standard_normal((N, p, n))
+    A = rng.standard_normal((N, n, n))
+    Q = 1e-3 * np.einsum("nij,nkj->nik", A, A) + 1e-4 * np.eye(n)
+    B = rng.standard_normal((N, p, p))
+    R = 1e-2 * np.einsum("nij,nkj->nik", B, B) + np.exp(rng.uniform(np.log(1e-3), np.log(1e-1), size=(N, p)))[:, :, None] * np.eye(p)
+    G = rng.standard_normal((N, n, m)) if m else None
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = rng.uniform(1.0, 10.0, size=(N, n))
+    y = rng.standard_normal((STEPS, N, p))
+    u = rng.standard_normal((STEPS, N, m)) if m else None
+    return dict(x0=x0, P0=P0, F=F, H=H, Q=Q, R=R, G=G, y=y, u=u)
+
+
+GRID = [(n, p) for n in range(1, 17) for p in range(1, 9)]
+
+
+@pytest.mark.parametrize("kind,okind", [(k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)])
+def test_every_shape_vanilla_squareroot(kind, okind):
+    bad = []
+    for n, p in GRID:
+        m, full = (n + p) % 3, bool((n + p) % 2)
+        d = _model(n, p, m, 100 * n + p)
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE if full else 0)
+        fs = [orc.Filter.ldkf(okind, d["x0"][i], d["P0"][i], d["F"][i], None if m == 0 else d["G"][i], d["H"][i], d["Q"][i], d["R"][i]) for i in range(N)]
+        for t in range(STEPS):
+            est = b.update(d["y"][t], None if m == 0 else d["u"][t])
+            for i, f in enumerate(fs):
+                assert f.update(d["y"][t, i], None if m == 0 else d["u"][t, i]) == orc.OK
+        ex = synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs]))
+        eP = synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs]))
+        eK = synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) if full else 0.0
+        ePm = synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in fs])) if full else 0.0
+        if b.status().any() or b.step() != STEPS or max(ex, eP, eK, ePm) > 1e-9:
+            bad.append((n, p, m, full, ex, eP, eK, ePm))
+    assert not bad, bad
+
+
+def test_every_shape_information():
+    bad = []
+    for n, p in GRID:
+        m = (n + p) % 3
+        d = _model(n, p, m, 300 * n + p)
+        b = ga.FilterBatch.new_ldkf(k.INFORMATION, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=k.FLAG_INFO_FROM_STATE)
+        fs = [orc.Filter.information_from_state(d["x0"][i], d["P0"][i], d["F"][i], None if m == 0 else d["G"][i], d["H"][i], d["Q"][i], d["R"][i]) for i in range(N)]
+        for t in range(STEPS):
+            b.update(d["y"][t], None if m == 0 else d["u"][t], snapshot=False)
+            for i, f in enumerate(fs):
+                assert f.update(d["y"][t, i], None if m == 0 else d["u"][t, i]) == orc.OK
+        ei = synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs]))
+        eI = synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs]))
+        if b.status().any() or b.step() != STEPS or max(ei, eI) > 1e-9:
+            bad.append((n, p, m, ei, eI))
+    assert not bad, bad
+
+
+def _nl(n, p, rng):
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((STEPS, N, n, n))
+    Ht = rng.standard_normal((STEPS, N, p, n))
+    real = rng.standard_normal((STEPS, N, p))
+    comp = real + 1e-2 * rng.standard_normal((STEPS, N, p))
+    return Phi, Ht, real, comp
+
+
+@pytest.mark.parametrize("ekf", [False, True])
+def test_every_shape_hybrid(ekf):
+    bad = []
+    for n, p in GRID:
+        rng = np.random.default_rng(500 * n + p)
+        full = bool((n + p) % 2)
+        x0 = rng.standard_normal((N, n))
+        P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = rng.uniform(1.0, 10.0, size=(N, n))
+        R = np.tile(np.diag(np.full(p, 1e-2)), (N, 1, 1))
+        Phi, Ht, real, comp = _nl(n, p, rng)
+        b = ga.FilterBatch(k.HYBRID, n, p, 0, N, flags=k.FLAG_FULL_ESTIMATE if full else 0)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        if ekf:
+            b.enable_ekf()
+        fs = []
+        for i in range(N):
+            f = orc.Filter.hybrid(x0[i], P0[i], None, R[i], p)
+            if ekf:
+                f.enable_ekf()
+            fs.append(f)
+        for t in range(STEPS):
+            b.prepare(Phi[t], Ht[t])
+            est = b.predict_nl() if t == 1 else b.update_nl(real[t], comp[t])
+            for i, f in enumerate(fs):
+                f.prepare(Phi[t, i], Ht[t, i])
+                assert (f.predict_nl() if t == 1 else f.update_nl(real[t, i], comp[t, i])) == orc.OK
+        ex = synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs]))
+        eP = synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs]))
+        eK = synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) if full else 0.0
+        # (p > n with R = 1e-2 I: the update cancels x- against K (y - H x-) to ~1e-7 of its size; the covariance and the gain stay at 1e-15)
+        if b.status().any() or b.step() != STEPS or max(eP, eK) > 1e-9 or ex > (1e-9 if p <= n else 1e-7):
+            bad.append((n, p, full, ex, eP, eK))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype,tol", [(k.F64, 1e-9), (k.F32, 2e-5)])
+def test_every_shape_srif(dtype, tol):
+    bad = []
+    for n, p in GRID:
+        if p > 6:
+            continue
+        rng = np.random.default_rng(700 * n + p)
+        x0 = rng.standard_normal((N, n))
+        P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+        R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+        Phi, Ht, real, comp = _nl(n, p, rng)
+        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dtype, flags=k.FLAG_FULL_ESTIMATE if (n + p) % 2 else 0)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        fs = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+        for t in range(STEPS):
+            b.prepare(Phi[t], Ht[t])
+            b.predict_nl() if t == 1 else b.update_nl(real[t], comp[t])
+            for i, f in enumerate(fs):
+                f.prepare(Phi[t, i], Ht[t, i])
+                assert (f.predict_nl() if t == 1 else f.update_nl(real[t, i], comp[t, i])) == orc.OK
+        eR = synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs]))
+        eb = synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs]))
+        if b.status().any() or b.step() != STEPS or max(eR, eb) > tol:
+            bad.append((n, p, eR, eb))
+    assert not bad, bad
