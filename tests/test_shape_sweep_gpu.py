@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 N, STEPS = 70, 3
 
 
-def _model(n, p, m, seed):
+def _model(n, p, m, seed, N=N, STEPS=STEPS):
     rng = np.random.default_rng(seed)
     F = np.eye(n) + 0.05 * rng.standard_normal((N, n, n))
     H = rng.standard_normal((N, p, n))
@@ -140,3 +140,19 @@ def test_every_shape_srif(dtype, tol):
         if b.status().any() or b.step() != STEPS or max(eR, eb) > tol:
             bad.append((n, p, eR, eb))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("kind,okind", [(k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)])
+@pytest.mark.parametrize("n,p,ntiles_extra", [(16, 4, 37), (14, 7, 8), (13, 2, 9), (9, 3, 23), (12, 8, 15), (7, 3, 5)])
+def test_many_tiles_odd_counts(kind, okind, n, p, ntiles_extra):
+    """Tile counts that are no multiple of 8 (the eight-lane kernels hand neighbouring parts to workgroups b and b + 8: the map from
+    workgroup to part has to stay a bijection, kb_vanilla_split.h split_part_of_block) and a batch that ends inside a part."""
+    Nb, steps = 64 * ntiles_extra + 11, 2
+    d = _model(n, p, 0, 900 * n + p, N=Nb, STEPS=steps)
+    b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+    for t in range(steps):
+        b.update(d["y"][t], snapshot=False)
+    xo, Po, nerr = orc.ldkf_batch(okind, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+    assert nerr == 0 and not b.status().any() and b.step() == steps
+    assert synth.rel_frobenius(b.get(k.STATE), xo) <= 1e-9
+    assert synth.rel_frobenius(b.get(k.COVAR), Po) <= 1e-9
