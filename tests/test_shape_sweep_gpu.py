@@ -156,3 +156,32 @@ def test_many_tiles_odd_counts(kind, okind, n, p, ntiles_extra):
     assert nerr == 0 and not b.status().any() and b.step() == steps
     assert synth.rel_frobenius(b.get(k.STATE), xo) <= 1e-9
     assert synth.rel_frobenius(b.get(k.COVAR), Po) <= 1e-9
+
+
+@pytest.mark.parametrize("kind", [k.VANILLA, k.SQUAREROOT, k.INFORMATION])
+def test_every_shape_device_measurements_equal_host_measurements(kind):
+    """kb_update_dev (planar device measurements and controls, leading dimension beyond N) == kb_update (host arrays), bit for bit, at
+    every shape: the two entry points differ in where y and u come from, never in the kernel."""
+    import torch
+    bad = []
+    ld = N + 13
+    for n, p in GRID:
+        m = (n + p) % 3
+        d = _model(n, p, m, 1100 * n + p)
+        flags = k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0
+        h = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=flags)
+        g = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=flags)
+        yd = torch.zeros(STEPS, p, ld, dtype=torch.float64, device="cuda")
+        yd[:, :, :N] = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+        ud = None
+        if m:
+            ud = torch.zeros(STEPS, m, ld, dtype=torch.float64, device="cuda")
+            ud[:, :, :N] = torch.from_numpy(np.ascontiguousarray(d["u"].transpose(0, 2, 1))).cuda()
+        for t in range(STEPS):
+            h.update(d["y"][t], None if m == 0 else d["u"][t], snapshot=False)
+            g.update_dev(yd[t].data_ptr(), ld, ud[t].data_ptr() if m else None, ld if m else 0)
+        g.synchronize()
+        same = all(np.array_equal(h.get(f), g.get(f)) for f in ((k.RAW_VEC, k.RAW_MAT) if kind == k.INFORMATION else (k.STATE, k.COVAR)))
+        if not same or g.status().any() or g.step() != STEPS:
+            bad.append((n, p, m))
+    assert not bad, bad
