@@ -185,3 +185,25 @@ def test_every_shape_device_measurements_equal_host_measurements(kind):
         if not same or g.status().any() or g.step() != STEPS:
             bad.append((n, p, m))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("kind", [k.VANILLA, k.SQUAREROOT, k.INFORMATION])
+def test_every_shape_one_model_for_all_filters_equals_per_filter_copies(kind):
+    """A batch whose model fields were all uploaded once (broadcast) == a batch given N copies of that model, bit for bit, at every shape
+    (n <= 8: SHARED instantiations with scalar model loads; beyond: the split kernels read tile 0's block)."""
+    bad = []
+    flags = k.FLAG_INFO_FROM_STATE if kind == k.INFORMATION else 0
+    tile = lambda M: None if M is None else np.broadcast_to(M, (N,) + M.shape).copy()
+    for n, p in GRID:
+        m = (n + p) % 3
+        d = _model(n, p, m, 1300 * n + p)
+        F, G, H, Q, R = d["F"][0], None if m == 0 else d["G"][0], d["H"][0], d["Q"][0], d["R"][0]
+        shared = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], F, G, H, Q, R, nfilters=N, flags=flags)
+        perf = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], tile(F), tile(G), tile(H), tile(Q), tile(R), flags=flags)
+        for t in range(STEPS):
+            shared.update(d["y"][t], None if m == 0 else d["u"][t], snapshot=False)
+            perf.update(d["y"][t], None if m == 0 else d["u"][t], snapshot=False)
+        same = all(np.array_equal(shared.get(f).view(np.uint64), perf.get(f).view(np.uint64)) for f in (k.RAW_VEC, k.RAW_MAT))
+        if not same or shared.status().any() or not np.array_equal(shared.status(), perf.status()):
+            bad.append((n, p, m))
+    assert not bad, bad
