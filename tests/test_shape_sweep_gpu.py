@@ -207,3 +207,33 @@ def test_every_shape_one_model_for_all_filters_equals_per_filter_copies(kind):
         if not same or shared.status().any() or not np.array_equal(shared.status(), perf.status()):
             bad.append((n, p, m))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("kind,okind", [(k.VANILLA, orc.VANILLA), (k.SQUAREROOT, orc.SQUAREROOT)])
+def test_every_shape_awgn_replayed_through_the_oracle(kind, okind):
+    """AWGN (noise.go:109-164) at every shape: the device's draws (kb_noise_sample) replayed through the oracle in the reference's call
+    order (vanilla.go:146,157,195; squareroot.go draws Measurement(k) only into yhat)."""
+    bad = []
+    for n, p in GRID:
+        m, full = (n + p) % 3, bool((n + p) % 2)
+        d = _model(n, p, m, 1700 * n + p)
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], d["G"], d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE if full else 0,
+                                    noise=k.NOISE_AWGN, seed=77)
+        for t in range(STEPS):
+            est = b.update(d["y"][t], d["u"][t] if m else None, snapshot=(t == STEPS - 1))
+        check = list(range(0, N, 9)) + [N - 1]
+        xs, Ps, ys = [], [], []
+        for i in check:
+            LQ, LR = orc.cholesky_lower(d["Q"][i])[1], orc.cholesky_lower(d["R"][i])[1]
+            f = orc.Filter.ldkf(okind, d["x0"][i], d["P0"][i], d["F"][i], d["G"][i] if m else None, d["H"][i], d["Q"][i], d["R"][i])
+            for t in range(STEPS):
+                w0, v, w2 = LQ @ b.noise_sample(i, 0, t, 0, n), LR @ b.noise_sample(i, 0, t, 1, p), LQ @ b.noise_sample(i, 0, t, 2, n)
+                assert f.update(d["y"][t, i], d["u"][t, i] if m else None, w_pred=w0, v_meas=v, w_post=w2) == orc.OK
+            xs.append(f.state()); Ps.append(f.covariance()); ys.append(f.measurement())
+        idx = np.array(check)
+        ex = synth.rel_frobenius(est.state()[idx], np.array(xs))
+        eP = synth.rel_frobenius(est.covariance()[idx], np.array(Ps))
+        ey = synth.rel_frobenius(est.measurement()[idx], np.array(ys)) if full else 0.0
+        if b.status().any() or b.step() != STEPS or max(ex, eP, ey) > 1e-9:
+            bad.append((n, p, m, full, ex, eP, ey))
+    assert not bad, bad
