@@ -237,3 +237,44 @@ def test_every_shape_awgn_replayed_through_the_oracle(kind, okind):
         if b.status().any() or b.step() != STEPS or max(ex, eP, ey) > 1e-9:
             bad.append((n, p, m, full, ex, eP, ey))
     assert not bad, bad
+
+
+def test_every_shape_monte_carlo_and_chisquare_vs_oracle_replay():
+    """NewMonteCarloRuns (montecarlo.go:92-119) and NewChiSquare (chisquare.go:16-95) at every shape: the runs replayed through the
+    oracle with the device's draws, the NIS / NEES means against the oracle's restatement over those runs."""
+    bad = []
+    runs, steps = 70, 4
+    for n, p in GRID:
+        m = (n + p) % 3
+        rng = np.random.default_rng(1900 * n + p)
+        F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); G = 0.3 * rng.standard_normal((n, m)) if m else None; H = rng.standard_normal((p, n))
+        A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n)
+        B = 0.2 * rng.standard_normal((p, p)); R = B @ B.T + 1e-2 * np.eye(p)
+        x0, P0, mc_x0 = np.zeros(n), 1.5 * np.eye(n), 0.2 * rng.standard_normal(n)
+        controls = rng.standard_normal((steps, m)) if m else np.zeros((1, 1))
+        truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R, nfilters=runs, noise=k.NOISE_AWGN, seed=9)
+        kf = ga.FilterBatch.new_ldkf(k.VANILLA, x0, P0, F, G, H, Q, R, nfilters=runs)
+        mc = ga.new_monte_carlo_runs(runs, steps, p, controls, truth)
+        nis, nees = ga.new_chi_square(kf, mc, controls)
+        LQ, LR = orc.cholesky_lower(Q)[1], orc.cholesky_lower(R)[1]
+        ts, tm = np.zeros((runs, steps, n)), np.zeros((runs, steps, p))
+        for r in range(runs):
+            f = orc.Filter.ldkf(orc.VANILLA_PREDICT, mc_x0, P0, F, G, H, Q, R)
+            for t in range(steps):
+                w = LQ @ truth.noise_sample(r, 0, t, 0, n); v = LR @ truth.noise_sample(r, 0, t, 1, p)
+                assert f.update(np.zeros(p), controls[t] if m else None, w_pred=w, v_meas=v) == orc.OK
+                ts[r, t], tm[r, t] = f.state(), f.measurement()
+
+        def factory():
+            f = orc.Filter.ldkf(orc.VANILLA, x0, P0, F, G, H, Q, R)
+            f._H, f._R = H, R
+            return f
+
+        onis, onees = orc.chisquare(factory, ts, tm, controls if m else None)
+        es, em = synth.rel_frobenius(mc._states(), ts), synth.rel_frobenius(mc._measurements(), tm)
+        ok = es <= 1e-12 and em <= 1e-12 and np.allclose(nis, onis, rtol=1e-8) and np.allclose(nees, onees, rtol=1e-8)
+        ok = ok and np.allclose(mc.mean(steps - 1), ts[:, steps - 1].mean(axis=0), rtol=1e-9, atol=1e-12)
+        ok = ok and np.allclose(mc.stddev(steps - 1), ts[:, steps - 1].std(axis=0, ddof=1), rtol=1e-9, atol=1e-12)
+        if not ok:
+            bad.append((n, p, m, es, em))
+    assert not bad, bad
