@@ -203,10 +203,12 @@ static int input_target(Batch &b, int field, int p_rows, FieldTarget &t) {
     const Layout &L = b.L;
     switch (field) {
     case KB_X:
+        b.sh_state_current = false;
         t.block = b.d_state; t.block_elems = L.st_elems; t.src_elems = n;
         map_dense(1, n, L.st_vec, n, t.map);
         return KB_OK;
     case KB_P:
+        b.sh_state_current = false;
         t.block = b.d_state; t.block_elems = L.st_elems; t.src_elems = n * n;
         if (L.st_mat_full) map_dense(n, n, L.st_mat, n, t.map); else map_sym_in(n, L.st_mat, t.map);
         return KB_OK;
@@ -497,6 +499,7 @@ int kb_init(kb_batch *b) {
         if (required && !b->have[f]) { set_error("kb_init: %s has not been set", names[f]); return KB_ERR_INVALID; }
     }
     int not_pd = 0;
+    b->sh_state_current = false;
     if ((rc = launch_init(*b, &not_pd))) return rc;
     if (not_pd) {
         set_error("constructor: matrix is not positive definite (Cholesky failed for %d filter(s))", not_pd);
@@ -513,6 +516,7 @@ int kb_reset(kb_batch *b) {
     if (!b || !b->initialized) { set_error("batch not initialised"); return KB_ERR_INVALID; }
     int rc = use_device(*b);
     if (rc) return rc;
+    b->sh_state_current = false;
     KB_HIP(hipMemcpyAsync(b->d_state, b->d_state0, b->block_bytes(b->L.st_elems), hipMemcpyDeviceToDevice, b->stream));
     if (b->d_est) KB_HIP(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
     KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));

@@ -41,6 +41,7 @@ struct Batch {
     void *d_state = nullptr, *d_state0 = nullptr;  // current / initial estimate
     void *d_est = nullptr;
     mutable void *d_sh_state = nullptr, *d_sh_model = nullptr, *d_sh_est = nullptr;   // KB_SRIF with an odd n: the widened shadow blocks (kb_srif_odd.hip)
+    mutable bool sh_state_current = false;   // ... the shadow state block equals d_state (last writer: an odd-n step; cleared by every other writer of d_state)
     void *d_model = nullptr;
     uint32_t *d_status = nullptr;
     // kf.step per filter.  The reference returns from a failed Update BEFORE `kf.step++` (vanilla.go:164-167 / :207-215 against

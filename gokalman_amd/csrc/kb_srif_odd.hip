@@ -3,9 +3,9 @@
 // filter diag(that filter, one uncoupled state): R' = diag(R, 1), b' = (b, 0), Phi' = diag(Phi, 1), Htilde' = (Htilde, 0).  Phi'^-1 =
 // diag(Phi^-1, 1) (the extra pivot is 1), every Householder step k < n sees a zero in the extra row and column (its norm and its
 // updates add exact zeros), step n reflects the extra row onto itself -- so the leading n x n block of the result IS the n-state
-// filter's, to rounding order.  Per step: one launch copies state and model (the caller's planar Phi / Htilde of kb_prepare_dev are
-// read in place) into the widened shadow blocks, the even kernel steps them, one launch copies the state (and the Estimate extras)
-// back: ~2.5x the bytes of the even kernel, against the statement kernel's scratch arrays two orders of magnitude above it.
+// filter's, to rounding order.  Per step: the state (unless the shadow still holds it from the step before) and the model (the caller's
+// planar Phi / Htilde of kb_prepare_dev are read in place) are copied into the widened shadow blocks, the even kernel steps them, one
+// launch copies the state (and the Estimate extras) back: ~2x the bytes of the even kernel, against the statement kernel's scratch arrays two orders of magnitude above it.
 #include "kb_internal.h"
 
 namespace kb {
@@ -65,16 +65,15 @@ int launch_srif_odd(const Batch &b, const StepArgs &a) {
     const int n = a.n, n2 = n + 1, pm = a.pmax;
     const Layout L2 = make_layout(KB_SRIF, n2, pm, a.m, a.flags);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
-    if (!b.d_sh_state) {
-        KB_HIP(dev_alloc(&b.d_sh_state, b.block_bytes(L2.st_elems)));
-        KB_HIP(dev_alloc(&b.d_sh_model, b.block_bytes(L2.mo_elems)));
-        if (full) KB_HIP(dev_alloc(&b.d_sh_est, b.block_bytes(L2.es_elems)));
-    }
+    if (!b.d_sh_state) KB_HIP(dev_alloc(&b.d_sh_state, b.block_bytes(L2.st_elems)));
+    if (!b.d_sh_model) KB_HIP(dev_alloc(&b.d_sh_model, b.block_bytes(L2.mo_elems)));
+    if (full && !b.d_sh_est) KB_HIP(dev_alloc(&b.d_sh_est, b.block_bytes(L2.es_elems)));
     PadArgs st{};   // state: b, R
     st.src = a.state; st.dst = b.d_sh_state; st.src_elems = a.L.st_elems; st.dst_elems = L2.st_elems; st.ld = 0; st.N = a.N; st.nf = 2;
     st.f[0] = PadField{a.L.st_vec, L2.st_vec, 1, n, 1, n2, 0, nullptr};
     st.f[1] = PadField{a.L.st_mat, L2.st_mat, n, n, n2, n2, 1, nullptr};
-    pad_launch(b, st);
+    if (!b.sh_state_current) pad_launch(b, st);   // (consecutive steps: the shadow still holds what the last step copied back)
+    b.sh_state_current = false;
     PadArgs mo{};   // model: Phi, Htilde (from the model block or the caller's planar arrays), chol(R)
     mo.src = a.model; mo.dst = b.d_sh_model; mo.src_elems = a.L.mo_elems; mo.dst_elems = L2.mo_elems; mo.ld = a.ext_ld; mo.N = a.N; mo.nf = 3;
     mo.f[0] = PadField{a.L.mo_F, L2.mo_F, n, n, n2, n2, 1, a.ext_phi};
@@ -92,6 +91,7 @@ int launch_srif_odd(const Batch &b, const StepArgs &a) {
     back.f[0] = PadField{L2.st_vec, a.L.st_vec, 1, n2, 1, n, 0, nullptr};
     back.f[1] = PadField{L2.st_mat, a.L.st_mat, n2, n2, n, n, 0, nullptr};
     pad_launch(b, back);
+    b.sh_state_current = true;
     if (full) {
         PadArgs es{};
         es.src = b.d_sh_est; es.dst = a.est; es.src_elems = L2.es_elems; es.dst_elems = a.L.es_elems; es.N = a.N; es.nf = 5;

@@ -224,3 +224,41 @@ def test_srif_leftover_dense_tiles_and_a_new_failure_update_every_filter_once(n,
             assert b.filter_step(i) == t + 1 - nfail[i], (t, i)
     st = b.status()
     assert sorted(np.nonzero(st)[0].tolist()) == [7, 40, 130, 150]
+
+
+@pytest.mark.parametrize("n,p,dtype,tol", [(7, 3, k.F64, 1e-9), (11, 4, k.F64, 1e-9), (9, 2, k.F32, SRIF_F32_TOL)])
+def test_srif_odd_states_shadow_follows_every_other_writer_of_the_state(n, p, dtype, tol):
+    """kb_srif_odd.hip keeps the widened copy of the state between consecutive steps; kb_reset and a step that fails for some filters
+    have to show in the step after them, and a second handle has its own copy."""
+    rng = np.random.default_rng(4242 + n)
+    N, steps = 100, 3
+    x0 = rng.standard_normal((N, n)); x1 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = rng.uniform(1.0, 10.0, size=(N, n))
+    P1 = np.zeros((N, n, n)); P1[:, np.arange(n), np.arange(n)] = rng.uniform(0.5, 2.0, size=(N, n))
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((3 * steps, N, n, n))
+    Ht = rng.standard_normal((3 * steps, N, p, n))
+    real = rng.standard_normal((3 * steps, N, p)); comp = real + 1e-2 * rng.standard_normal((3 * steps, N, p))
+    Phi[1, 5, 2, :] = 0.0   # one filter skips step 1 (singular Phi): its state stays, in the shadow as well
+    b = _srif_batch(N, n, p, dtype, x0, P0, R)
+
+    def run(t0, xs, Ps):
+        fs = [orc.Filter.srif(xs[i], Ps[i], R[i], p) for i in range(N)]
+        for t in range(t0, t0 + steps):
+            b.prepare(Phi[t], Ht[t])
+            b.predict_nl() if t % steps == 2 else b.update_nl(real[t], comp[t])
+            for i, f in enumerate(fs):
+                f.prepare(Phi[t, i], Ht[t, i])
+                f.predict_nl() if t % steps == 2 else f.update_nl(real[t, i], comp[t, i])
+        assert synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs])) <= tol
+        assert synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs])) <= tol
+
+    run(0, x0, P0)
+    assert b.status()[5] == k.ST_SINGULAR
+    b.reset()
+    run(steps, x0, P0)                 # Reset(): back to the constructor's estimate
+    with pytest.raises(ga.KalmanError, match="constructor arguments"):   # (x0 / P0 cannot change after kb_init: no third writer)
+        b.set(k.X, x1, 1)
+    b2 = _srif_batch(N, n, p, dtype, x1, P1, R)   # a second handle has its own shadow
+    b, keep = b2, b
+    run(2 * steps, x1, P1)
