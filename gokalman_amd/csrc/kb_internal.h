@@ -200,7 +200,7 @@ bool hybrid_split_ok(const Batch &b, const StepArgs &a);
 bool launch_hybrid_split(const Batch &b, const StepArgs &a);     // kb_hybrid_split.hip: 8 < n <= 16, p <= 6, on the split-lane Vanilla kernel (HYB)
 bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_strict.hip: KB_FLAG_STRICT_SYMCHECK on registers (6 / 1..3, fp64)
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
-bool srif_odd_ok(const Batch &b, const StepArgs &a);      // kb_srif_odd.hip: 5, 7, 9, 11 states on the next even instantiation
+bool srif_odd_ok(const Batch &b, const StepArgs &a);      // kb_srif_odd.hip: 1..5, 7, 9, 11 states on the next instantiation (6, 8, 10, 12)
 int launch_srif_odd(const Batch &b, const StepArgs &a);
 Layout make_layout(int kind, int n, int pmax, int m, unsigned flags);   // kb_api.hip
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered

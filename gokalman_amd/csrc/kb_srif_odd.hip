@@ -1,6 +1,6 @@
-// kb_srif_odd.hip -- SRIF (srif.go:101-160, :298-340) with an ODD number of states (5, 7, 9, 11).  The two-lanes-per-filter kernel
-// (kb_srif_pair.h) splits rows and columns by parity and is built for even n; an odd filter runs on the next even instantiation as the
-// filter diag(that filter, one uncoupled state): R' = diag(R, 1), b' = (b, 0), Phi' = diag(Phi, 1), Htilde' = (Htilde, 0).  Phi'^-1 =
+// kb_srif_odd.hip -- SRIF (srif.go:101-160, :298-340) with an ODD number of states (7, 9, 11) or fewer than six.  The two-lanes-per-filter
+// kernel (kb_srif_pair.h) splits rows and columns by parity and is built for n = 6, 8, 10, 12; any other filter up to 11 states runs on the
+// next instantiation as the filter diag(that filter, uncoupled states) -- with ONE extra state: R' = diag(R, 1), b' = (b, 0), Phi' = diag(Phi, 1), Htilde' = (Htilde, 0).  Phi'^-1 =
 // diag(Phi^-1, 1) (the extra pivot is 1), every Householder step k < n sees a zero in the extra row and column (its norm and its
 // updates add exact zeros), step n reflects the extra row onto itself -- so the leading n x n block of the result IS the n-state
 // filter's, to rounding order.  Per step: the state (unless the shadow still holds it from the step before) and the model (the caller's
@@ -54,15 +54,18 @@ void pad_launch(const Batch &b, const PadArgs &pa) {
 
 }  // namespace
 
+// the instantiated size an n-state filter runs on: 6 below six states, the next even number for 7, 9, 11; 0: none (n is instantiated itself, or beyond 12)
+static int srif_widened(int n) { return n < 6 ? 6 : ((n & 1) && n < 12 ? n + 1 : 0); }
+
 bool srif_odd_ok(const Batch &b, const StepArgs &a) {
-    if (!(a.n & 1) || a.n < 5 || a.n > 11 || (a.flags & KB_FLAG_STATEMENT_KERNELS)) return false;
+    if (!srif_widened(a.n) || (a.flags & KB_FLAG_STATEMENT_KERNELS)) return false;
     StepArgs a2 = a;
-    a2.n = a.n + 1; a2.ext_phi = a2.ext_h = nullptr; a2.ext_ld = 0;
+    a2.n = srif_widened(a.n); a2.ext_phi = a2.ext_h = nullptr; a2.ext_ld = 0;
     return srif_reg_ok(b, a2);
 }
 
 int launch_srif_odd(const Batch &b, const StepArgs &a) {
-    const int n = a.n, n2 = n + 1, pm = a.pmax;
+    const int n = a.n, n2 = srif_widened(n), pm = a.pmax;
     const Layout L2 = make_layout(KB_SRIF, n2, pm, a.m, a.flags);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     if (!b.d_sh_state) KB_HIP(dev_alloc(&b.d_sh_state, b.block_bytes(L2.st_elems)));
