@@ -417,7 +417,7 @@ def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
 
 @pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64), (k.HYBRID, 12, 4, k.F64), (k.HYBRID, 9, 2, k.F64), (k.HYBRID, 11, 7, k.F64), (k.HYBRID, 16, 8, k.F64),
                                             (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32), (k.SRIF, 8, 3, k.F64), (k.SRIF, 12, 1, k.F32), (k.SRIF, 10, 4, k.F64), (k.SRIF, 6, 1, k.F64),
-                                            (k.SRIF, 12, 3, k.F64), (k.SRIF, 12, 5, k.F64), (k.SRIF, 12, 5, k.F32), (k.SRIF, 7, 3, k.F64), (k.SRIF, 11, 4, k.F32), (k.SRIF, 9, 1, k.F64)])
+                                            (k.SRIF, 12, 3, k.F64), (k.SRIF, 12, 5, k.F64), (k.SRIF, 12, 5, k.F32), (k.SRIF, 7, 3, k.F64), (k.SRIF, 11, 4, k.F32), (k.SRIF, 9, 1, k.F64), (k.SRIF, 8, 6, k.F64), (k.SRIF, 10, 5, k.F32), (k.SRIF, 4, 2, k.F64)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
     import torch
