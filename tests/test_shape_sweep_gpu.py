@@ -119,8 +119,6 @@ def test_every_shape_hybrid(ekf):
 def test_every_shape_srif(dtype, tol):
     bad = []
     for n, p in GRID:
-        if p > 6:
-            continue
         rng = np.random.default_rng(700 * n + p)
         x0 = rng.standard_normal((N, n))
         P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
