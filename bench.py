@@ -241,6 +241,7 @@ def _leg_parity(ga, k, synth, leg):
         Ht = torch.randn(p * n, N, dtype=tdt, device="cuda", generator=g)
         real = torch.randn(p, N, dtype=tdt, device="cuda", generator=g)
         comp = (real + (1e-2 if fp32 else 1e-3) * torch.randn(p, N, dtype=tdt, device="cuda", generator=g)).contiguous()
+        torch.cuda.synchronize()   # the handle's stream does not wait for torch's: the arrays must be complete when they are handed over
         k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
         k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
         b.synchronize()
@@ -570,6 +571,7 @@ def main():
         Ht = torch.randn(hp * hn, M, dtype=torch.float64, device=dev, generator=g)
         real = torch.randn(hp, M, dtype=torch.float64, device=dev, generator=g)
         comp = real + 1e-3 * torch.randn(hp, M, dtype=torch.float64, device=dev, generator=g)
+        torch.cuda.synchronize()   # (the handle's stream does not wait for torch's)
         hs = torch.cuda.ExternalStream(hb.stream(), device=dev)
 
         def hstep():
@@ -721,6 +723,7 @@ def main():
         Ht = torch.randn(sp * sn, M, dtype=torch.float32, device=dev, generator=g)
         real = torch.randn(sp, M, dtype=torch.float32, device=dev, generator=g)
         comp = real + 1e-2 * torch.randn(sp, M, dtype=torch.float32, device=dev, generator=g)
+        torch.cuda.synchronize()
 
         def sstep():
             k.check(k.lib().kb_prepare_dev(sb._h, Phi.data_ptr(), Ht.data_ptr(), M))

@@ -165,7 +165,10 @@ int kb_reset(kb_batch *b);
  * needCtrl (vanilla.go:129). */
 int kb_update(kb_batch *b, const double *meas, int meas_rows, const double *ctrl, int ctrl_rows);
 /* Same, measurements already in HBM (planar, batch dtype): element e of filter
- * i at meas[e*ld_meas + i].  Asynchronous on the handle's stream. */
+ * i at meas[e*ld_meas + i].  Asynchronous on the handle's stream (kb_stream: created non-blocking, it does NOT wait for the
+ * null stream): the caller's device arrays of every *_dev entry point are read there, so whatever produced them on another
+ * stream has to be complete, or ordered before it with an event, when the call is made -- and they stay untouched until the
+ * step has run (kb_synchronize, or an event recorded on kb_stream). */
 int kb_update_dev(kb_batch *b, const void *meas, int64_t ld_meas,
                   const void *ctrl, int64_t ld_ctrl);
 /* The caller loop `for k { kf.Update(y_k, u_k) }` fused into one launch:

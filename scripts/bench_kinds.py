@@ -40,6 +40,7 @@ def warm_clocks(ms=60.0):
 
 
 def timed(b, fn, K=20, warm=5):
+    torch.cuda.synchronize()   # arrays made by torch are complete before the handle's (non-blocking) stream reads them
     warm_clocks()
     s = torch.cuda.ExternalStream(b.stream())
     for _ in range(warm):

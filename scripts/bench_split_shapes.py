@@ -46,6 +46,7 @@ for kind, name in ((k.VANILLA, "vanilla"), (k.SQUAREROOT, "squareroot"), (k.INFO
                                     noise=k.NOISE_AWGN if AWGN else k.NOISE_NOISELESS, seed=7)
         del F, Q
         y = torch.randn((p, N), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
         s = torch.cuda.ExternalStream(b.stream())
         for _ in range(3):
             b.update_dev(y.data_ptr(), N)

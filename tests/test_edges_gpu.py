@@ -150,6 +150,7 @@ def test_device_side_set_and_get_planar_roundtrip():
         ref.update(d["y"][t]); b.update(d["y"][t])
     assert np.array_equal(b.get(k.STATE), ref.get(k.STATE)) and np.array_equal(b.get(k.COVAR), ref.get(k.COVAR))
     xs = torch.zeros(n, N + 5, dtype=torch.float64, device="cuda"); Ps = torch.zeros(n * n, N + 5, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()   # (the zero fills run on torch's stream; the handle's does not wait for it)
     k.check(k.lib().kb_get_dev(b._h, k.STATE, xs.data_ptr(), N + 5))
     k.check(k.lib().kb_get_dev(b._h, k.COVAR, Ps.data_ptr(), N + 5))
     b.synchronize()
@@ -308,6 +309,7 @@ def test_baseline_size_1m_hybrid_ekf_properties():
     comp_s = real_s + 1e-3 * torch.randn(p, small, dtype=torch.float64, device="cuda", generator=gen)
     rep = N // small
     Phi, Ht, real, comp = (v.repeat(1, rep).contiguous() for v in (Phi_s, Ht_s, real_s, comp_s))
+    torch.cuda.synchronize()   # the handles' streams do not wait for torch's
 
     def make(M, x0):
         h = ga.FilterBatch(k.HYBRID, n, p, 0, M)

@@ -601,6 +601,7 @@ def test_smooth_all_backward_sweep_vs_oracle(kind):
         b.prepare(Phi[t], Ht[t]); b.update_nl(real[t], comp[t])
     phis = torch.from_numpy(np.ascontiguousarray(Phi.reshape(steps, N, n * n).transpose(0, 2, 1))).cuda()   # [steps][n*n][N]
     xs = torch.zeros(steps, n, N, dtype=torch.float64, device="cuda"); Ps = torch.zeros(steps, n * n, N, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()   # (the zero fills run on torch's stream; the handle's does not wait for it)
     k.check(k.lib().kb_smooth_all_dev(b._h, phis.data_ptr(), N, steps, xs.data_ptr(), Ps.data_ptr()))
     b.synchronize()
     xs_h = xs.cpu().numpy().transpose(2, 0, 1); Ps_h = Ps.cpu().numpy().transpose(2, 0, 1).reshape(N, steps, n, n)

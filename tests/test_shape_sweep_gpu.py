@@ -175,6 +175,7 @@ def test_every_shape_device_measurements_equal_host_measurements(kind):
         if m:
             ud = torch.zeros(STEPS, m, ld, dtype=torch.float64, device="cuda")
             ud[:, :, :N] = torch.from_numpy(np.ascontiguousarray(d["u"].transpose(0, 2, 1))).cuda()
+        torch.cuda.synchronize()   # (fills and copies run on torch's stream; the handle's does not wait for it)
         for t in range(STEPS):
             h.update(d["y"][t], None if m == 0 else d["u"][t], snapshot=False)
             g.update_dev(yd[t].data_ptr(), ld, ud[t].data_ptr() if m else None, ld if m else 0)

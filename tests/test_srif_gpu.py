@@ -46,6 +46,7 @@ def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
     Ht = [torch.randn(p * n, N, dtype=tdt, device="cuda", generator=g) for _ in SEQ]
     real = [torch.randn(p, N, dtype=tdt, device="cuda", generator=g) for _ in SEQ]
     comp = [(real[t] + 1e-2 * torch.randn(p, N, dtype=tdt, device="cuda", generator=g)).contiguous() for t in range(len(SEQ))]
+    torch.cuda.synchronize()   # the handles' streams do not wait for torch's
     es = 4 if dtype == k.F32 else 8
 
     def drive(b, first, count):
@@ -162,6 +163,7 @@ def test_srif_partial_half_tiles_zero_copy_and_full_estimate(N, dtype, tol):
         dH = torch.full((p * n, ld), float("nan"), dtype=tdt, device="cuda"); dH[:, :N] = torch.from_numpy(Ht.reshape(N, -1).T.copy()).to(tdt)
         dre = torch.full((p, ld), float("nan"), dtype=tdt, device="cuda"); dre[:, :N] = torch.from_numpy(real.T.copy()).to(tdt)
         dco = torch.full((p, ld), float("nan"), dtype=tdt, device="cuda"); dco[:, :N] = torch.from_numpy(comp.T.copy()).to(tdt)
+        torch.cuda.synchronize()   # (fills and copies run on torch's stream; the handle's does not wait for it)
         k.check(k.lib().kb_prepare_dev(b._h, dPhi.data_ptr(), dH.data_ptr(), ld))
         k.check(k.lib().kb_update_nl_dev(b._h, dre.data_ptr(), dco.data_ptr(), ld))
         b.synchronize()
