@@ -211,6 +211,8 @@ bool launch_srif_pair_f32c(const Batch &b, const StepArgs &a);  // kb_srif_pair3
 bool launch_srif_pair_f64c(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32d(const Batch &b, const StepArgs &a);  // kb_srif_pair32d.hip / 64d.hip: 6, 8, 10 states, p = 5 / 6
 bool launch_srif_pair_f64d(const Batch &b, const StepArgs &a);
+bool launch_srif_pair_f32e(const Batch &b, const StepArgs &a);  // kb_srif_pair32e.hip / 64e.hip: 6, 8, 10 (fp32: and 12) states, p = 7 / 8
+bool launch_srif_pair_f64e(const Batch &b, const StepArgs &a);
 // traj != nullptr: keep every run's State() and Measurement() per step (Batch::d_traj layout)
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, void *traj, int64_t traj_ld);
 int mc_repl();

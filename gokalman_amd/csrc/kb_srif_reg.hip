@@ -202,15 +202,16 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     if ((a.n & 1) || a.n < 6) return srif_odd_ok(b, a);
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
-    return srif_shape_ok(a, 12, 6) || (a.n == 12 && a.p == 5) || ((a.n == 6 || a.n == 8 || a.n == 10 || a.n == 12) && a.p >= 1 && a.p <= 6);
+    if (a.n != 6 && a.n != 8 && a.n != 10 && a.n != 12) return false;
+    return a.p >= 1 && a.p <= ((a.n == 12 && b.dtype == KB_F64) ? 6 : 8);   // (12 states with 7 / 8 measurements: fp32 only, kb_srif_pair64e.hip)
 }
 
 int launch_srif(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_srif_gen(b, a);
     if (((a.n & 1) || a.n < 6) && srif_odd_ok(b, a)) return launch_srif_odd(b, a);   // kb_srif_odd.hip
     bool done = false;
-    if (!a.predict) done = b.dtype == KB_F32 ? (launch_srif_pair_f32(b, a) || launch_srif_pair_f32b(b, a) || launch_srif_pair_f32c(b, a) || launch_srif_pair_f32d(b, a))
-                                             : (launch_srif_pair_f64(b, a) || launch_srif_pair_f64b(b, a) || launch_srif_pair_f64c(b, a) || launch_srif_pair_f64d(b, a));   // kb_srif_pair.h
+    if (!a.predict) done = b.dtype == KB_F32 ? (launch_srif_pair_f32(b, a) || launch_srif_pair_f32b(b, a) || launch_srif_pair_f32c(b, a) || launch_srif_pair_f32d(b, a) || launch_srif_pair_f32e(b, a))
+                                             : (launch_srif_pair_f64(b, a) || launch_srif_pair_f64b(b, a) || launch_srif_pair_f64c(b, a) || launch_srif_pair_f64d(b, a) || launch_srif_pair_f64e(b, a));   // kb_srif_pair.h
     else if (b.dtype == KB_F32) done = srif_try_predict<float, 12, 6>(b, a) || srif_try_predict<float, 6, 2>(b, a) || srif_try_predict<float, 8, 2>(b, a) || srif_try_predict<float, 8, 4>(b, a) ||
                                        srif_try_predict<float, 10, 2>(b, a) || srif_try_predict<float, 10, 4>(b, a) || srif_try_predict<float, 12, 2>(b, a) || srif_try_predict<float, 12, 4>(b, a);
     else done = srif_try_predict<double, 6, 2>(b, a) || srif_try_predict<double, 12, 6>(b, a) || srif_try_predict<double, 8, 2>(b, a) || srif_try_predict<double, 8, 4>(b, a) ||
