@@ -203,7 +203,7 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if ((a.n & 1) || a.n < 6) return srif_odd_ok(b, a);
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
     if (a.n != 6 && a.n != 8 && a.n != 10 && a.n != 12) return false;
-    return a.p >= 1 && a.p <= ((a.n == 12 && b.dtype == KB_F64) ? 6 : 8);   // (12 states with 7 / 8 measurements: fp32 only, kb_srif_pair64e.hip)
+    return a.p >= 1 && a.p <= 8;
 }
 
 int launch_srif(const Batch &b, const StepArgs &a) {
