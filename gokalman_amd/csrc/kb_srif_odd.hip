@@ -54,8 +54,8 @@ void pad_launch(const Batch &b, const PadArgs &pa) {
 
 }  // namespace
 
-// the instantiated size an n-state filter runs on: 6 below six states, the next even number for 7, 9, 11; 0: none (n is instantiated itself, or beyond 12)
-static int srif_widened(int n) { return n < 6 ? 6 : ((n & 1) && n < 12 ? n + 1 : 0); }
+// the instantiated size an n-state filter runs on: 6 below six states, the next even number for 7, 9, ... 15; 0: none (n is instantiated itself)
+static int srif_widened(int n) { return n < 6 ? 6 : ((n & 1) && n < 16 ? n + 1 : 0); }
 
 bool srif_odd_ok(const Batch &b, const StepArgs &a) {
     if (!srif_widened(a.n) || (a.flags & KB_FLAG_STATEMENT_KERNELS)) return false;

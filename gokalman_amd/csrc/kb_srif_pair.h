@@ -292,7 +292,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     // ---- P Phi = L U (srif.go:111-114's Inverse = Dgetrf + ...), the columns split over the halves: the half that owns
     // column j searches the pivot and forms the multipliers, the other half receives them (one exchange each) and both
     // update their own columns.  nibble k of perm = original index of the row now in position k.
-    uint64_t perm = 0xBA9876543210ull;
+    uint64_t perm = 0xFEDCBA9876543210ull;
 #pragma unroll
     for (int j = 0; j < NS; j++) {
         const int cj = j / 2, oj = j % 2;
@@ -330,7 +330,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
             for (int cs = cj + 1; cs < HS; cs++) pc[r * HS + cs] -= lf * pc[j * HS + cs];
         }
     }
-    const bool anyswap = __any(perm != 0xBA9876543210ull);
+    const bool anyswap = __any(perm != 0xFEDCBA9876543210ull);
     KB_SRIF_STOP_AT(2, {
         for (int i = 0; i < NS; i++) sink__ += xbar[i];
         for (int e = 0; e < NS * HS; e++) sink__ += pc[e];

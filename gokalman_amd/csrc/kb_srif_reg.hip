@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) * NS * NS > 600 ? 1 : 2)) srif
         ltmp[i * KB_TILE] = s;
     }
     // P Phi = L U (srif.go:111-114's Inverse = Dgetrf + ...): nibble k of perm = original index of the row now in position k
-    uint64_t perm = 0xBA9876543210ull;
+    uint64_t perm = 0xFEDCBA9876543210ull;
 #pragma unroll
     for (int j = 0; j < NS; j++) {
 #pragma unroll
@@ -202,6 +202,7 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     if ((a.n & 1) || a.n < 6) return srif_odd_ok(b, a);
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
+    if (a.n == 14 || a.n == 16) return !a.predict && a.p >= 1 && a.p <= 6;   // (Update only: kb_srif_pair32f.hip ...)
     if (a.n != 6 && a.n != 8 && a.n != 10 && a.n != 12) return false;
     return a.p >= 1 && a.p <= 8;
 }
@@ -209,9 +210,10 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
 int launch_srif(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_srif_gen(b, a);
     if (((a.n & 1) || a.n < 6) && srif_odd_ok(b, a)) return launch_srif_odd(b, a);   // kb_srif_odd.hip
+    if (a.state == b.d_state) b.sh_state_current = false;   // (every other kernel writes the state block itself: a widened copy of it is stale)
     bool done = false;
-    if (!a.predict) done = b.dtype == KB_F32 ? (launch_srif_pair_f32(b, a) || launch_srif_pair_f32b(b, a) || launch_srif_pair_f32c(b, a) || launch_srif_pair_f32d(b, a) || launch_srif_pair_f32e(b, a))
-                                             : (launch_srif_pair_f64(b, a) || launch_srif_pair_f64b(b, a) || launch_srif_pair_f64c(b, a) || launch_srif_pair_f64d(b, a) || launch_srif_pair_f64e(b, a));   // kb_srif_pair.h
+    if (!a.predict) done = b.dtype == KB_F32 ? (launch_srif_pair_f32(b, a) || launch_srif_pair_f32b(b, a) || launch_srif_pair_f32c(b, a) || launch_srif_pair_f32d(b, a) || launch_srif_pair_f32e(b, a) || launch_srif_pair_f32f(b, a) || launch_srif_pair_f32g(b, a))
+                                             : (launch_srif_pair_f64(b, a) || launch_srif_pair_f64b(b, a) || launch_srif_pair_f64c(b, a) || launch_srif_pair_f64d(b, a) || launch_srif_pair_f64e(b, a) || launch_srif_pair_f64f(b, a) || launch_srif_pair_f64g(b, a));   // kb_srif_pair.h
     else if (b.dtype == KB_F32) done = srif_try_predict<float, 12, 6>(b, a) || srif_try_predict<float, 6, 2>(b, a) || srif_try_predict<float, 8, 2>(b, a) || srif_try_predict<float, 8, 4>(b, a) ||
                                        srif_try_predict<float, 10, 2>(b, a) || srif_try_predict<float, 10, 4>(b, a) || srif_try_predict<float, 12, 2>(b, a) || srif_try_predict<float, 12, 4>(b, a);
     else done = srif_try_predict<double, 6, 2>(b, a) || srif_try_predict<double, 12, 6>(b, a) || srif_try_predict<double, 8, 2>(b, a) || srif_try_predict<double, 8, 4>(b, a) ||

@@ -148,7 +148,7 @@ def _nl_models(N, n, p, steps, rng):
 
 @pytest.mark.parametrize("pivoting", [False, True])
 @pytest.mark.parametrize("n,p,dtype,tol", [(6, 2, k.F64, 1e-9), (12, 6, k.F64, 1e-9), (12, 6, k.F32, SRIF_F32_TOL), (8, 3, k.F64, 1e-9), (10, 1, k.F64, 1e-9), (12, 5, k.F64, 1e-9), (12, 5, k.F32, SRIF_F32_TOL), (6, 3, k.F32, SRIF_F32_TOL),
-                                           (7, 3, k.F64, 1e-9), (11, 6, k.F64, 1e-9), (9, 4, k.F32, SRIF_F32_TOL), (5, 3, k.F64, 1e-9), (8, 8, k.F64, 1e-9), (10, 7, k.F64, 1e-9), (12, 8, k.F32, SRIF_F32_TOL)])
+                                           (7, 3, k.F64, 1e-9), (11, 6, k.F64, 1e-9), (9, 4, k.F32, SRIF_F32_TOL), (5, 3, k.F64, 1e-9), (8, 8, k.F64, 1e-9), (10, 7, k.F64, 1e-9), (12, 8, k.F32, SRIF_F32_TOL), (16, 4, k.F64, 1e-9), (14, 5, k.F64, 1e-9), (15, 6, k.F32, SRIF_F32_TOL)])
 def test_srif_vs_oracle(n, p, dtype, tol, pivoting):
     """pivoting: Phi = (a different row permutation per filter and step) x (I + noise), so the partial pivoting of
     Phi's LU exchanges rows, differently in every lane of a wave."""
@@ -417,7 +417,7 @@ def test_hybrid_beyond_8_states_vs_oracle(n, p, full, ekf):
 
 @pytest.mark.parametrize("kind,n,p,dtype", [(k.HYBRID, 6, 2, k.F64), (k.HYBRID, 6, 1, k.F64), (k.HYBRID, 6, 3, k.F64), (k.HYBRID, 8, 4, k.F64), (k.HYBRID, 5, 2, k.F64), (k.HYBRID, 3, 1, k.F64), (k.HYBRID, 12, 4, k.F64), (k.HYBRID, 9, 2, k.F64), (k.HYBRID, 11, 7, k.F64), (k.HYBRID, 16, 8, k.F64),
                                             (k.SRIF, 12, 6, k.F64), (k.SRIF, 6, 2, k.F64), (k.SRIF, 12, 6, k.F32), (k.SRIF, 8, 3, k.F64), (k.SRIF, 12, 1, k.F32), (k.SRIF, 10, 4, k.F64), (k.SRIF, 6, 1, k.F64),
-                                            (k.SRIF, 12, 3, k.F64), (k.SRIF, 12, 5, k.F64), (k.SRIF, 12, 5, k.F32), (k.SRIF, 7, 3, k.F64), (k.SRIF, 11, 4, k.F32), (k.SRIF, 9, 1, k.F64), (k.SRIF, 8, 6, k.F64), (k.SRIF, 10, 5, k.F32), (k.SRIF, 4, 2, k.F64), (k.SRIF, 10, 8, k.F64), (k.SRIF, 12, 7, k.F32), (k.SRIF, 8, 7, k.F64)])
+                                            (k.SRIF, 12, 3, k.F64), (k.SRIF, 12, 5, k.F64), (k.SRIF, 12, 5, k.F32), (k.SRIF, 7, 3, k.F64), (k.SRIF, 11, 4, k.F32), (k.SRIF, 9, 1, k.F64), (k.SRIF, 8, 6, k.F64), (k.SRIF, 10, 5, k.F32), (k.SRIF, 4, 2, k.F64), (k.SRIF, 10, 8, k.F64), (k.SRIF, 12, 7, k.F32), (k.SRIF, 8, 7, k.F64), (k.SRIF, 16, 4, k.F64), (k.SRIF, 13, 2, k.F32), (k.SRIF, 14, 6, k.F64)])
 def test_nldkf_device_path_zero_copy_equals_host_path(kind, n, p, dtype):
     """kb_prepare_dev + kb_update_nl_dev (planar device arrays read in place) == kb_prepare + kb_update_nl."""
     import torch

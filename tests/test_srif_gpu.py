@@ -101,9 +101,11 @@ def test_srif_config_e_at_size_vs_oracle_and_chunked(dtype, tol):
                                            (12, 5, k.F64, 1e-9), (12, 5, k.F32, SRIF_F32_TOL),
                                            (7, 3, k.F64, 1e-9), (9, 2, k.F64, 1e-9), (11, 4, k.F32, SRIF_F32_TOL), (11, 6, k.F64, 1e-9), (5, 1, k.F64, 1e-9), (11, 5, k.F64, 1e-9), (13, 3, k.F64, 1e-9),
                                            (8, 6, k.F64, 1e-9), (10, 5, k.F32, SRIF_F32_TOL), (6, 6, k.F64, 1e-9), (9, 5, k.F64, 1e-9), (3, 2, k.F64, 1e-9), (4, 4, k.F32, SRIF_F32_TOL),
-                                           (8, 8, k.F64, 1e-9), (10, 7, k.F64, 1e-9), (6, 8, k.F32, SRIF_F32_TOL), (12, 8, k.F32, SRIF_F32_TOL), (7, 7, k.F64, 1e-9), (12, 7, k.F64, 1e-9), (11, 8, k.F64, 1e-9)])
+                                           (8, 8, k.F64, 1e-9), (10, 7, k.F64, 1e-9), (6, 8, k.F32, SRIF_F32_TOL), (12, 8, k.F32, SRIF_F32_TOL), (7, 7, k.F64, 1e-9), (12, 7, k.F64, 1e-9), (11, 8, k.F64, 1e-9),
+                                           (14, 4, k.F64, 1e-9), (16, 6, k.F64, 1e-9), (16, 3, k.F32, SRIF_F32_TOL), (15, 2, k.F64, 1e-9), (14, 7, k.F64, 1e-9)])
 def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
-    """(13, 3) has no register kernel: the generic one must behave the same; 8 / 10 / 12 states with 2 / 4 measurements run further
+    """(14, 7) has no register kernel (more than six measurements beyond 12 states): the generic one must behave the same; 13 .. 16 states
+    Predict() on the generic kernel between Updates on the two-lane one; 8 / 10 / 12 states with 2 / 4 measurements run further
     instantiations of the two-lanes-per-filter kernel (kb_srif_pair*b.hip, *c.hip) and of the Predict() kernel; an odd number of measurements runs
     the next even instantiation with a padded row (kb_srif_pair.h PADM); an odd number of states (5 with p != 2, 7, 9, 11) the next even
     one as diag(filter, one uncoupled state) (kb_srif_odd.hip)."""
