@@ -186,6 +186,26 @@ def _leg_parity(ga, k, synth, leg):
         out.update({"oracle_filters": M, "max_rel_frobenius_information_vector": ei, "max_rel_frobenius_information_matrix": eI, "tolerance": 1e-9,
                     "ok": bool(ei <= 1e-9 and eI <= 1e-9 and nerr == 0 and not b.status().any())})
         return out
+    if leg == "fused":
+        # kb_update_steps_dev (T steps inside one launch) evaluates the Joseph form in the distributed order with Newton reciprocals:
+        # NOT bit-identical to T calls of kb_update_dev (include/gokalman_amd.h) -- held to the oracle like every other leg, and the
+        # distance to the per-step kernel on the same input is reported next to it
+        d = synth.linear_batch(N, N_STATE, N_MEAS, T, seed=synth.SEED + 78)
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        b1 = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+        torch.cuda.synchronize()
+        b.update_steps_dev(y.data_ptr(), N, T)
+        for t in range(T):
+            b1.update_dev(y[t].data_ptr(), N)
+        b.synchronize(); b1.synchronize()
+        xo, Po, nerr = orc.ldkf_batch(orc.VANILLA, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+        ex, eP = synth.rel_frobenius(b.get(k.STATE), xo), synth.rel_frobenius(b.get(k.COVAR), Po)
+        out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
+                    "vs_per_step_kernel": {"state": synth.rel_frobenius(b.get(k.STATE), b1.get(k.STATE)),
+                                           "covariance": synth.rel_frobenius(b.get(k.COVAR), b1.get(k.COVAR))},
+                    "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any() and b.step() == T)})
+        return out
     if leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "vanilla_10x4"):
         nn, pp = (12, 6) if leg in ("vanilla_12x6", "squareroot_12x6") else ((10, 4) if leg == "vanilla_10x4" else (N_STATE, N_MEAS))
         d = synth.linear_batch(N, nn, pp, T, seed=synth.SEED + 77)
@@ -531,6 +551,9 @@ def main():
                                        "value": args.mc_total * args.mc_steps / ens_s, "unit": "run-steps/s (whole job)",
                                        "matches_covariance_recursion": ok_mc, "stddev_last": ens.stddev(args.mc_steps - 1).tolist()}
             del shards
+        elif rank == 0:
+            print("bench: extra.mc.ensemble skipped: --mc-total %d is not a multiple of world x --mc-runs = %d x %d"
+                  % (args.mc_total, world, args.mc_runs), file=sys.stderr, flush=True)
         # ---- chi-square on the same ensemble (chisquare.go:16-95): NIS / NEES sums all-reduced like the means ----
         if args.chisq_runs > 0:
             R = min(args.chisq_runs, args.mc_runs)
@@ -796,6 +819,8 @@ def main():
             for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6", "vanilla_10x4", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
                 if leg in extra:
                     extra[leg]["parity"] = _leg_parity(ga, k, synth, leg)
+            if fused:   # the time-fused launch is a different kernel from the headline's: its own gate
+                fused["parity"] = _leg_parity(ga, k, synth, "fused")
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
             out["cpu_baseline"] = _cpu_baseline(d)
         print(json.dumps(out), flush=True)

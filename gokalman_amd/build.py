@@ -26,11 +26,6 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build the gfx950 kernels")
 
 
-def _deps_mtime():
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    return max(os.path.getmtime(h) for h in hdrs)
-
-
 # per-file extra flags: the SLP vectoriser packs fp32 pairs in the fully unrolled SRIF panels and
 # lengthens live ranges (more AGPR / scratch spills); it buys nothing there
 # the two-lanes-per-filter SRIF kernel is ~10k instructions of straight-line code per variant: past LLVM's default budget for
@@ -41,15 +36,43 @@ EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR,
          "kb_vanilla_split12.hip": _UNROLL, "kb_vanilla_split16.hip": _UNROLL, "kb_vanilla_split12p.hip": _UNROLL, "kb_hybrid_split.hip": _UNROLL, "kb_hybrid_split8.hip": _UNROLL, "kb_vanilla_split16p.hip": _UNROLL, "kb_squareroot_split12.hip": _UNROLL, "kb_squareroot_split12p.hip": _UNROLL, "kb_squareroot_split16p.hip": _UNROLL, "kb_squareroot_split16.hip": _UNROLL, "kb_information_split12.hip": _UNROLL, "kb_information_split8.hip": _UNROLL, "kb_information_split12f.hip": _UNROLL}
 
 
+# file-name prefixes of the kernel families whose translation units MUST have an EXTRA entry
+_NEEDS_EXTRA = ("kb_srif_pair", "kb_vanilla_split", "kb_squareroot_split", "kb_information_split", "kb_hybrid_split")
+
+
+def _read_deps(dep):
+    """Prerequisites of a make-style dependency file (-MMD): the source and every header it includes."""
+    try:
+        txt = open(dep).read()
+    except OSError:
+        return None
+    txt = txt.replace("\\\n", " ")
+    return [t for t in txt.split(":", 1)[1].split() if t] if ":" in txt else None
+
+
 def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-            and os.path.getmtime(obj) > _deps_mtime()):
-        return obj
-    cmd = [_hipcc()] + FLAGS + EXTRA.get(os.path.basename(src), []) + os.environ.get("KB_EXTRA_DEFS", "").split() + ["-c", src, "-o", obj]
+    """One translation unit -> csrc/_obj/<name>.o, rebuilt when the source, a header IT includes (hipcc -MMD) or its
+    command line changed (a header edit used to rebuild all 55 units: six minutes)."""
+    base = os.path.basename(src)
+    if base not in EXTRA and any(base.startswith(pfx) for pfx in _NEEDS_EXTRA):
+        # a missed entry silently turns the register arrays of these kernels into scratch arrays (NOTES.md)
+        raise RuntimeError("build.py: %s belongs to a kernel family that needs per-file flags (EXTRA) and has none" % base)
+    obj = os.path.join(OBJ, base + ".o")
+    dep, cmdf = obj + ".d", obj + ".cmd"
+    cmd = [_hipcc()] + FLAGS + EXTRA.get(base, []) + os.environ.get("KB_EXTRA_DEFS", "").split() + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
+    if not force and os.path.exists(obj):
+        deps = _read_deps(dep)
+        try:
+            same_cmd = open(cmdf).read() == " ".join(cmd)
+        except OSError:
+            same_cmd = False
+        if deps and same_cmd and all(os.path.exists(d) and os.path.getmtime(d) < os.path.getmtime(obj) for d in deps):
+            return obj
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))
+    with open(cmdf, "w") as fh:
+        fh.write(" ".join(cmd))
     return obj
 
 

@@ -70,7 +70,12 @@ int launch_srif_odd(const Batch &b, const StepArgs &a) {
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     if (!b.d_sh_state) KB_HIP(dev_alloc(&b.d_sh_state, b.block_bytes(L2.st_elems)));
     if (!b.d_sh_model) KB_HIP(dev_alloc(&b.d_sh_model, b.block_bytes(L2.mo_elems)));
-    if (full && !b.d_sh_est) KB_HIP(dev_alloc(&b.d_sh_est, b.block_bytes(L2.es_elems)));
+    if (full && !b.d_sh_est) {
+        // a failed filter's Estimate slots are not written by the even kernel and ARE copied back below: defined values (zeros,
+        // what a fresh batch's estimate block holds), never uninitialised memory
+        KB_HIP(dev_alloc(&b.d_sh_est, b.block_bytes(L2.es_elems)));
+        KB_HIP(hipMemsetAsync(b.d_sh_est, 0, b.block_bytes(L2.es_elems), b.stream));
+    }
     PadArgs st{};   // state: b, R
     st.src = a.state; st.dst = b.d_sh_state; st.src_elems = a.L.st_elems; st.dst_elems = L2.st_elems; st.ld = 0; st.N = a.N; st.nf = 2;
     st.f[0] = PadField{a.L.st_vec, L2.st_vec, 1, n, 1, n2, 0, nullptr};

@@ -6,6 +6,11 @@ namespace kb {
 
 bool launch_vanilla_split16(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
+    // BatchNoise reports ZERO noise matrices (noise.go:89-98): once the measurements have pinned the state down, P is amplified
+    // rounding noise and only the reference's own order of operations reproduces its digits (kb_vanilla_reg.h).  The split kernel
+    // evaluates the Joseph form in the distributed order, so these batches take the statement-order kernel (as the SquareRoot and
+    // Information split launchers already decide).
+    if (a.noise_kind == KB_NOISE_BATCH) return false;
     if (launch_vanilla_split16_plain(b, a)) return true;
     hipLaunchKernelGGL((vanilla_split_kernel<double, 16, 8, 2, 8, true, false, false>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
     return true;

@@ -6,8 +6,8 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; src=$2; defs=$3
 obj=gokalman_amd/csrc/_obj
-extra=""
-case "$src" in kb_vanilla_split*|kb_squareroot_split*|kb_information_split*) extra="-mllvm -pragma-unroll-threshold=200000";; kb_srif_pair*) extra="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=200000";; kb_srif_reg.hip) extra="-fno-slp-vectorize";; esac
+# the per-file flags come from gokalman_amd/build.py (EXTRA): the variant is the library's kernel plus the defines, nothing else
+extra=$(python3 -c "import sys; sys.path.insert(0, '.'); from gokalman_amd import build as b; print(' '.join(b.EXTRA.get('$src', [])))")
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast-honor-pragmas -fno-fast-math $extra $defs -c gokalman_amd/csrc/$src -o /tmp/variant_$name.o
 objs=$(ls $obj/*.o | grep -v "/$src.o")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o gokalman_amd/_variants/lib$name.so $objs /tmp/variant_$name.o

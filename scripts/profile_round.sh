@@ -9,6 +9,7 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from gokalman_amd import roofline as rl; print(rl.kernel_source_hash('$ROOT'))" > $OUT/source_hash.txt
 export TMPDIR=/tmp
 cd $ROOT
 B="--steps 40 --warmup 5 --repeat 1 --no-cpu-baseline --no-parity --no-host-path --ooc-filters 0 --mc-runs 0 --chisq-runs 0 --hybrid-filters 0 --sqrt-filters 0 --srif-filters 0 --shared-filters 0 --split-filters 0"

@@ -26,7 +26,12 @@ def short(name):
 
 
 def condense():
-    out = {"stats": {}, "pmc": {}, "source_hash": rl.kernel_source_hash(ROOT)}   # the sources the counters were measured on
+    # the sources the counters were measured on: profile_round.sh writes the hash BEFORE its first pass (on the GPU box, where the
+    # snapshot cannot change under it); a hash taken later would stamp edited sources as measured
+    hf = os.path.join(SRC, "source_hash.txt")
+    if not os.path.exists(hf):
+        sys.exit("summarise_round: %s missing -- counters without the hash of the sources they were collected on are not summarised" % hf)
+    out = {"stats": {}, "pmc": {}, "source_hash": open(hf).read().strip()}
     for d in sorted(glob.glob(os.path.join(SRC, "*"))):
         if not os.path.isdir(d):
             continue
@@ -155,11 +160,11 @@ def main():
     open(os.path.join(DST, "summary.md"), "w").write("\n".join(md) + "\n")
     json.dump({"tag": tag, "head": head, "condensed": c}, open(os.path.join(DST, "summary.json"), "w"), indent=1)
     if traffic:
-        json.dump({"tag": tag, "head": head, "source_hash": c.get("source_hash", rl.kernel_source_hash(ROOT)), "kernels": traffic,
+        json.dump({"tag": tag, "head": head, "source_hash": c["source_hash"], "kernels": traffic,
                    "note": "FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE; separate --pmc passes; the counters sit on the "
                            "L2's fabric side and include Infinity-Cache hits"}, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
     if named:
-        json.dump({"tag": tag, "head": head, "source_hash": c.get("source_hash", rl.kernel_source_hash(ROOT)), "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
+        json.dump({"tag": tag, "head": head, "source_hash": c["source_hash"], "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
                   open(os.path.join(ROOT, "profiles", "valu_latest.json"), "w"), indent=1)
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resource_usage.py"), "--md", os.path.join(DST, "resource_usage.md"),
                     "reg_kernel", "srif_", "mc_kernel", "chisq_kernel"], stdout=subprocess.DEVNULL)

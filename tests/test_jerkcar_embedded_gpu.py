@@ -1,0 +1,93 @@
+"""The reference's own golden outputs (examples/jerkcar/{vanilla,sqrt,information}.csv) on the kernels that REORDER the
+reference's arithmetic: the block-diagonal embedding of the 4-state scenario (tests/jerkcar.py `embedded`: k = 2, 3, 4 copies =
+8, 12, 16 states, p = k on ordinary steps and 2k on every 10th -- the H / noise swap changes p between steps) runs on
+kb_vanilla_split.h / kb_squareroot_split.h / kb_information_split.h (four lanes per filter at 8 and 12 states, eight at 16) and
+every 4-state diagonal block of the result has to equal the CSV at its print precision over all 2000 steps, and the oracle on the
+same embedded input at 1e-9.  tests/test_jerkcar_embedded_cpu.py pins the oracle side."""
+import numpy as np
+import pytest
+
+import gokalman_amd as ga
+from gokalman_amd import _capi as k
+from oracle import oracle as orc
+from tests import jerkcar as jc
+
+pytestmark = pytest.mark.gpu
+PRINT_TOL = 5.1e-7
+KINDS = {"vanilla": (k.VANILLA, orc.VANILLA), "sqrt": (k.SQUAREROOT, orc.SQUAREROOT), "information": (k.INFORMATION, orc.INFORMATION)}
+
+
+def _run(name, kk, full):
+    kind, okind = KINDS[name]
+    info = name == "information"
+    e = jc.embedded_information(kk) if info else jc.embedded(kk)
+    H0, R0 = (e["H1Z"], e["RI"]) if info else (e["H2"], e["R2"])
+    flags = k.FLAG_FULL_ESTIMATE if full else 0
+    b = ga.FilterBatch.new_ldkf(kind, e["X0"], e["P0"], e["F"], e["G"], H0, e["Q"], R0, nfilters=3, pmax=2 * kk, flags=flags)
+    f = orc.Filter.ldkf(okind, e["X0"], e["P0"], e["F"], e["G"], H0, e["Q"], R0)
+    worst = {"x": 0.0, "P": 0.0, "Pm": 0.0, "K": 0.0, "y": 0.0, "off": 0.0, "spread": 0.0}
+
+    def rel(a, r):
+        a, r = np.asarray(a, dtype=np.float64).ravel(), np.asarray(r, dtype=np.float64).ravel()
+        den = np.linalg.norm(r)
+        return float(np.linalg.norm(a - r) / den) if den > 0 else float(np.linalg.norm(a))
+
+    def row():
+        x, P = b.get(k.STATE, 1, 1)[0], b.get(k.COVAR, 1, 1)[0]
+        worst["off"] = max(worst["off"], jc.off_block_max(P, kk))
+        worst["x"] = max(worst["x"], rel(x, f.state()))
+        worst["P"] = max(worst["P"], rel(P, f.covariance()))
+        # the three filters of the batch are the same filter (one model, broadcast)
+        worst["spread"] = max(worst["spread"], float(np.max(np.abs(b.get(k.STATE) - x))))
+        return jc.export_rows_blocks(x, P, kk)
+
+    def upd(y, u):
+        est = b.update(y, u)
+        assert f.update(y, u) == orc.OK
+        if full:
+            worst["Pm"] = max(worst["Pm"], rel(est.pred_covariance()[1], f.pred_covariance()))
+            worst["y"] = max(worst["y"], float(np.max(np.abs(est.measurement()[1] - f.measurement()))))
+            if not info:   # InformationEstimate has no gain
+                worst["K"] = max(worst["K"], rel(est.gain()[1], f.gain()))
+
+    def set_h(H):
+        b.set_measurement_matrix(H); f.set_measurement_matrix(H)
+
+    def set_noise(Q, R):
+        b.set_noise(Q, R); f.set_noise(Q, R)
+
+    if info:
+        got = jc.run_protocol_embedded_information(kk, upd, set_h, row)
+    else:
+        got = jc.run_protocol_embedded(kk, upd, set_h, set_noise, row)
+    return got, worst, b
+
+
+@pytest.mark.parametrize("full", [False, True])
+@pytest.mark.parametrize("kk", [2, 3, 4])
+@pytest.mark.parametrize("name", ["vanilla", "sqrt", "information"])
+def test_embedded_jerkcar_on_the_split_kernels_equals_reference_csv(name, kk, full):
+    got, worst, b = _run(name, kk, full)
+    exp = jc.load_expected(name)
+    assert got.shape == (2001, kk, 12)
+    err = max(float(np.max(np.abs(got[:, blk] - exp))) for blk in range(kk))
+    print("embedded x%d %s%s: max |gpu - csv| %.3e; vs oracle (worst step of 2000, rel-Frobenius) x %.2e P %.2e P- %.2e K %.2e yhat(abs) %.2e; "
+          "off-block |P| %.2e; spread over the batch %.1e"
+          % (kk, name, " FULL" if full else "", err, worst["x"], worst["P"], worst["Pm"], worst["K"], worst["y"], worst["off"], worst["spread"]))
+    assert err <= PRINT_TOL
+    # rows 0..19 of the Information run: I is singular, State() / Covariance() are zeros on both sides (information.go:284-288)
+    if name == "information":
+        assert np.all(got[:20, :, 1::3] == 0.0)
+        assert not (b.status() & ~np.uint32(k.ST_INFO_NOT_INVERTIBLE)).any()
+        # one more inversion on both sides between (i, I) and the exported (x, P)
+        assert worst["x"] <= 1e-7 and worst["P"] <= 1e-7
+    else:
+        assert not b.status().any()
+        assert worst["x"] <= 1e-9 and worst["P"] <= 1e-9
+        if full:
+            assert worst["Pm"] <= 1e-9 and worst["K"] <= 1e-9
+    if full:
+        assert worst["y"] <= 1e-7
+    assert worst["spread"] == 0.0
+    # blocks never mix: whatever order the sums run in, the products with the zero blocks are exact zeros
+    assert worst["off"] == 0.0

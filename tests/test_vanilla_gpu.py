@@ -110,6 +110,45 @@ def test_vanilla_device_path_and_fused_steps():
         assert synth.rel_frobenius(b.get(k.COVAR, 0, 128), Po) <= TOL
 
 
+def test_fused_steps_on_ill_conditioned_innovation_covariance():
+    """kb_update_steps_dev's time-fused kernel divides by Newton-refined reciprocals and evaluates the Joseph form in the distributed
+    order (include/gokalman_amd.h): not the per-step kernel's bits.  Nearly collinear measurement rows and a small R make
+    S = H P- H^T + R ill-conditioned (cond ~1e6..1e7); any backward-stable evaluation is then cond(S) x eps away from the oracle, and
+    both device paths are held to 64 x cond(S) x 2^-53 -- printed next to what they achieve."""
+    import torch
+    N, steps = 2048, 20
+    d = synth.linear_batch(N, 6, 3, steps, seed=synth.SEED + 5)
+    rng = np.random.default_rng(55)
+    d["H"][:, 1] = d["H"][:, 0] + 1e-3 * rng.standard_normal((N, 6))
+    d["R"] = np.ascontiguousarray(np.broadcast_to(1e-7 * np.eye(3), (N, 3, 3)))
+    M = 256
+    fs = [orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]) for i in range(M)]
+    cond = 1.0
+    for t in range(steps):
+        for i, f in enumerate(fs):
+            assert f.update(d["y"][t, i]) == orc.OK
+            Pm = f.pred_covariance()
+            cond = max(cond, np.linalg.cond(d["H"][i] @ Pm @ d["H"][i].T + d["R"][i]))
+    xo, Po = np.array([f.state() for f in fs]), np.array([f.covariance() for f in fs])
+    tol = 64 * cond * 2.0 ** -53
+    y_planar = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+    got = {}
+    for fused in (False, True):
+        b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        if fused:
+            b.update_steps_dev(y_planar.data_ptr(), N, steps)
+        else:
+            for t in range(steps):
+                b.update_dev(y_planar[t].data_ptr(), N)
+        b.synchronize()
+        assert b.step() == steps and not b.status().any()
+        got[fused] = (synth.rel_frobenius(b.get(k.STATE, 0, M), xo), synth.rel_frobenius(b.get(k.COVAR, 0, M), Po))
+    print("ill-conditioned S (max cond %.2e, bound %.2e): per-step kernel x %.2e P %.2e; fused kernel x %.2e P %.2e"
+          % (cond, tol, got[False][0], got[False][1], got[True][0], got[True][1]))
+    assert cond >= 1e5
+    assert max(got[False]) <= tol and max(got[True]) <= tol
+
+
 def test_vanilla_singular_innovation_sets_status_and_keeps_estimate():
     """H = 0 and R = 0 make H P- H^T + R exactly singular: the reference returns (nil, err)
     (vanilla.go:164-167) and leaves prevEst alone."""

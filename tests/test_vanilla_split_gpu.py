@@ -185,29 +185,38 @@ def test_split_awgn_replayed_through_the_oracle(n, p, m, full, predict):
     assert not b.status().any() and b.step() == steps
 
 
-@pytest.mark.parametrize("n,p", [(12, 3), (15, 4)])   # (steps x p < n: with zero noise matrices the state is pinned down exactly after n measurements)
-def test_split_batch_noise_vs_oracle(n, p):
+@pytest.mark.parametrize("n,p", [(12, 3), (15, 4), (9, 2)])
+def test_split_shapes_batch_noise_vs_oracle_past_n_measurements(n, p):
     """BatchNoise (noise.go:67-106): recorded vectors, the same for every filter of a batch, indexed by kf.step.  BatchNoise reports
-    ZERO noise matrices (noise.go:89-98), so after the first update P is singular along the rows of H and the later innovation
-    covariances H P- H^T are badly conditioned (the model's F only mixes 5 % per step): the comparison is at 1e-7, three steps."""
-    N, steps = 100, 3
+    ZERO noise matrices (noise.go:89-98), so once steps x p >= n measurements have pinned the state down P is amplified rounding
+    noise: only the reference's order of operations reproduces the reference's digits, and the split launchers hand these batches
+    to the statement-order kernel.  Eight steps (24 / 32 / 16 measurements > n), state AND covariance at the normal
+    tolerance -- P relative to the scale it started from (it decays to rounding noise, its own norm is no yardstick)."""
+    N, steps = 100, 8
     d = _model(N, n, p, 0, steps, 900 + n)
     rng = np.random.default_rng(n)
     proc, meas = 1e-2 * rng.standard_normal((steps, n)), 1e-2 * rng.standard_normal((steps, p))
     ZQ, ZR = np.zeros((n, n)), np.zeros((p, p))
     b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], ZQ, ZR, nfilters=N, flags=k.FLAG_FULL_ESTIMATE)
     b.set_batch_noise(proc, meas)
+    fs = [orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], ZQ, ZR) for i in range(N)]
+    p0 = np.linalg.norm(d["P0"].reshape(N, -1), axis=1).max()
+    worst_x = worst_P = worst_y = 0.0
     for t in range(steps):
         est = b.update(d["y"][t])
-    xs, ys = [], []
-    for i in range(N):
-        f = orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], np.zeros((n, n)), np.zeros((p, p)))
-        for t in range(steps):
-            f.update(d["y"][t, i], None, proc[t], meas[t], proc[t])
-        xs.append(f.state()); ys.append(f.measurement())
-    assert not b.status().any()
-    assert synth.rel_frobenius(est.state(), np.array(xs)) <= 1e-7
-    assert synth.rel_frobenius(est.measurement(), np.array(ys)) <= 1e-7
+        rcs = np.array([f.update(d["y"][t, i], None, proc[t], meas[t], proc[t]) for i, f in enumerate(fs)])
+        st = b.status()
+        # a filter the oracle fails (singular H P- H^T once P has collapsed) fails here too, and keeps its estimate on both sides
+        assert np.array_equal(rcs != orc.OK, st != 0), (t, rcs[rcs != orc.OK], st[st != 0])
+        b.clear_status()
+        xs, Ps = np.array([f.state() for f in fs]), np.array([f.covariance() for f in fs])
+        ok = rcs == orc.OK
+        worst_x = max(worst_x, synth.rel_frobenius(est.state(), xs))
+        worst_P = max(worst_P, float(np.max(np.abs(est.covariance() - Ps)) / p0))
+        if ok.any():
+            worst_y = max(worst_y, synth.rel_frobenius(est.measurement()[ok], np.array([f.measurement() for f in fs])[ok]))
+    print("BatchNoise %d/%d, %d steps: worst x %.2e, P (relative to |P0|) %.2e, yhat %.2e" % (n, p, steps, worst_x, worst_P, worst_y))
+    assert worst_x <= TOL and worst_P <= TOL and worst_y <= TOL
 
 
 def test_split_shared_model_one_filter_batches_and_measurement_dimension_changes():
