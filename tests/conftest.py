@@ -36,3 +36,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Every bound looser than 1e-9 with the error achieved against it (tests/achieved.py)."""
+    import json
+    from tests import achieved
+    rows = achieved.summary()
+    if not rows:
+        return
+    tr = terminalreporter
+    tr.section("bounds looser than 1e-9: achieved / bound (tests/achieved.py)")
+    for r in rows:
+        tr.write_line("%-110s %-22s achieved %.2e  bound %.0e  (slack x%.1f)" % (r["test"][:110], r["label"][:22], r["achieved"], r["bound"], min(r["slack"], 9.9e99)))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "achieved_errors.json"), "w") as fh:
+            json.dump(rows, fh, indent=1)
+    except OSError:
+        pass

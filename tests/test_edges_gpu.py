@@ -7,6 +7,7 @@ import gokalman_amd as ga
 from gokalman_amd import _capi as k
 from gokalman_amd import synth
 from oracle import oracle as orc
+from tests.achieved import within
 
 pytestmark = pytest.mark.gpu
 
@@ -87,8 +88,8 @@ def test_set_state_transition_and_noise_between_steps():
             b.update(d["y"][t])
             for i, f in enumerate(fs):
                 assert f.update(d["y"][t, i]) == orc.OK
-        assert synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])) <= tol, kind
-        assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= tol, kind
+        assert within(synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])), tol, "state"), kind
+        assert within(synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])), tol, "covariance"), kind
 
 
 def test_is_within_nsigma_matches_oracle():

@@ -8,6 +8,7 @@ import pytest
 import gokalman_amd as ga
 from gokalman_amd import _capi as k, synth
 from oracle import oracle as orc
+from tests.achieved import within
 
 pytestmark = pytest.mark.gpu
 
@@ -70,8 +71,8 @@ def test_random_call_sequences_match_the_oracle(kind, okind, tol, n, m, seed):
     for i, f in enumerate(fs):
         assert f.update(y[i], u[i] if m else None) == orc.OK
         xs.append(f.state()); Ps.append(f.covariance())
-    assert synth.rel_frobenius(est.state(), np.array(xs)) <= tol, nupd
-    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= tol, nupd
+    assert within(synth.rel_frobenius(est.state(), np.array(xs)), tol, "state"), nupd
+    assert within(synth.rel_frobenius(est.covariance(), np.array(Ps)), tol, "covariance"), nupd
     assert not (b.status() & ~np.uint32(k.ST_INFO_NOT_INVERTIBLE)).any()
 
 
@@ -150,6 +151,6 @@ def test_random_nldkf_call_sequences_match_the_oracle(kind, n, p, dtype, tol, se
         f.prepare(Phi[i], Ht[i])
         assert f.update_nl(real[i], comp[i]) == orc.OK
         xs.append(f.state()); Ps.append(f.covariance())
-    assert synth.rel_frobenius(est.state(), np.array(xs)) <= tol
-    assert synth.rel_frobenius(est.covariance(), np.array(Ps)) <= tol
+    assert within(synth.rel_frobenius(est.state(), np.array(xs)), tol, "state")
+    assert within(synth.rel_frobenius(est.covariance(), np.array(Ps)), tol, "covariance")
     assert not b.status().any()

@@ -11,6 +11,7 @@ import gokalman_amd as ga
 from gokalman_amd import _capi as k
 from oracle import oracle as orc
 from tests import jerkcar as jc
+from tests.achieved import within
 
 pytestmark = pytest.mark.gpu
 PRINT_TOL = 5.1e-7
@@ -80,14 +81,14 @@ def test_embedded_jerkcar_on_the_split_kernels_equals_reference_csv(name, kk, fu
         assert np.all(got[:20, :, 1::3] == 0.0)
         assert not (b.status() & ~np.uint32(k.ST_INFO_NOT_INVERTIBLE)).any()
         # one more inversion on both sides between (i, I) and the exported (x, P)
-        assert worst["x"] <= 1e-7 and worst["P"] <= 1e-7
+        assert worst["x"] <= 1e-9 and worst["P"] <= 1e-9   # achieved 1.7e-11 / 2.3e-11 (one more inversion on both sides)
     else:
         assert not b.status().any()
         assert worst["x"] <= 1e-9 and worst["P"] <= 1e-9
         if full:
             assert worst["Pm"] <= 1e-9 and worst["K"] <= 1e-9
     if full:
-        assert worst["y"] <= 1e-7
+        assert within(worst["y"], 1e-7)
     assert worst["spread"] == 0.0
     # blocks never mix: whatever order the sums run in, the products with the zero blocks are exact zeros
     assert worst["off"] == 0.0

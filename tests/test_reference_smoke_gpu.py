@@ -10,6 +10,7 @@ import pytest
 import gokalman_amd as ga
 from gokalman_amd import _capi as k, synth
 from oracle import oracle as orc
+from tests.achieved import within
 
 pytestmark = pytest.mark.gpu
 YACC = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "midterm2_yacc.csv"), delimiter=",")
@@ -39,12 +40,12 @@ def test_midterm2_awgn_run_setters_reset_and_dimension_errors(kind, okind, tol):
         w1, v, w2 = LQ @ kf.noise_sample(0, 0, t, 0, 3), LR @ kf.noise_sample(0, 0, t, 1, 1), LQ @ kf.noise_sample(0, 0, t, 2, 3)
         assert f.update(np.array([YACC[step]]), np.zeros(1), w1, v, w2) == orc.OK
         xs = est.state()[0]
-        assert np.linalg.norm(xs - f.state()) <= tol * max(np.linalg.norm(f.state()), 1e-3), step
+        assert within(np.linalg.norm(xs - f.state()) / max(np.linalg.norm(f.state()), 1e-3), tol, "state"), step
         within = bool(est.is_within_nsigma(2)[0])
         assert within == bool(f.is_within_nsigma(2)), step
         breaches += (not within)
     assert kf.step() == 99
-    assert synth.rel_frobenius(est.covariance(), f.covariance()[None]) <= max(tol, 1e-8)
+    assert within(synth.rel_frobenius(est.covariance(), f.covariance()[None]), max(tol, 1e-8), "covariance")
     # Reset (vanilla_test.go:78-84)
     kf.reset()
     assert kf.step() == 0

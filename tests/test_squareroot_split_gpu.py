@@ -10,6 +10,7 @@ from gokalman_amd import _capi as k
 from gokalman_amd import synth
 from oracle import oracle as orc
 from tests.test_vanilla_split_gpu import _model
+from tests.achieved import within
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
@@ -54,8 +55,8 @@ def test_sqsplit_padded_family_vs_oracle(n, p, m, full):
     if full:
         assert synth.rel_frobenius(est.pred_covariance(), np.array([f.pred_covariance() for f in fs])) <= TOL
         assert synth.rel_frobenius(est.gain(), np.array([f.gain() for f in fs])) <= TOL
-        assert np.max(np.abs(est.innovation() - np.array([f.innovation() for f in fs]))) <= 1e-8
-        assert np.max(np.abs(est.measurement() - np.array([f.measurement() for f in fs]))) <= 1e-8
+        assert within(np.max(np.abs(est.innovation() - np.array([f.innovation() for f in fs]))), 1e-8)
+        assert within(np.max(np.abs(est.measurement() - np.array([f.measurement() for f in fs]))), 1e-8)
 
 
 @pytest.mark.parametrize("n,p,m,full", [(12, 6, 0, False), (12, 6, 0, True), (9, 3, 1, True), (11, 8, 2, False), (16, 8, 2, True), (14, 5, 0, False),
