@@ -202,6 +202,23 @@ bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_str
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 bool srif_odd_ok(const Batch &b, const StepArgs &a);      // kb_srif_odd.hip: 1..5, 7, 9, 11 states on the next instantiation (6, 8, 10, 12)
 int launch_srif_odd(const Batch &b, const StepArgs &a);
+// kb_srif_split_*.hip: fp64, one filter over 4 (n <= 12) / 8 (n <= 16) lanes, the state dimension at compile time, p at run time (kb_srif_split.h)
+void launch_srif_split_n1(const Batch &b, const StepArgs &a);
+void launch_srif_split_n2(const Batch &b, const StepArgs &a);
+void launch_srif_split_n3(const Batch &b, const StepArgs &a);
+void launch_srif_split_n4(const Batch &b, const StepArgs &a);
+void launch_srif_split_n5(const Batch &b, const StepArgs &a);
+void launch_srif_split_n6(const Batch &b, const StepArgs &a);
+void launch_srif_split_n7(const Batch &b, const StepArgs &a);
+void launch_srif_split_n8(const Batch &b, const StepArgs &a);
+void launch_srif_split_n9(const Batch &b, const StepArgs &a);
+void launch_srif_split_n10(const Batch &b, const StepArgs &a);
+void launch_srif_split_n11(const Batch &b, const StepArgs &a);
+void launch_srif_split_n12(const Batch &b, const StepArgs &a);
+void launch_srif_split_n13(const Batch &b, const StepArgs &a);
+void launch_srif_split_n14(const Batch &b, const StepArgs &a);
+void launch_srif_split_n15(const Batch &b, const StepArgs &a);
+void launch_srif_split_n16(const Batch &b, const StepArgs &a);
 Layout make_layout(int kind, int n, int pmax, int m, unsigned flags);   // kb_api.hip
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip

@@ -12,6 +12,7 @@
 // keeps its estimate for THAT step only; step k+1 runs normally (the status word is a sticky report, not a gate).
 #include "kb_internal.h"
 #include "kb_static.h"
+#include <cstdlib>
 
 namespace kb {
 
@@ -197,9 +198,32 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
     return true;
 }
 
+// fp64 shapes of the split-lane kernel (kb_srif_split.h, round 5): every odd n and n < 6 (natively, no widened shadow blocks), 13..16
+// states with any p <= 8, Update and Predict.  KB_SRIF_SPLIT_ALL=1 (environment, diagnostic) sends every fp64 shape there.
+static bool srif_split_all() {
+    static const bool on = [] { const char *e = getenv("KB_SRIF_SPLIT_ALL"); return e && *e && *e != '0'; }();
+    return on;
+}
+bool srif_split_ok(const Batch &b, const StepArgs &a) {
+    if (b.dtype != KB_F64 || (a.flags & KB_FLAG_STATEMENT_KERNELS) || a.n < 1 || a.n > 16 || a.p < 1 || a.p > 8) return false;
+    return (a.n & 1) || a.n < 6 || a.n > 12 || srif_split_all();
+}
+static int launch_srif_split(const Batch &b, const StepArgs &a) {
+    typedef void (*launch_t)(const Batch &, const StepArgs &);
+    static const launch_t by_n[17] = {nullptr, launch_srif_split_n1, launch_srif_split_n2, launch_srif_split_n3, launch_srif_split_n4, launch_srif_split_n5,
+                                      launch_srif_split_n6, launch_srif_split_n7, launch_srif_split_n8, launch_srif_split_n9, launch_srif_split_n10,
+                                      launch_srif_split_n11, launch_srif_split_n12, launch_srif_split_n13, launch_srif_split_n14, launch_srif_split_n15,
+                                      launch_srif_split_n16};
+    if (a.state == b.d_state) b.sh_state_current = false;
+    by_n[a.n](b, a);
+    KB_HIP(hipGetLastError());
+    return KB_OK;
+}
+
 // zero-copy Phi / Htilde (kb_prepare_dev) need one of the kernels that read the caller's planar arrays
 bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
+    if (srif_split_ok(b, a)) return true;
     if ((a.n & 1) || a.n < 6) return srif_odd_ok(b, a);
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
     if (a.n == 14 || a.n == 16) return !a.predict && a.p >= 1 && a.p <= 6;   // (Update only: kb_srif_pair32f.hip ...)
@@ -209,6 +233,7 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
 
 int launch_srif(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_srif_gen(b, a);
+    if (srif_split_ok(b, a)) return launch_srif_split(b, a);   // kb_srif_split.h
     if (((a.n & 1) || a.n < 6) && srif_odd_ok(b, a)) return launch_srif_odd(b, a);   // kb_srif_odd.hip
     if (a.state == b.d_state) b.sh_state_current = false;   // (every other kernel writes the state block itself: a widened copy of it is stale)
     bool done = false;

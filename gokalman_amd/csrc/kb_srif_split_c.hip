@@ -1,0 +1,9 @@
+// kb_srif_split_c.hip -- SRIF Update / Predict in fp64, one filter over four (n <= 12) / eight lanes (kb_srif_split.h): n = 11 12, p <= 4 and p <= 8.
+#include "kb_srif_split.h"
+
+namespace kb {
+
+KB_SRIF_SPLIT_TU(11)
+KB_SRIF_SPLIT_TU(12)
+
+}  // namespace kb

@@ -17,6 +17,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 which = args or ["vsplit", "vpad", "sqsplit", "infsplit", "vfull", "vbase", "vshared", "vnoise", "vstrict", "sqrt", "info", "sshared", "srif", "srifpad", "hybrid", "hpad", "hstrict", "mc"]
 Nopt = None
 for a in sys.argv[1:]:
+    if a.startswith("--srif-shapes="):
+        continue
     if a.startswith("--n="):
         Nopt = int(a[4:])
 
@@ -243,7 +245,11 @@ if "srif" in which:
 if "srifpad" in which:
     # further SRIF shapes of the two-lanes-per-filter kernel (kb_srif_pair*b.hip, *c.hip), fp64, against the statement kernel
     N = Nopt or (1 << 18)
-    for (n, p) in ((8, 2), (10, 4), (12, 2), (12, 5), (7, 3), (11, 4), (10, 6), (4, 2), (8, 8), (10, 8), (12, 8), (14, 4), (16, 4), (16, 6), (15, 3)):
+    shapes = ((8, 2), (10, 4), (12, 2), (12, 5), (7, 3), (11, 4), (10, 6), (4, 2), (8, 8), (10, 8), (12, 8), (14, 4), (16, 4), (16, 6), (15, 3), (13, 8), (16, 8))
+    for a_ in sys.argv[1:]:
+        if a_.startswith("--srif-shapes="):   # e.g. --srif-shapes=16x6,14x4
+            shapes = tuple(tuple(int(v) for v in t.split("x")) for t in a_[14:].split(","))
+    for (n, p) in shapes:
         rng = np.random.default_rng(5)
         x0 = rng.standard_normal((N, n)); P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
         R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
