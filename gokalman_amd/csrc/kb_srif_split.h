@@ -34,7 +34,6 @@
 namespace kb {
 
 #define KB_SB() __builtin_amdgcn_sched_barrier(0)
-
 // The lane group holding the largest v wins, on a tie the smaller low byte of tag (LAPACK's first-largest in its row order): the
 // same (v, tag) in all L lanes of a filter afterwards.
 __device__ __forceinline__ void argmax_pick(double v0, unsigned t0, double v1, unsigned t1, double &v, unsigned &t) {
@@ -110,8 +109,14 @@ __device__ __forceinline__ void reduce_scatter(const double (&v)[NS], double (&o
     }
 }
 
-template <int NS, int L>
-constexpr int srif_split_lds_elems() { return (NS * NS + NS) * (64 / L); }
+// [R | b] staged for the dense State(prev) / the rows put back in order: NS^2 + NS; two pivot-row buffers: 4 NS; two reflector buffers
+template <int NS, int NM, int L>
+constexpr int srif_split_lds_elems() {
+    int e = NS * NS + NS;
+    if (4 * NS > e) e = 4 * NS;
+    if (2 * (NS + NM + 1) > e) e = 2 * (NS + NM + 1);
+    return e * (64 / L);
+}
 
 // N: the state dimension, exact (the panel is padded to NS = the next multiple of L in registers: identity / zero, never loaded or
 // stored); NM >= p, the measurement dimension at run time.
@@ -151,6 +156,9 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
     bool colok[RP];
 #pragma unroll
     for (int r = 0; r < RP; r++) { jr[r] = q + L * r; colok[r] = jr[r] < rn; }
+    unsigned ulast[RP];   // the last REAL column of slot r, as a lane offset from column L r
+#pragma unroll
+    for (int r = 0; r < RP; r++) ulast[r] = us + (unsigned)(((L * r + L - 1 < N ? L - 1 : N - 1 - L * r) > 0 ? (L * r + L - 1 < N ? L - 1 : N - 1 - L * r) : 0) * KB_TILE);
     unsigned err = 0;
 
     // ---- phase 0: own columns of R (upper triangle only in the steady state) and of Phi, own b, own diagonal of R ----------------
@@ -164,7 +172,8 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
                 // steady state: rows below the slot's last column are never needed; rows inside it are needed by some lanes only
                 const bool mine = colok[r] && (dense || i <= jr[r]);
                 T v = T(0);
-                if (dense || i <= L * r + L - 1) v = *(ep(st, 0, N + i * N + L * r) + (mine ? uq : us));
+                // (a lane that does not need the entry re-reads one that another lane of the same instruction needs: no extra line)
+                if (dense || i <= L * r + L - 1) v = *(ep(st, 0, N + i * N + L * r) + (mine ? uq : ulast[r]));
                 Rc[r][i] = mine ? v : T(0);
             } else {
                 Rc[r][i] = (!colok[r] && i == jr[r]) ? T(1) : T(0);
@@ -181,20 +190,31 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             dg[r] = T(1);
         }
     }
+    auto load_phi = [&]() __attribute__((always_inline)) {
+        // (ONE test of `ext` around the loops: inside them every load would carry its own branch and both address computations)
+        if (ext) {
+            const T *const xp = (const T *)a.ext_phi;
 #pragma unroll
-    for (int r = 0; r < RP; r++) {
+            for (int r = 0; r < RP; r++)
 #pragma unroll
-        for (int i = 0; i < NS; i++) {
-            if (i < N && L * r < N) {
-                T v;
-                if (ext) v = __builtin_nontemporal_load((const T *)a.ext_phi + ((int64_t)(i * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld)));
-                else v = __builtin_nontemporal_load(ep(mo, 0, i * N + L * r) + (colok[r] ? umq : um));
-                Pc[r][i] = colok[r] ? v : T(0);
-            } else {
-                Pc[r][i] = (!colok[r] && i == jr[r]) ? T(1) : T(0);
-            }
+                for (int i = 0; i < NS; i++)
+                    if (i < N && L * r < N) Pc[r][i] = __builtin_nontemporal_load(xp + ((int64_t)(i * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld)));
+        } else {
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int i = 0; i < NS; i++)
+                    if (i < N && L * r < N) Pc[r][i] = __builtin_nontemporal_load(ep(mo, 0, i * N + L * r) + (colok[r] ? umq : um));
         }
-    }
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                if (i < N && L * r < N) Pc[r][i] = colok[r] ? Pc[r][i] : T(0);
+                else Pc[r][i] = (!colok[r] && i == jr[r]) ? T(1) : T(0);
+            }
+    };
+    load_phi();
     KB_SB();
 
     // ---- phase 1: State(prev) = R^-1 b (srif.go:223-234), x_j in the owner of column j ------------------------------------------
@@ -429,7 +449,10 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
         }
     }
     // Rc[r][i] = RBar[i][j_r] from here on.  bBar = RBar xBar (srif.go:119)
-    T rhs[ROWS], bbo[RP];
+    // The right-hand side column [bBar ; L y] lives by ROWS: lane q carries rows q, q + L, ... (the state rows are exactly where the
+    // reduce-scatter leaves bBar; 1 / L of the entries and of the arithmetic per lane, one lane sum per Householder step)
+    constexpr int MP = (NM + L - 1) / L;
+    T rv[RP + MP], bbo[RP];
     {
         T part[NS];
 #pragma unroll
@@ -482,33 +505,32 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
         }
         return;
     }
-    // every lane carries the whole right-hand side through the Householder steps: bBar is gathered through LDS
 #pragma unroll
-    for (int r = 0; r < RP; r++) lf[jr[r] * FPW] = bbo[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < NS; i++) rhs[i] = lf[i * FPW];
-    wave_lds_fence();
+    for (int r = 0; r < RP; r++) rv[r] = bbo[r];
     KB_SB();
 
     // ---- phase 5: the whitened measurement rows (srif.go:143-148), own columns of Htilde ---------------------------------------------
-    T W[RP][NM], real[NM];
+    T W[RP][NM], real[NM], yw[NM];
     {
         T Hc[RP][NM], LR[tri(NM)], yv[NM];
+        if (ext) {
+            const T *const xh = (const T *)a.ext_h;
 #pragma unroll
-        for (int r = 0; r < RP; r++) {
-            constexpr bool anycol = true;
+            for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int m = 0; m < NM; m++) {
-                const bool uni = anycol && L * r < N && m < rp;
-                T v = T(0);
-                if (uni) {
-                    if (ext) v = __builtin_nontemporal_load((const T *)a.ext_h + ((int64_t)(m * rn + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld)));
-                    else v = __builtin_nontemporal_load(ep(mo, 0, N * N + m * N + L * r) + (colok[r] ? umq : um));
-                }
-                Hc[r][m] = colok[r] ? v : T(0);
-            }
+                for (int m = 0; m < NM; m++)
+                    Hc[r][m] = (L * r < N && m < rp) ? __builtin_nontemporal_load(xh + ((int64_t)(m * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld))) : T(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int m = 0; m < NM; m++)
+                    Hc[r][m] = (L * r < N && m < rp) ? __builtin_nontemporal_load(ep(mo, 0, N * N + m * N + L * r) + (colok[r] ? umq : um)) : T(0);
         }
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+#pragma unroll
+            for (int m = 0; m < NM; m++) Hc[r][m] = colok[r] ? Hc[r][m] : T(0);
 #pragma unroll
         for (int m = 0; m < NM; m++)
 #pragma unroll
@@ -535,15 +557,23 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             T s = T(0);
 #pragma unroll
             for (int l = 0; l <= m; l++) s += LR[symi(l, m)] * yv[l];
-            rhs[NS + m] = s;
+            yw[m] = s;
         }
+    }
+#pragma unroll
+    for (int t = 0; t < MP; t++) {   // the lane's own measurement rows q + L t
+        T v = T(0);
+#pragma unroll
+        for (int qq = 0; qq < L; qq++)
+            if (L * t + qq < NM) v = q == qq ? yw[L * t + qq] : v;
+        rv[RP + t] = v;
     }
     if (full && ok) {
 #pragma unroll
         for (int m = 0; m < NM; m++)
             if (m < rp && q == m % L) {
                 __builtin_nontemporal_store(real[m], (gptr)ep(es, a.L.es_yhat, m) + us);
-                __builtin_nontemporal_store(rhs[NS + m], (gptr)ep(es, a.L.es_dobs, m) + us);
+                __builtin_nontemporal_store(yw[m], (gptr)ep(es, a.L.es_dobs, m) + us);
             }
     }
     KB_SB();
@@ -591,13 +621,24 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 #pragma unroll
                 for (int i = k; i < ROWS; i++) A(r, i) -= g * u[i];
             }
-            {
-                T g2[2] = {T(0), T(0)};
+            {   // the right-hand side: own rows at or below k (u of the own rows straight from LDS: their index depends on the lane)
+                T uo[RP + MP], gp = T(0);
 #pragma unroll
-                for (int i = k; i < ROWS; i++) g2[(i - k) & 1] += u[i] * rhs[i];
-                const T g = (g2[0] + g2[1]) * bt;
+                for (int t = 0; t < RP + MP; t++) {
+                    constexpr int unused = 0; (void)unused;
+                    const int base = t < RP ? L * t : NS + L * (t - RP);   // first row of slot t
+                    if (base + L - 1 >= k && base < ROWS) {
+                        const bool in = base + q >= k && base + q < ROWS;
+                        const T v = lf[(in ? base + q : k) * FPW];
+                        uo[t] = in ? v : T(0);
+                        gp += uo[t] * rv[t];
+                    } else {
+                        uo[t] = T(0);
+                    }
+                }
+                const T g = sum_lanes<L>(gp) * bt;
 #pragma unroll
-                for (int i = k; i < ROWS; i++) rhs[i] -= g * u[i];
+                for (int t = 0; t < RP + MP; t++) rv[t] -= g * uo[t];
             }
             A(r0, k) = own ? -sigma : A(r0, k);   // (helper.go:166-168 zeroes the sub-column: those registers are never read again)
             wave_lds_fence();
@@ -611,7 +652,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 #pragma unroll
         for (int i = 0; i < NS; i++) chk += (i <= jr[r] ? Rc[r][i] : T(0)) * T(0);
 #pragma unroll
-    for (int i = 0; i < ROWS; i++) chk += rhs[i] * T(0);
+    for (int t = 0; t < RP + MP; t++) chk += rv[t] * T(0);
     chk = sum_lanes<L>(chk);
     if (ok) {
 #pragma unroll
@@ -620,12 +661,12 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             for (int i = 0; i < NS; i++)
                 if (colok[r] && i < rn && (dense || i <= jr[r])) *((gptr)ep(st, 0, N + i * N + L * r) + uq) = i <= jr[r] ? Rc[r][i] : T(0);
 #pragma unroll
-        for (int i = 0; i < NS; i++)
-            if (i < rn && q == i % L) *((gptr)ep(st, 0, i) + us) = rhs[i];
+        for (int r = 0; r < RP; r++)
+            if (colok[r]) *((gptr)ep(st, 0, L * r) + uq) = rv[r];
         if (full) {
 #pragma unroll
-            for (int m = 0; m < NM; m++)
-                if (m < rp && q == m % L) __builtin_nontemporal_store(rhs[NS + m], (gptr)ep(es, a.L.es_innov, m) + us);
+            for (int t = 0; t < MP; t++)
+                if (L * t + q < rp) __builtin_nontemporal_store(rv[RP + t], (gptr)ep(es, a.L.es_innov, L * t) + uq);
         }
         // a non-finite result is stored as it is (helper.go:142-172 has no guard) and flagged
         if (chk != chk && q == 0) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
@@ -633,8 +674,8 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 }
 
 template <int N, int NM, int L>
-__global__ void __launch_bounds__(64, 2) srif_split_kernel(const StepArgs a) {
-    __shared__ double lds[srif_split_lds_elems<(N + L - 1) / L * L, L>()];
+__global__ void __launch_bounds__(64, (N <= 8 && NM <= 4) ? 3 : 2) srif_split_kernel(const StepArgs a) {
+    __shared__ double lds[srif_split_lds_elems<(N + L - 1) / L * L, NM, L>()];
     srif_split_part<N, NM, L>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
 }
 
@@ -644,10 +685,11 @@ static void srif_split_launch(const Batch &b, const StepArgs &a) {
     constexpr int L = N <= 12 ? 4 : 8;
     hipLaunchKernelGGL((srif_split_kernel<N, NM, L>), dim3((unsigned)(a.ntiles * L)), dim3(64), 0, b.stream, a);
 }
-// one translation unit per group of state dimensions (kb_srif_split_*.hip): p <= 4 and p <= 8 instantiations of each
+// one translation unit per group of state dimensions (kb_srif_split_*.hip): p <= 4, p <= 6 and p <= 8 instantiations of each
 #define KB_SRIF_SPLIT_TU(N_)                                                                                              \
     void launch_srif_split_n##N_(const Batch &b, const StepArgs &a) {                                                     \
         if (a.p <= 4) srif_split_launch<N_, 4>(b, a);                                                                     \
+        else if (a.p <= 6) srif_split_launch<N_, 6>(b, a);                                                                \
         else srif_split_launch<N_, 8>(b, a);                                                                              \
     }
 #undef KB_SB
