@@ -451,6 +451,24 @@ def main():
             fused["roofline"] = rl.valu_roofline(fms, (N + 63) // 64, vk["vanilla_fused"]["valu_insts_per_wave_per_step"] * T, vs)
         elif vs:
             fused["roofline"] = {"bound": "valu_issue", "frac": None, "source": vs}
+        # the same loop with the Noise drawn inside the launch (AWGN, noise.go:109-164; round 5): bit-identical to T single steps
+        if rank == 0:
+            ba = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], device=local_rank,
+                                         noise=k.NOISE_AWGN, seed=2016)
+            ba.update_steps_dev(yy.data_ptr(), N, T)
+            ba.synchronize()
+            warm_clocks()
+            sa = torch.cuda.ExternalStream(ba.stream())
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(sa)
+            for _ in range(3):
+                ba.update_steps_dev(yy.data_ptr(), N, T)
+            a1.record(sa)
+            ba.synchronize()
+            ams = a0.elapsed_time(a1) / 3
+            fused["awgn"] = {"steps_per_launch": T, "ms_per_launch": ams, "value": N * T / (ams * 1e-3), "errors": int(np.count_nonzero(ba.status())),
+                             "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev, AWGN drawn in the kernel)"}
+            del ba
         del yy
     torch.cuda.empty_cache()   # (the headline batch stays: warm_clocks() runs it before every later timed region)
 

@@ -229,11 +229,8 @@ bool launch_srif_pair_f64c(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32d(const Batch &b, const StepArgs &a);  // kb_srif_pair32d.hip / 64d.hip: 6, 8, 10 states, p = 5 / 6
 bool launch_srif_pair_f64d(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32e(const Batch &b, const StepArgs &a);  // kb_srif_pair32e.hip / 64e.hip: 6, 8, 10 (fp32: and 12) states, p = 7 / 8
-bool launch_srif_pair_f64e(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32f(const Batch &b, const StepArgs &a);  // kb_srif_pair32f/g.hip, 64f/g.hip: 14 and 16 states, p = 1 .. 6
 bool launch_srif_pair_f32g(const Batch &b, const StepArgs &a);
-bool launch_srif_pair_f64f(const Batch &b, const StepArgs &a);
-bool launch_srif_pair_f64g(const Batch &b, const StepArgs &a);
 // traj != nullptr: keep every run's State() and Measurement() per step (Batch::d_traj layout)
 int launch_mc(const Batch &b, const StepArgs &a, const void *d_controls, int ncontrols, double *d_sums, void *traj, int64_t traj_ld);
 int mc_repl();

@@ -199,14 +199,16 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
 }
 
 // fp64 shapes of the split-lane kernel (kb_srif_split.h, round 5): every odd n and n < 6 (natively, no widened shadow blocks), 13..16
-// states with any p <= 8, Update and Predict.  KB_SRIF_SPLIT_ALL=1 (environment, diagnostic) sends every fp64 shape there.
+// states, p = 7, 8 at any n; Update and Predict.  KB_SRIF_SPLIT_ALL=1 (environment, diagnostic) sends every fp64 shape there.
 static bool srif_split_all() {
     static const bool on = [] { const char *e = getenv("KB_SRIF_SPLIT_ALL"); return e && *e && *e != '0'; }();
     return on;
 }
 bool srif_split_ok(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || (a.flags & KB_FLAG_STATEMENT_KERNELS) || a.n < 1 || a.n > 16 || a.p < 1 || a.p > 8) return false;
-    return (a.n & 1) || a.n < 6 || a.n > 12 || srif_split_all();
+    // (measured, 256k filters: the split kernel wins at p = 7, 8 -- 12/8 232 us against 390, 8/8 140 against 172 -- and at 12/5, 201 against
+    // 234; the two-lane kernel keeps the other even shapes up to 12 states: 12/6 214 against 235, 6/2 39 against 64)
+    return (a.n & 1) || a.n < 6 || a.n > 12 || a.p > 6 || (a.n == 12 && a.p == 5) || srif_split_all();
 }
 static int launch_srif_split(const Batch &b, const StepArgs &a) {
     typedef void (*launch_t)(const Batch &, const StepArgs &);
@@ -226,7 +228,7 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if (srif_split_ok(b, a)) return true;
     if ((a.n & 1) || a.n < 6) return srif_odd_ok(b, a);
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
-    if (a.n == 14 || a.n == 16) return !a.predict && a.p >= 1 && a.p <= 6;   // (Update only: kb_srif_pair32f.hip ...)
+    if (a.n == 14 || a.n == 16) return b.dtype == KB_F32 && !a.predict && a.p >= 1 && a.p <= 6;   // (fp32, Update only: kb_srif_pair32f.hip ...)
     if (a.n != 6 && a.n != 8 && a.n != 10 && a.n != 12) return false;
     return a.p >= 1 && a.p <= 8;
 }
@@ -238,7 +240,7 @@ int launch_srif(const Batch &b, const StepArgs &a) {
     if (a.state == b.d_state) b.sh_state_current = false;   // (every other kernel writes the state block itself: a widened copy of it is stale)
     bool done = false;
     if (!a.predict) done = b.dtype == KB_F32 ? (launch_srif_pair_f32(b, a) || launch_srif_pair_f32b(b, a) || launch_srif_pair_f32c(b, a) || launch_srif_pair_f32d(b, a) || launch_srif_pair_f32e(b, a) || launch_srif_pair_f32f(b, a) || launch_srif_pair_f32g(b, a))
-                                             : (launch_srif_pair_f64(b, a) || launch_srif_pair_f64b(b, a) || launch_srif_pair_f64c(b, a) || launch_srif_pair_f64d(b, a) || launch_srif_pair_f64e(b, a) || launch_srif_pair_f64f(b, a) || launch_srif_pair_f64g(b, a));   // kb_srif_pair.h
+                                             : (launch_srif_pair_f64(b, a) || launch_srif_pair_f64b(b, a) || launch_srif_pair_f64c(b, a) || launch_srif_pair_f64d(b, a));   // kb_srif_pair.h
     else if (b.dtype == KB_F32) done = srif_try_predict<float, 12, 6>(b, a) || srif_try_predict<float, 6, 2>(b, a) || srif_try_predict<float, 8, 2>(b, a) || srif_try_predict<float, 8, 4>(b, a) ||
                                        srif_try_predict<float, 10, 2>(b, a) || srif_try_predict<float, 10, 4>(b, a) || srif_try_predict<float, 12, 2>(b, a) || srif_try_predict<float, 12, 4>(b, a);
     else done = srif_try_predict<double, 6, 2>(b, a) || srif_try_predict<double, 12, 6>(b, a) || srif_try_predict<double, 8, 2>(b, a) || srif_try_predict<double, 8, 4>(b, a) ||

@@ -251,6 +251,7 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
         done = launch_vanilla_shared(b, a);   // one model for the whole batch: kb_vanilla_shared.hip
     if (!done && reg && !(a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind != KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_noise(b, a) || launch_vanilla_noise_padded(b, a);   // AWGN / BatchNoise on the register kernels
+    if (!done && fused && a.noise_kind != KB_NOISE_NOISELESS) done = launch_vanilla_noise_fused(b, a);   // (vanilla_fused_ok said yes)
     if (reg && (a.flags & KB_FLAG_STRICT_SYMCHECK) && a.noise_kind == KB_NOISE_NOISELESS && b.dtype == KB_F64 && !fused && a.nsteps == 1)
         done = launch_vanilla_strict(b, a);
     if (special && !done) {
@@ -276,9 +277,16 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
 // Is there a time-fused register kernel (state carried in registers over a.nsteps steps) for this batch?  Only the benchmark
 // shapes have one (try_reg<.., WITH_FUSED>); for everything else kb_update_steps_dev enqueues one single-step register launch
 // per step (kb_api.hip) rather than dropping to the multi-step statement kernel.
-bool vanilla_fused_ok(const Batch &, const StepArgs &a) {
+bool vanilla_noise_fused_ok(const Batch &b, const StepArgs &a) {
+    if (a.flags & (KB_FLAG_STRICT_SYMCHECK | KB_FLAG_STATEMENT_KERNELS | KB_FLAG_FULL_ESTIMATE)) return false;
+    if (b.dtype != KB_F64 || a.predict || a.mo_ts == 0 || (a.need_ctrl ? a.m : 0) != 0) return false;
+    return (a.noise_kind == KB_NOISE_AWGN || a.noise_kind == KB_NOISE_BATCH) && a.n == 6 && a.p == 3;
+}
+
+bool vanilla_fused_ok(const Batch &b, const StepArgs &a) {
     if (a.flags & (KB_FLAG_STRICT_SYMCHECK | KB_FLAG_STATEMENT_KERNELS)) return false;
-    if (a.noise_kind != KB_NOISE_NOISELESS || (a.need_ctrl ? a.m : 0) != 0) return false;
+    if (a.noise_kind != KB_NOISE_NOISELESS) return vanilla_noise_fused_ok(b, a);
+    if ((a.need_ctrl ? a.m : 0) != 0) return false;
     return (a.n == 6 && a.p == 3) || (a.n == 4 && a.p == 2);
 }
 

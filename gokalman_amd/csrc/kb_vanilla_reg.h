@@ -134,7 +134,10 @@ __device__ __forceinline__ void tri_times(const T (&L)[tri(NV)], const T (&z)[NV
 
 template <typename T, int NS, int NM, int NC, bool FULL, bool PREDICT, bool FUSED, bool PAD = false, bool NOISE = false, bool SHARED = false>
 __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(T) * (NS * NS + NS * NM) > 8 * 56)) ? 1 : 2) vanilla_reg_kernel(const StepArgs a) {
-    static_assert(!(NOISE && FUSED), "the time-fused variant is Noiseless");
+    // FASTJ: the time-fused Noiseless kernel's own arithmetic (distributed Joseph form, Newton reciprocals).  The time-fused NOISE kernel
+    // (round 5) keeps the per-step kernel's operations in its order instead: kb_update_steps_dev(T) with AWGN / BatchNoise is
+    // bit-identical to T calls of kb_update_dev (tests/test_kinds_gpu.py), and the draws, not the Joseph form, are what it spends on.
+    constexpr bool FASTJ = FUSED && !NOISE;
     constexpr int TR = tri(NS);
     constexpr int TM = tri(NM);
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;   // real sizes (compile-time constants unless PAD)
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
             __builtin_amdgcn_sched_barrier(0);   // the draws stay behind the gain (see the comment above draw_normals)
             // (global filter index and kf.step are formed HERE, not at the top: nothing of the noise path is alive in the load phase)
             const uint64_t gfi = (uint64_t)(a.first_filter + tile * KB_TILE) + lane;
-            const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
+            const uint32_t stepno = (uint32_t)a.step0 + (uint32_t)t - nfail - (active ? a.lag[tile * KB_TILE + lane] : 0u);   // kf.step of this filter
             if (awgn) {
                 // all the normals first (only they are alive beside the filter's own values while the fp64 log / sincospi run),
                 // then chol(Q) is formed ONCE (from Q, kept alive until here) and applied to both Process draws; w' waits in
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
                 for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
                 S[r * NM + c] = s + R[symi(r, c)];
             }
-        unsigned err = inverse_lu<T, NM, FUSED>(S, Si, rp) ? KB_ST_SINGULAR : 0u;
+        unsigned err = inverse_lu<T, NM, FASTJ>(S, Si, rp) ? KB_ST_SINGULAR : 0u;
         T K[NS * NM];
 #pragma unroll
         for (int i = 0; i < NS; i++)
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
                 for (int r = 0; r < NM; r++) park[(NM + r) * 64] = innov[r];
             }
-            if constexpr (FUSED) {
+            if constexpr (FASTJ) {
                 // ---- Joseph form with both multiplications by A = I - K H distributed (kb_vanilla_split.h has the argument):
                 //   AP = P- - K (P- H^T)^T,   P+ = AP + (K R - AP H^T) K^T     [= A P- A^T + K R K^T, vanilla.go:197-205]
                 // 333 FMAs where forming A, A P- and (A P-) A^T takes 567, and no 6 x 6 A in the register file.  The time-fused
@@ -616,6 +619,8 @@ bool launch_vanilla_padded(const Batch &b, const StepArgs &a);
 bool launch_vanilla_padded8(const Batch &b, const StepArgs &a);
 // AWGN / BatchNoise batches (kb_vanilla_noise.hip, kb_vanilla_noise_pad.hip): every shape up to n = 8, p = 4, m = 2, fp64
 bool launch_vanilla_noise(const Batch &b, const StepArgs &a);
+bool launch_vanilla_noise_fused(const Batch &b, const StepArgs &a);   // kb_vanilla_noise.hip: T steps in one launch, AWGN / BatchNoise, 6 / 3
+bool vanilla_noise_fused_ok(const Batch &b, const StepArgs &a);      // kb_vanilla.hip
 bool launch_vanilla_noise_padded(const Batch &b, const StepArgs &a);
 // KB_FLAG_STRICT_SYMCHECK batches (kb_vanilla_strict.hip): both triangles, AsSymDense's test, the oracle's rounding; n <= 6, p <= 4, m <= 2
 bool launch_vanilla_strict(const Batch &b, const StepArgs &a);

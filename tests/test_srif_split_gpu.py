@@ -11,8 +11,9 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
-# (the kernel serves: every odd n, n < 6, and 13..16 states, any p <= 8)
-SHAPES = [(1, 1), (3, 2), (5, 4), (7, 3), (7, 8), (9, 5), (11, 4), (11, 7), (13, 2), (13, 8), (14, 4), (15, 3), (15, 6), (16, 6), (16, 8), (16, 1)]
+# (the kernel serves: every odd n, n < 6, 13..16 states with any p <= 8, and p = 7, 8 / 12 states with p = 5 at the even n up to 12)
+SHAPES = [(1, 1), (2, 2), (3, 2), (4, 3), (5, 4), (7, 3), (7, 8), (9, 5), (11, 4), (11, 7), (13, 2), (13, 8), (14, 4), (15, 3), (15, 6), (16, 6), (16, 8), (16, 1),
+          (6, 7), (8, 8), (10, 7), (12, 8), (12, 5)]
 
 
 def _inputs(rng, N, n, p, steps, mix=1e-2):
