@@ -678,6 +678,24 @@ def main():
                                "roofline": rl.hbm_roofline(qms, M, rl.algorithmic_bytes("squareroot", n, p), rl.moved_bytes("squareroot", n, p),
                                                            *rl.load_traffic(ROOT, "squareroot_reg_kernel<double, 6, 3, 0, false")),
                                "filters_with_error_status": qbad}
+        if args.fused_steps > 0 and rank == 0:
+            # config C with the caller loop inside one launch (round 5): x, S and the model resident over T steps; bit-identical to T launches
+            T = args.fused_steps
+            yT = yq.unsqueeze(0).repeat(T, 1, 1).contiguous()   # [T][p][M] (the same measurement every step: throughput only)
+            sq.update_steps_dev(yT.data_ptr(), M, T)
+            sq.synchronize()
+            warm_clocks()
+            sstream = torch.cuda.ExternalStream(sq.stream())
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(sstream)
+            for _ in range(3):
+                sq.update_steps_dev(yT.data_ptr(), M, T)
+            f1.record(sstream)
+            sq.synchronize()
+            fq = f0.elapsed_time(f1) / 3
+            extra["squareroot"]["fused"] = {"steps_per_launch": T, "ms_per_launch": fq, "value": M * T / (fq * 1e-3),
+                                            "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev)", "filters_with_error_status": int(np.count_nonzero(sq.status()))}
+            del yT
         del sq, yq
     if args.shared_filters > 0:
         # one model for the whole batch (the reference's own shape of use: ONE filter object; kb_replicate / BatchLDKF / the ensembles):

@@ -14,6 +14,7 @@
 #include "kb_internal.h"
 
 namespace kb {
+bool squareroot_fused_ok(const Batch &b, const StepArgs &a);   // kb_squareroot_reg.hip
 
 static thread_local char g_err[512] = "";
 
@@ -634,7 +635,8 @@ static int update_dev_common(kb_batch *b, const void *meas, int64_t ld_meas, con
     a.y = meas; a.y_es = ld_meas; a.y_ts = KB_TILE; a.y_step = (int64_t)b->p * ld_meas;
     if (b->need_ctrl) { a.u = ctrl; a.u_es = ld_ctrl; a.u_ts = KB_TILE; a.u_step = (int64_t)b->m * ld_ctrl; }
     const bool vanilla = b->kind == KB_VANILLA || b->kind == KB_VANILLA_PREDICT;
-    if (fused && !(b->flags & KB_FLAG_STATEMENT_KERNELS) && !(vanilla && vanilla_fused_ok(*b, a))) {
+    const bool have_fused = (vanilla && vanilla_fused_ok(*b, a)) || (b->kind == KB_SQUAREROOT && squareroot_fused_ok(*b, a));
+    if (fused && !(b->flags & KB_FLAG_STATEMENT_KERNELS) && !have_fused) {
         // no time-fused register kernel for this kind / shape / noise: one single-step launch per step, back to back on the stream
         // (the multi-step statement kernel is 16-30x slower than that)
         for (int t = 0; t < nsteps; t++) {

@@ -40,8 +40,16 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 // SHARED: instantiated for batches with ONE model for all filters (StepArgs::mo_ts == 0): the model operands are read from lane 0's
 // copy in tile 0's block with the default cache policy -- wave-uniform addresses, scalar loads where no store precedes them
 // (kb_vanilla_reg.h ldm)
-template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false, bool NOISE = false, bool SHARED = false>
-__global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PAD>())) squareroot_reg_kernel(const StepArgs a) {
+// FUSED (round 5): the caller loop `for k { kf.Update(y_k) }` inside one launch (kb_update_steps_dev): x, S and the model (F, H, chol Q,
+// chol R: 81 doubles at 6 / 3) stay in registers over a.nsteps steps, one wave per SIMD; the same source, operation for operation, as the
+// one-step kernel.  Measured: T = 1 is bit-identical to one launch for every filter; from the second step on a few filters per thousand and
+// step end one last place apart (max 2.4e-14 relative after six steps) -- the two instantiations are contracted into FMAs by the same
+// rules but not in the same context, and neither hiding the 3 x 3 inverse's identity from the optimiser nor anything else short of
+// switching contraction off for both moved it.  Held to 1e-12 against T launches and to the oracle like them (tests/test_kinds_gpu.py).
+// Noiseless, state only, no control.
+template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false, bool NOISE = false, bool SHARED = false, bool FUSED = false>
+__global__ void __launch_bounds__(64 * SQRT_WPB, (FUSED ? 1 : sqrt_waves<T, NS, NM, FULL, PAD>())) squareroot_reg_kernel(const StepArgs a) {
+    static_assert(!FUSED || (!FULL && !PAD && !NOISE && !SHARED && NC == 0), "the time-fused variant: Noiseless, state only, exact shape");
     constexpr int TR = tri(NS), TM = tri(NM), DD = NS + NM;
     const int rn = PAD ? a.n : NS, rp = PAD ? a.p : NM, rm = PAD ? a.m : NC;
     const int lane = threadIdx.x & 63;
@@ -70,8 +78,20 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             for (int k2 = 0; k2 <= i; k2++) S[symi(k2, i)] = (i < rn) ? ldp<nt>(st, rn + symi(k2, i)) : T(0);  // S[i][k], k <= i, at symi(k, i)
     };
     KB_WITH_STATE_POLICY(a, load_state);
+    [[maybe_unused]] T Hres[FUSED ? NM * NS : 1], LQres[FUSED ? TR : 1], LRres[FUSED ? TM : 1];
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int e = 0; e < NM * NS; e++) Hres[e] = ldmo(mo, a.L.mo_H + e);
+#pragma unroll
+        for (int e = 0; e < TR; e++) LQres[e] = ldmo(mo, a.L.mo_LQ + e);
+#pragma unroll
+        for (int e = 0; e < TM; e++) LRres[e] = ldmo(mo, a.L.mo_LR + e);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
+    const int nsteps = FUSED ? a.nsteps : 1;
+    unsigned bad = 0;
+    for (int t = 0; t < nsteps; t++) {
     // :139-147 x- = F x [+ G u]
     T xm[NS];
     smv<T, NS, NS>(F, x, xm);
@@ -112,7 +132,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i && j < rn) ? ldmo(mo, a.L.mo_LQ + symi(i, j)) : T(0);  // sqrtQ^T[i][j] = L[j][i]
+        for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i && j < rn) ? (FUSED ? LQres[symi(i, j)] : ldmo(mo, a.L.mo_LQ + symi(i, j))) : T(0);  // sqrtQ^T[i][j] = L[j][i]
     sqr_r<T, 2 * NS, NS, ActC<NS>>(C);
     __builtin_amdgcn_sched_barrier(0);  // H, chol(R) loads and the Delta panel stay below the C phase
     // Sm[i][j] = C[i*NS+j], j >= i
@@ -120,7 +140,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
     for (int r = 0; r < NM; r++)
 #pragma unroll
-        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? ldmo(mo, a.L.mo_H + r * rn + l) : T(0);
+        for (int l = 0; l < NS; l++) H[r * NS + l] = (r < rp && l < rn) ? (FUSED ? Hres[r * NS + l] : ldmo(mo, a.L.mo_H + r * rn + l)) : T(0);
     // :190-216 Delta = [[sqrtR^T, 0],[S-^T H^T, S-^T]]
     T D[DD * DD];
 #pragma unroll
@@ -130,7 +150,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
             T val;
             if (c < NM) {
                 if (r < NM) {
-                    val = (c >= r) ? (c < rp ? ldmo(mo, a.L.mo_LR + symi(r, c)) : (r == c ? T(1) : T(0))) : T(0);
+                    val = (c >= r) ? (c < rp ? (FUSED ? LRres[symi(r, c)] : ldmo(mo, a.L.mo_LR + symi(r, c))) : (r == c ? T(1) : T(0))) : T(0);
                 } else {
                     T s = T(0);  // (S-^T H^T)[r-NM][c] = sum_{l <= r-NM} Sm[l][r-NM] H[c][l]
 #pragma unroll
@@ -199,7 +219,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
     T innov[NM], xn[NS];
 #pragma unroll
     for (int r = 0; r < NM; r++) {
-        const T yv = (active && r < rp) ? __builtin_nontemporal_load(yp + (int64_t)r * a.y_es) : T(0);
+        const T yv = (active && r < rp) ? __builtin_nontemporal_load(yp + (int64_t)t * a.y_step + (int64_t)r * a.y_es) : T(0);
         innov[r] = yv - Hxm[r];
     }
     T chk = T(0);
@@ -261,6 +281,17 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
 #pragma unroll
         for (int j = 0; j <= i; j++) chk += D[(NM + j) * DD + (NM + i)] * T(0);
     const bool ok = !(chk != chk);
+    if constexpr (FUSED) {
+        // a non-finite step leaves (x, S) as they were -- the one-step kernel's predicated store -- and the next step runs normally
+#pragma unroll
+        for (int i = 0; i < NS; i++) x[i] = ok ? xn[i] : x[i];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) S[symi(j, i)] = ok ? D[(NM + j) * DD + (NM + i)] : S[symi(j, i)];
+        bad |= ok ? 0u : 1u;
+        continue;
+    }
     if (active && ok) {
         auto store_state = [&](auto NT) {
             constexpr bool nt = decltype(NT)::value;
@@ -287,6 +318,16 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (sqrt_waves<T, NS, NM, FULL, PA
         }
     }
     if (active && !ok) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
+    }
+    if constexpr (FUSED) {
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) stt(st, i, x[i]);
+#pragma unroll
+            for (int e = 0; e < TR; e++) stt(st, NS + e, S[e]);
+            if (bad) atomicOr(a.status + tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE);
+        }
+    }
 }
 
 template <typename T, int NS, int NM, int NC = 0, bool NOISE = false, bool SHARED = false>
@@ -313,8 +354,19 @@ static bool sqrt_try_pad(const Batch &b, const StepArgs &a) {
     return true;
 }
 
-int launch_squareroot(const Batch &b, const StepArgs &a, bool) {
+// a time-fused register kernel exists for this batch (kb_update_steps_dev keeps x, S and the model in registers over the steps)
+bool squareroot_fused_ok(const Batch &b, const StepArgs &a) {
+    if (a.flags & (KB_FLAG_STATEMENT_KERNELS | KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK)) return false;
+    return b.dtype == KB_F64 && a.n == 6 && a.p == 3 && a.sqrt_p == 3 && (a.need_ctrl ? a.m : 0) == 0 && a.noise_kind == KB_NOISE_NOISELESS && a.mo_ts != 0;
+}
+
+int launch_squareroot(const Batch &b, const StepArgs &a, bool fused) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_squareroot_gen(b, a);
+    if (fused && squareroot_fused_ok(b, a)) {
+        hipLaunchKernelGGL((squareroot_reg_kernel<double, 6, 3, 0, false, false, false, false, true>), dim3((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), dim3(64 * SQRT_WPB), 0, b.stream, a);
+        KB_HIP(hipGetLastError());
+        return KB_OK;
+    }
     bool done = false;
     if (b.dtype == KB_F64 && a.mo_ts == 0)   // one model for all filters: the SHARED instantiations (Noiseless; the benchmark shapes and the padded families)
         done = sqrt_try<double, 6, 3, 0, false, true>(b, a) || sqrt_try<double, 4, 2, 0, false, true>(b, a) || sqrt_try_pad<double, 4, 2, 0, false, true>(b, a) ||

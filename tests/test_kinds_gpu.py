@@ -773,10 +773,11 @@ def test_information_full_estimate_on_the_register_kernels(n, p, m, awgn, from_s
 @pytest.mark.parametrize("kind,flags,n,p,noise", [(k.SQUAREROOT, 0, 6, 3, k.NOISE_NOISELESS), (k.INFORMATION, k.FLAG_INFO_FROM_STATE, 6, 3, k.NOISE_NOISELESS),
                                                  (k.VANILLA, 0, 5, 2, k.NOISE_NOISELESS), (k.VANILLA, 0, 6, 3, k.NOISE_AWGN),
                                                  (k.VANILLA, k.FLAG_STRICT_SYMCHECK, 6, 3, k.NOISE_NOISELESS), (k.SQUAREROOT, 0, 4, 2, k.NOISE_AWGN)])
-def test_update_steps_dev_without_a_fused_kernel_runs_the_register_kernel_per_step(kind, flags, n, p, noise):
-    """kb_update_steps_dev(T steps) on a kind / shape / noise that has no time-fused register kernel enqueues T single-step
-    register launches (kb_api.hip update_dev_common) instead of the multi-step statement kernel: bit-identical to T calls of
-    kb_update_dev, kf.step advanced by T, and (Noiseless) the oracle's numbers."""
+def test_update_steps_dev_equals_single_steps(kind, flags, n, p, noise):
+    """kb_update_steps_dev(T steps): a kind / shape / noise without a time-fused register kernel enqueues T single-step register
+    launches (kb_api.hip update_dev_common) instead of the multi-step statement kernel; Vanilla 6/3 with AWGN and SquareRoot 6/3 have
+    time-fused kernels of their own (round 5).  Bit-identical to T calls of kb_update_dev (SquareRoot fused: to 1e-12), kf.step advanced
+    by T, and (Noiseless) the oracle's numbers."""
     import torch
     N, steps = 1000, 6
     d = synth.linear_batch(N, 6, 3, steps, seed=77)
@@ -794,8 +795,16 @@ def test_update_steps_dev_without_a_fused_kernel_runs_the_register_kernel_per_st
         b.synchronize()
         assert b.step() == steps and not b.status().any()
         res.append((b.get(k.STATE), b.get(k.COVAR)))
-    assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
-    assert np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
+    if kind == k.SQUAREROOT and n == 6 and p == 3 and noise == k.NOISE_NOISELESS:
+        # the time-fused SquareRoot kernel (round 5): the one-step kernel's source in a loop; a few filters per thousand and step end one
+        # last place apart (csrc/kb_squareroot_reg.hip), so: the same to 1e-12, and most filters the same bits
+        ex, eP = synth.rel_frobenius(res[0][0], res[1][0]), synth.rel_frobenius(res[0][1], res[1][1])
+        same = np.mean(np.all(res[0][0] == res[1][0], axis=1))
+        print("fused SquareRoot against %d launches: state %.2e covariance %.2e, %.1f %% of the filters bit-identical" % (steps, ex, eP, 100 * same))
+        assert ex <= 1e-12 and eP <= 1e-12
+    else:
+        assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
+        assert np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
     if noise == k.NOISE_NOISELESS:
         okind = {k.SQUAREROOT: orc.SQUAREROOT, k.INFORMATION: orc.INFORMATION, k.VANILLA: orc.VANILLA}[kind]
         xo, Po, _ = orc.ldkf_batch(okind, x0[:64], sl["P0"][:64], sl["F"][:64], H[:64], sl["Q"][:64], R[:64], d["y"][:, :64, :p])
