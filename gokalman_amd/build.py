@@ -32,7 +32,7 @@ def _hipcc():
 # `#pragma unroll` (16k cost units) a loop silently stays rolled, its register arrays become scratch arrays
 _PAIR = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]
 _UNROLL = ["-mllvm", "-pragma-unroll-threshold=200000"]
-EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR, "kb_srif_pair32b.hip": _PAIR, "kb_srif_pair64b.hip": _PAIR, "kb_srif_pair32c.hip": _PAIR, "kb_srif_pair64c.hip": _PAIR, "kb_srif_pair32d.hip": _PAIR, "kb_srif_pair64d.hip": _PAIR, "kb_srif_pair32e.hip": _PAIR, "kb_srif_pair32f.hip": _PAIR, "kb_srif_pair32g.hip": _PAIR, "kb_srif_pair64g6.hip": _PAIR,
+EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR, "kb_srif_pair32b.hip": _PAIR, "kb_srif_pair32c.hip": _PAIR, "kb_srif_pair32d.hip": _PAIR, "kb_srif_pair32e.hip": _PAIR, "kb_srif_pair32f.hip": _PAIR, "kb_srif_pair32g.hip": _PAIR, "kb_srif_pair64g6.hip": _PAIR,
          "kb_vanilla_split12.hip": _UNROLL, "kb_vanilla_split16.hip": _UNROLL, "kb_vanilla_split12p.hip": _UNROLL, "kb_hybrid_split.hip": _UNROLL, "kb_hybrid_split8.hip": _UNROLL, "kb_vanilla_split16p.hip": _UNROLL, "kb_squareroot_split12.hip": _UNROLL, "kb_squareroot_split12p.hip": _UNROLL, "kb_squareroot_split16p.hip": _UNROLL, "kb_squareroot_split16.hip": _UNROLL, "kb_information_split12.hip": _UNROLL, "kb_information_split8.hip": _UNROLL, "kb_information_split12f.hip": _UNROLL,
          "kb_srif_split_a.hip": _UNROLL, "kb_srif_split_b.hip": _UNROLL, "kb_srif_split_c.hip": _UNROLL, "kb_srif_split_d.hip": _UNROLL, "kb_srif_split_e.hip": _UNROLL}
 
@@ -77,9 +77,23 @@ def _compile(src, force):
     return obj
 
 
+# translation units that take the longest to compile (seconds on this image), for the scheduling order of a build from scratch
+_SLOW = {"kb_srif_pair32g.hip": 150, "kb_srif_pair32f.hip": 110, "kb_information_reg.hip": 100, "kb_vanilla_shared.hip": 90, "kb_srif_pair32c.hip": 80,
+         "kb_srif_pair32b.hip": 70, "kb_srif_pair32e.hip": 70, "kb_srif_reg.hip": 60, "kb_srif_pair64.hip": 55, "kb_squareroot_reg.hip": 45,
+         "kb_srif_pair32d.hip": 40, "kb_vanilla_strict.hip": 40, "kb_hybrid_pad8.hip": 35, "kb_srif_pair32.hip": 35}
+
+
+def _cost(src):
+    base = os.path.basename(src)
+    obj = os.path.join(OBJ, base + ".o")
+    if base in _SLOW:
+        return _SLOW[base] * 1e6
+    return os.path.getsize(obj) if os.path.exists(obj) else os.path.getsize(src)
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")), key=_cost, reverse=True)   # longest first: the tail of the build is not one late giant
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if (force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):

@@ -223,11 +223,8 @@ Layout make_layout(int kind, int n, int pmax, int m, unsigned flags);   // kb_ap
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip
 bool launch_srif_pair_f32b(const Batch &b, const StepArgs &a);  // kb_srif_pair32b.hip / 64b.hip: 8 / 10 states, p = 2 / 4
-bool launch_srif_pair_f64b(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32c(const Batch &b, const StepArgs &a);  // kb_srif_pair32c.hip / 64c.hip: 12 states, p = 1 .. 5
-bool launch_srif_pair_f64c(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32d(const Batch &b, const StepArgs &a);  // kb_srif_pair32d.hip / 64d.hip: 6, 8, 10 states, p = 5 / 6
-bool launch_srif_pair_f64d(const Batch &b, const StepArgs &a);
 bool launch_srif_pair_f32e(const Batch &b, const StepArgs &a);  // kb_srif_pair32e.hip / 64e.hip: 6, 8, 10 (fp32: and 12) states, p = 7 / 8
 bool launch_srif_pair_f32f(const Batch &b, const StepArgs &a);  // kb_srif_pair32f/g.hip, 64f/g.hip: 14 and 16 states, p = 1 .. 6
 bool launch_srif_pair_f32g(const Batch &b, const StepArgs &a);

@@ -19,7 +19,13 @@ def test_gpu_suite_with_fenced_device_blocks():
     env = dict(os.environ, KB_DEBUG_FENCE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
                         "--deselect", "tests/test_fence_gpu.py"],
-                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
-    tail = "\n".join(r.stdout.splitlines()[-25:])
-    assert r.returncode == 0, "fenced run failed (a memory access fault aborts the run):\n" + tail
-    assert " passed" in tail and "failed" not in tail, tail
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1000)
+    lines = r.stdout.splitlines()
+    # what failed INSIDE goes first (the outer run shows one failing test and a tail): the nested test ids, the fault message if the
+    # process died of one, the summary line -- and only then the last lines of the log
+    inner = [ln for ln in lines if ln.startswith("FAILED ") or ln.startswith("ERROR ") or "Memory access fault" in ln or "HSA_STATUS" in ln or "Aborted" in ln]
+    summary = [ln for ln in lines if " passed" in ln or " failed" in ln][-1:]
+    tail = "\n".join(lines[-25:])
+    head = "fenced run (KB_DEBUG_FENCE=1) exit code %d; inner failures: %s; %s" % (r.returncode, inner or "none reported (the process died: a fault?)", summary)
+    assert r.returncode == 0, head + "\n" + tail
+    assert " passed" in tail and "failed" not in tail, head + "\n" + tail

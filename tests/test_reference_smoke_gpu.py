@@ -41,9 +41,9 @@ def test_midterm2_awgn_run_setters_reset_and_dimension_errors(kind, okind, tol):
         assert f.update(np.array([YACC[step]]), np.zeros(1), w1, v, w2) == orc.OK
         xs = est.state()[0]
         assert within(np.linalg.norm(xs - f.state()) / max(np.linalg.norm(f.state()), 1e-3), tol, "state"), step
-        within = bool(est.is_within_nsigma(2)[0])
-        assert within == bool(f.is_within_nsigma(2)), step
-        breaches += (not within)
+        inside = bool(est.is_within_nsigma(2)[0])
+        assert inside == bool(f.is_within_nsigma(2)), step
+        breaches += (not inside)
     assert kf.step() == 99
     assert within(synth.rel_frobenius(est.covariance(), f.covariance()[None]), max(tol, 1e-8), "covariance")
     # Reset (vanilla_test.go:78-84)
