@@ -391,7 +391,7 @@ void kb_destroy(kb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_est, b->d_model, b->d_status,
-                    b->d_sh_state, b->d_sh_model, b->d_sh_est, b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
+                    b->d_sh_state, b->d_sh_model, b->d_sh_est, b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_chi_table, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
                     b->h_lag ? nullptr : (void *)b->d_lag, (void *)b->d_srif_dense};
     for (void *p : ptrs)
         if (p) (void)dev_free(p);

@@ -488,6 +488,337 @@ __global__ void __launch_bounds__(64) chisq_gen_kernel(const ChiArgs a, int n, i
     }
 }
 
+// =====================================================================================
+// Every other shape with ONE filter fanned out (round 5; chisquare.go:16-95 is shape-generic and NewChiSquare takes ONE kf and the runs
+// of ONE Monte-Carlo filter): the covariance recursion of the tested filter does not see the measurements -- P-, S, K, P+ and the two
+// inverses the statistics need are the same for every run, bit for bit, because every run performs the same operations on the same
+// numbers.  chisq_cov_kernel runs that recursion ONCE (one workgroup, matrices in LDS, chisq_gen_kernel's sums in its order) and writes
+// per step K | inverse(P+) | inverse(H P- H^T + R); chisq_shared_kernel then advances one run per lane with only the truth state and the
+// filter state in registers (2 n doubles), the models in LDS as broadcast operands (mc_gen_kernel's way) and the step's table entries
+// read at wave-uniform addresses: ~3.5 n^2 FMAs and the draws per run-step where the whole Update takes ~10 n^3.
+// =====================================================================================
+// inverse(M) by Gauss-Jordan elimination with partial pivoting (first largest entry of the column, as dgetf2 picks), the whole workgroup on
+// matrices in LDS: M (leading dimension ld) is destroyed, X receives the inverse.  (One thread running the statement kernels' LU routine
+// on private arrays took 0.35 ms per step at 12 states -- a dependent chain through scratch memory; this takes microseconds.)
+template <typename T>
+__device__ void lds_inverse(int n, int ld, T *M, T *X, T *col, int *pivot) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < n * n; e += nt) X[(e / n) * ld + e % n] = (e / n == e % n) ? T(1) : T(0);
+    for (int k = 0; k < n; k++) {
+        __syncthreads();
+        if (tid == 0) {
+            int piv = k;
+            T best = fabs(M[k * ld + k]);
+            for (int i = k + 1; i < n; i++) {
+                const T v = fabs(M[i * ld + k]);
+                if (v > best) { best = v; piv = i; }
+            }
+            *pivot = piv;
+        }
+        __syncthreads();
+        const int piv = *pivot;
+        if (piv != k) {
+            for (int c = tid; c < 2 * n; c += nt) {
+                T *A = c < n ? M : X;
+                const int cc = c < n ? c : c - n;
+                const T t0 = A[k * ld + cc], t1 = A[piv * ld + cc];
+                A[k * ld + cc] = t1; A[piv * ld + cc] = t0;
+            }
+        }
+        __syncthreads();
+        const T rinv = T(1) / M[k * ld + k];
+        for (int i = tid; i < n; i += nt) col[i] = M[i * ld + k];   // the column being eliminated, before anybody rewrites it
+        __syncthreads();
+        for (int c = tid; c < 2 * n; c += nt) {   // the pivot row, normalised
+            T *A = c < n ? M : X;
+            const int cc = c < n ? c : c - n;
+            A[k * ld + cc] = A[k * ld + cc] * rinv;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * 2 * n; e += nt) {
+            const int i = e / (2 * n), c = e % (2 * n);
+            if (i == k) continue;
+            T *A = c < n ? M : X;
+            const int cc = c < n ? c : c - n;
+            A[i * ld + cc] -= col[i] * A[k * ld + cc];
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, int LD>
+__global__ void __launch_bounds__(256) chisq_cov_kernel(const ChiArgs a, int n, int p, T *__restrict__ table) {
+    constexpr int PM = 8;
+    __shared__ T sP[LD * LD], sPm[LD * LD], sFP[LD * LD], sF[LD * LD], sQ[LD * LD], sA[LD * LD], sAP[LD * LD], sH[PM * LD], sR[PM * PM], sPHt[LD * PM], sS[PM * PM], sSi[PM * PM],
+        sK[LD * PM], sKR[LD * PM], sPi[LD * LD], sCol[LD];
+    __shared__ int sPiv;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const T *ks = (const T *)a.k_state, *km = (const T *)a.k_model;   // run 0 of tile 0: element e at [e * KB_TILE]
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        sP[i * LD + j] = ldt(ks, a.kL.st_mat + symi(i < j ? i : j, i < j ? j : i));
+        sF[i * LD + j] = ldt(km, a.kL.mo_F + i * n + j);
+        sQ[i * LD + j] = ldt(km, a.kL.mo_Q + symi(i < j ? i : j, i < j ? j : i));
+    }
+    for (int e = tid; e < p * n; e += nt) sH[(e / n) * LD + e % n] = ldt(km, a.kL.mo_H + e);
+    for (int e = tid; e < p * p; e += nt) { const int r = e / p, c = e % p; sR[r * PM + c] = ldt(km, a.kL.mo_R + symi(r < c ? r : c, r < c ? c : r)); }
+    __syncthreads();
+    const int ts = n * p + n * n + p * p;
+    for (int t = 0; t < a.nsteps; t++) {
+        for (int e = tid; e < n * n; e += nt) {   // FP = F P
+            const int i = e / n, k2 = e % n;
+            T sacc = T(0);
+            for (int l = 0; l < n; l++) sacc += sF[i * LD + l] * sP[l * LD + k2];
+            sFP[i * LD + k2] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {   // P- = FP F^T + Q: the upper triangle, mirrored
+            const int i = e / n, j = e % n;
+            if (j >= i) {
+                T sacc = T(0);
+                for (int k2 = 0; k2 < n; k2++) sacc += sFP[i * LD + k2] * sF[j * LD + k2];
+                const T v = sacc + sQ[i * LD + j];
+                sPm[i * LD + j] = v; sPm[j * LD + i] = v;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < n * p; e += nt) {   // P- H^T
+            const int i = e / p, c = e % p;
+            T sacc = T(0);
+            for (int l = 0; l < n; l++) sacc += sPm[i * LD + l] * sH[c * LD + l];
+            sPHt[i * PM + c] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < p * p; e += nt) {   // S = H P- H^T + R
+            const int r2 = e / p, c = e % p;
+            T sacc = T(0);
+            for (int i = 0; i < n; i++) sacc += sH[r2 * LD + i] * sPHt[i * PM + c];
+            sS[r2 * PM + c] = sacc + sR[r2 * PM + c];
+        }
+        __syncthreads();
+        lds_inverse<T>(p, PM, sS, sSi, sCol, &sPiv);   // (S is not needed again: P+ uses K R K^T)
+        for (int e = tid; e < n * p; e += nt) {   // K = P- H^T S^-1
+            const int i = e / p, c = e % p;
+            T sacc = T(0);
+            for (int k2 = 0; k2 < p; k2++) sacc += sPHt[i * PM + k2] * sSi[k2 * PM + c];
+            sK[i * PM + c] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {   // A = I - K H
+            const int i = e / n, j = e % n;
+            T sacc = T(0);
+            for (int c = 0; c < p; c++) sacc += sK[i * PM + c] * sH[c * LD + j];
+            sA[i * LD + j] = (i == j ? T(1) : T(0)) - sacc;
+        }
+        for (int e = tid; e < n * p; e += nt) {   // K R
+            const int i = e / p, c = e % p;
+            T sacc = T(0);
+            for (int k2 = 0; k2 < p; k2++) sacc += sK[i * PM + k2] * sR[k2 * PM + c];
+            sKR[i * PM + c] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {   // A P-
+            const int i = e / n, k2 = e % n;
+            T sacc = T(0);
+            for (int l = 0; l < n; l++) sacc += sA[i * LD + l] * sPm[l * LD + k2];
+            sAP[i * LD + k2] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {   // P+ = A P- A^T + K R K^T: the upper triangle, mirrored
+            const int i = e / n, j = e % n;
+            if (j >= i) {
+                T sacc = T(0), s2 = T(0);
+                for (int k2 = 0; k2 < n; k2++) sacc += sAP[i * LD + k2] * sA[j * LD + k2];
+                for (int c = 0; c < p; c++) s2 += sKR[i * PM + c] * sK[j * PM + c];
+                const T v = sacc + s2;
+                sP[i * LD + j] = v; sP[j * LD + i] = v;
+            }
+        }
+        __syncthreads();
+        if (a.with_nees) {   // inverse(P+) (chisquare.go:50-51), on a copy: P+ carries on
+            for (int e = tid; e < n * n; e += nt) sFP[(e / n) * LD + e % n] = sP[(e / n) * LD + e % n];
+            __syncthreads();
+            lds_inverse<T>(n, LD, sFP, sPi, sCol, &sPiv);
+        }
+        T *row = table + (size_t)t * ts;
+        for (int e = tid; e < n * p; e += nt) row[e] = sK[(e / p) * PM + e % p];
+        for (int e = tid; e < n * n; e += nt) row[n * p + e] = a.with_nees ? sPi[(e / n) * LD + e % n] : T(0);
+        for (int e = tid; e < p * p; e += nt) row[n * p + n * n + e] = sSi[(e / p) * PM + e % p];
+        __syncthreads();
+    }
+}
+
+template <typename T, int NS>
+__global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int n, int p, int nc, const T *__restrict__ table) {
+    constexpr int TQ = tri(NS), PM = 8, TP = tri(PM);
+    __shared__ T sF[NS * NS], sLQ[TQ], sG[NS * 2], sH[PM * NS], sLR[TP], kF[NS * NS], kG[NS * 2], kH[PM * NS];
+    {
+        const T *tm = (const T *)a.t_model, *km = (const T *)a.k_model;   // run 0's model blocks
+        for (int e = threadIdx.x; e < NS * NS; e += blockDim.x) {
+            const int i = e / NS, l = e % NS;
+            sF[e] = (i < n && l < n) ? ldt(tm, a.tL.mo_F + i * n + l) : T(0);
+            kF[e] = (i < n && l < n) ? ldt(km, a.kL.mo_F + i * n + l) : T(0);
+        }
+        for (int e = threadIdx.x; e < TQ; e += blockDim.x) sLQ[e] = e < tri(n) ? ldt(tm, a.tL.mo_LQ + e) : T(0);
+        for (int e = threadIdx.x; e < NS * 2; e += blockDim.x) {
+            const int i = e / 2, c = e % 2;
+            sG[e] = (i < n && c < nc) ? ldt(tm, a.tL.mo_G + i * nc + c) : T(0);
+            kG[e] = (i < n && c < nc) ? ldt(km, a.kL.mo_G + i * nc + c) : T(0);
+        }
+        for (int e = threadIdx.x; e < PM * NS; e += blockDim.x) {
+            const int r = e / NS, l = e % NS;
+            sH[e] = (r < p && l < n) ? ldt(tm, a.tL.mo_H + r * n + l) : T(0);
+            kH[e] = (r < p && l < n) ? ldt(km, a.kL.mo_H + r * n + l) : T(0);
+        }
+        for (int e = threadIdx.x; e < TP; e += blockDim.x) sLR[e] = e < tri(p) ? ldt(tm, a.tL.mo_LR + e) : T(0);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.ntiles) return;
+    const int64_t fi = tile * KB_TILE + lane;
+    const bool active = fi < a.N;
+    const T *ts0 = (const T *)a.t_state, *ks0 = (const T *)a.k_state;   // every run starts from run 0's initial estimate (one filter fanned out)
+    T xt[NS], x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) { xt[i] = i < n ? ldt(ts0, a.tL.st_vec + i) : T(0); x[i] = i < n ? ldt(ks0, a.kL.st_vec + i) : T(0); }
+    const uint64_t gfi = (uint64_t)(a.first_run + fi);
+    double *my = a.sums + (size_t)(tile % CHI_REPL) * a.nsteps * 2;
+    const int tstride = n * p + n * n + p * p;
+    for (int t = 0; t < a.nsteps; t++) {
+        asm volatile("" ::: "memory");   // (the models are re-read from LDS every step, not hoisted into hundreds of registers)
+        const T *row = table + (size_t)t * tstride;
+        T u0 = T(0), u1 = T(0);
+        if (nc > 0 && a.ncontrols != 1) {
+            const T *up = (const T *)a.controls + (int64_t)t * nc;
+            u0 = up[0];
+            u1 = nc > 1 ? up[1] : T(0);
+        }
+        // ---- truth: yhat_k = H x_{k-1} + v_k ; x_k = F x_{k-1} [+ G u_k] + w_k  (vanilla.go:138-157, predictionOnly)
+        T zv[PM], y[PM];
+#pragma unroll
+        for (int k2 = 0; k2 < PM; k2 += 2) {
+            zv[k2] = T(0); zv[k2 + 1] = T(0);
+            if (k2 < p) {   // (wave-uniform)
+                uint32_t r[4];
+                Philox::gen(a.seed, gfi, (uint32_t)t, ((uint32_t)(a.epoch * 4 + 1) << 8) | (uint32_t)(k2 >> 1), r);
+                double z0, z1;
+                box_muller(r, z0, z1);
+                zv[k2] = (T)z0; zv[k2 + 1] = (T)z1;
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < PM; r2++) {
+            T sacc = T(0), v = T(0);
+            if (r2 < p) {
+#pragma unroll
+                for (int l = 0; l < NS; l++) sacc += sH[r2 * NS + l] * xt[l];
+#pragma unroll
+                for (int k2 = 0; k2 <= r2; k2++) v += sLR[symi(k2, r2)] * zv[k2];
+            }
+            y[r2] = sacc + v;
+        }
+        T xtn[NS], z[NS];
+#pragma unroll
+        for (int k2 = 0; k2 < NS; k2 += 2) {
+            z[k2] = T(0);
+            if (k2 + 1 < NS) z[k2 + 1] = T(0);
+            if (k2 < n) {
+                uint32_t r[4];
+                Philox::gen(a.seed, gfi, (uint32_t)t, ((uint32_t)(a.epoch * 4 + 0) << 8) | (uint32_t)(k2 >> 1), r);
+                double z0, z1;
+                box_muller(r, z0, z1);
+                z[k2] = (T)z0;
+                if (k2 + 1 < NS) z[k2 + 1] = (T)z1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T sacc = T(0), w = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) sacc += sF[i * NS + l] * xt[l];
+            if (nc > 0) {
+                T g = T(0);
+                g += sG[i * 2 + 0] * u0;
+                if (nc > 1) g += sG[i * 2 + 1] * u1;
+                sacc = sacc + g;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 <= i; k2++) w += sLQ[symi(k2, i)] * z[k2];
+            xtn[i] = sacc + w;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) xt[i] = xtn[i];
+        // ---- filter: the state half of Vanilla.Update(y, u), Noiseless (vanilla.go:138-146, :183-195); K from the table
+        T xm[NS], innov[PM];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T sacc = T(0);
+#pragma unroll
+            for (int l = 0; l < NS; l++) sacc += kF[i * NS + l] * x[l];
+            if (nc > 0) {
+                T g = T(0);
+                g += kG[i * 2 + 0] * u0;
+                if (nc > 1) g += kG[i * 2 + 1] * u1;
+                sacc = sacc + g;
+            }
+            xm[i] = sacc;
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < PM; r2++) {
+            T sacc = T(0);
+            if (r2 < p) {
+#pragma unroll
+                for (int l = 0; l < NS; l++) sacc += kH[r2 * NS + l] * xm[l];
+            }
+            innov[r2] = r2 < p ? y[r2] - sacc : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            T sacc = T(0);
+            if (i < n)
+                for (int c = 0; c < p; c++) sacc += row[i * p + c] * innov[c];
+            x[i] = xm[i] + sacc;
+        }
+        // ---- statistics (chisquare.go:46-77)
+        double nis = 0.0, nees = 0.0;
+        if (a.with_nis) {
+            const T *si = row + n * p + n * n;
+            T sacc = T(0);
+            for (int r2 = 0; r2 < p; r2++) {
+                T v = T(0);
+                for (int c = 0; c < p; c++) v += si[r2 * p + c] * innov[c];
+                sacc += innov[r2] * v;
+            }
+            nis = (double)sacc;
+        }
+        if (a.with_nees) {
+            const T *pi = row + n * p;
+            T dlt[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) dlt[i] = xt[i] - x[i];
+            T sacc = T(0);
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                if (i < n) {
+                    T v = T(0);
+#pragma unroll
+                    for (int j = 0; j < NS; j++)
+                        if (j < n) v += pi[i * n + j] * dlt[j];
+                    sacc += dlt[i] * v;
+                }
+            }
+            nees = (double)sacc;
+        }
+        const double v0 = active ? nis : 0.0, v1 = active ? nees : 0.0;
+        const bool odd = (lane & 1) != 0;
+        double acc = (odd ? v1 : v0) + __shfl_xor(odd ? v0 : v1, 1, 64);
+#pragma unroll
+        for (int off = 2; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane < 2) atomicAdd(my + (size_t)t * 2 + lane, acc);
+    }
+}
+
 template <typename T, int NS, int NM>
 static bool chi_try(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
     if (n != NS || p != NM) return false;
@@ -502,12 +833,22 @@ static bool chi_try(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
 
 int chi_repl() { return CHI_REPL; }
 
-int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc) {
+int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc, void *shared_table) {
     bool ok = false;
     if (tb.dtype == KB_F64)
         ok = chi_try<double, 2, 1>(tb, a, n, p, nc) || chi_try<double, 3, 1>(tb, a, n, p, nc) || chi_try<double, 4, 2>(tb, a, n, p, nc) ||
              chi_try<double, 6, 3>(tb, a, n, p, nc);
-    if (!ok && tb.dtype == KB_F64 && n <= 16 && p <= 8 && nc <= 2) {   // every other shape: run-time dimensions on lane-private arrays
+    if (!ok && tb.dtype == KB_F64 && n <= 16 && p <= 8 && nc <= 2 && shared_table) {
+        // ONE filter fanned out (no per-run model, no per-run initial estimate): the covariance recursion once, then one run per lane
+        if (n <= 8) hipLaunchKernelGGL((chisq_cov_kernel<double, 8>), dim3(1), dim3(256), 0, tb.stream, a, n, p, (double *)shared_table);
+        else hipLaunchKernelGGL((chisq_cov_kernel<double, 16>), dim3(1), dim3(256), 0, tb.stream, a, n, p, (double *)shared_table);
+        const dim3 grid = tile_grid(a.ntiles), block(256);
+        if (n <= 8) hipLaunchKernelGGL((chisq_shared_kernel<double, 8>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
+        else if (n <= 12) hipLaunchKernelGGL((chisq_shared_kernel<double, 12>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
+        else hipLaunchKernelGGL((chisq_shared_kernel<double, 16>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
+        ok = true;
+    }
+    if (!ok && tb.dtype == KB_F64 && n <= 16 && p <= 8 && nc <= 2) {   // per-run models or initial estimates: run-time dimensions on lane-private arrays
         const HeavyScope hs(tb, n > 8);   // LD = 16: scratch-heavy, see kb_internal.h
         if (n <= 8) hipLaunchKernelGGL((chisq_gen_kernel<double, 8>), dim3((unsigned)a.ntiles), dim3(64), 0, hs.stream, a, n, p, nc);
         else hipLaunchKernelGGL((chisq_gen_kernel<double, 16>), dim3((unsigned)a.ntiles), dim3(64), 0, hs.stream, a, n, p, nc);
@@ -589,7 +930,20 @@ int kb::chisq_run_device(Batch &tb, Batch &kb_, int steps, const double *control
     a.seed = truth->seed;
     a.nsteps = steps; a.ncontrols = ncontrols; a.need_ctrl = truth->need_ctrl; a.with_nees = with_nees; a.with_nis = with_nis;
     a.controls = truth->d_ctrl; a.sums = truth->d_mc;
-    if ((rc = launch_chisq(*truth, a, truth->n, truth->p, truth->need_ctrl ? m : 0))) return rc;
+    // the table of the shared-covariance path (chisq_cov_kernel): [steps][n p + n n + p p] doubles behind the sums; only when both
+    // batches are ONE filter fanned out (kb_replicate / broadcast uploads: no per-run model field, no per-run x0 / P0)
+    void *table = nullptr;
+    if (!truth->per_filter_model && !truth->per_filter_init && !kf->per_filter_model && !kf->per_filter_init && truth->dtype == KB_F64) {
+        const size_t tb_bytes = (size_t)steps * (size_t)(truth->n * truth->p + truth->n * truth->n + truth->p * truth->p) * sizeof(double);
+        if (truth->chi_table_bytes < tb_bytes) {
+            if (truth->d_chi_table) KB_HIP(dev_free(truth->d_chi_table));
+            truth->d_chi_table = nullptr; truth->chi_table_bytes = 0;
+            KB_HIP(dev_alloc(&truth->d_chi_table, tb_bytes));
+            truth->chi_table_bytes = tb_bytes;
+        }
+        table = truth->d_chi_table;
+    }
+    if ((rc = launch_chisq(*truth, a, truth->n, truth->p, truth->need_ctrl ? m : 0, table))) return rc;
     *folded = truth->d_mc + nrep;
     if ((rc = launch_fold(truth->stream, truth->d_mc, repl, (int64_t)steps * 2, *folded))) return rc;
     if (!replay_last_mc) truth->epoch++;

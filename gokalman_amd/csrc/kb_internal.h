@@ -64,6 +64,7 @@ struct Batch {
     void *d_xp = nullptr;      // cached getter scratch: materialised State() | Covariance() (x[n] | P packed) per filter
     uint8_t *d_flags = nullptr;  // cached IsWithinNsigma output
     double *d_mc = nullptr; size_t mc_bytes = 0;
+    void *d_chi_table = nullptr; size_t chi_table_bytes = 0;   // kb_chisquare with one filter fanned out: K | inverse(P+) | inverse(S) per step (kb_chisq.hip)
     // Monte-Carlo runs kept on the device (kb_mc_run_ex with KB_MC_KEEP_RUNS): traj[(t * (n + p) + e) * mc_ld + run] = State() element
     // e < n, Measurement() element e - n of run `run` at step t, in the batch dtype
     void *d_traj = nullptr; size_t traj_bytes = 0; int mc_steps = 0, mc_p = 0; int64_t mc_ld = 0, mc_first_run = 0, mc_epoch = -1;

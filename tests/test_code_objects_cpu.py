@@ -1,0 +1,64 @@
+"""Reads the gfx950 code objects of the built library (scripts/resource_usage.py: the metadata the hardware launches with) and fails when
+a kernel documented as scratch-free spills, or loses the waves per SIMD DESIGN.md quotes.  A missed per-file flag
+in gokalman_amd/build.py (EXTRA: the unroll threshold) turns register arrays into scratch arrays without a diagnostic, a few more live
+values push an allocation over 256 registers: both show here, on the CPU, before any GPU minute is spent."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+# (regular expression on the demangled kernel name, max scratch bytes per lane, min waves per SIMD by registers, what it is)
+RULES = [
+    (r"^void vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, false, false>", 0, 2, "headline: Vanilla 6/3 per step"),
+    (r"^void vanilla_reg_kernel<double, 6, 3, 0, true, false, false, false, false, false>", 0, 2, "Vanilla 6/3 FULL"),
+    (r"^void vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, true, false>", 0, 2, "Vanilla 6/3 + AWGN per step"),
+    (r"^void vanilla_reg_kernel<double, 6, 3, 0, false, false, true, false, false, false>", 0, 1, "Vanilla 6/3 time-fused"),
+    (r"^void vanilla_reg_kernel<double, 6, 3, 0, false, false, true, false, true, false>", 32, 1, "Vanilla 6/3 + AWGN time-fused (28 B: the draws at the 512-register cap)"),
+    (r"^void squareroot_reg_kernel<double, 6, 3, 0, false, false, false, false, false>", 0, 2, "config C: SquareRoot 6/3 per step"),
+    (r"^void squareroot_reg_kernel<double, 6, 3, 0, false, false, false, false, true>", 0, 1, "SquareRoot 6/3 time-fused"),
+    (r"^void information_reg_kernel<double, 6, 3, 0, false, false, false, false, false>", 0, 2, "Information 6/3"),
+    (r"^void hybrid_reg_kernel<double, 6, 2, false, false", 0, 2, "config D(ii): Hybrid 6/2"),
+    (r"^void srif_pair_kernel<float, 12, 6, false, (true|false), false>", 0, 2, "config E: SRIF 12/6 fp32"),
+    (r"^void srif_pair_kernel<double, 12, 6, ", 0, 1, "SRIF 12/6 fp64, two lanes"),
+    (r"^void vanilla_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "Vanilla 12/6 exact, four lanes"),
+    (r"^void squareroot_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "SquareRoot 12/6 exact"),
+    (r"^void information_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "Information 12/6 exact"),
+    (r"^void srif_split_kernel<\d+, (4|6), (4|8)>", 0, 2, "SRIF fp64 split, p <= 6 (every n)"),
+    (r"^void srif_split_kernel<\d+, 8, (4|8)>", 16, 2, "SRIF fp64 split, p = 7, 8"),
+    (r"^void mc_kernel<double, 4, 2, ", 0, 2, "config D(i): Monte-Carlo statOD5044"),
+]
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    import resource_usage
+    return resource_usage.kernels()
+
+
+def test_documented_kernels_do_not_spill_and_keep_their_occupancy(kernels):
+    bad, seen = [], {}
+    for k in kernels:
+        for pat, max_scratch, min_waves, what in RULES:
+            if re.search(pat, k["name"]):
+                seen[pat] = seen.get(pat, 0) + 1
+                if k["private_segment_fixed_size"] > max_scratch or k["waves_per_simd"] < min_waves:
+                    bad.append((what, k["name"][:100], "scratch %d B (<= %d)" % (k["private_segment_fixed_size"], max_scratch),
+                                "waves/SIMD %d (>= %d)" % (k["waves_per_simd"], min_waves), "VGPR+AGPR %d" % k["vgpr_count"]))
+    missing = [what for pat, _, _, what in RULES if pat not in seen]
+    assert not missing, "rules that match no kernel (renamed template parameters?): %s" % missing
+    assert not bad, "\n".join(str(b) for b in bad)
+
+
+def test_every_translation_unit_of_a_flagged_family_has_its_flags():
+    """build.py refuses to compile a kb_*_split* / kb_srif_pair* unit without an EXTRA entry; the table and the tree agree."""
+    import glob
+    from gokalman_amd import build as kb_build
+    srcs = [os.path.basename(p) for p in glob.glob(os.path.join(kb_build.CSRC, "*.hip"))]
+    flagged = [s for s in srcs if any(s.startswith(p) for p in kb_build._NEEDS_EXTRA)]
+    assert flagged and all(s in kb_build.EXTRA for s in flagged), [s for s in flagged if s not in kb_build.EXTRA]
+    stale = [s for s in kb_build.EXTRA if s not in srcs]
+    assert not stale, "EXTRA names files that no longer exist: %s" % stale
