@@ -69,6 +69,7 @@ def parse_args(argv=None):
                     help="filters of the out-of-Infinity-Cache measurement of the same kernel (0 = skip)")
     ap.add_argument("--mc-runs", type=int, default=1 << 20, help="Monte-Carlo runs per GPU for extra.mc (0 = skip)")
     ap.add_argument("--mc-steps", type=int, default=1086)
+    ap.add_argument("--hybrid-total", type=int, default=8 << 20, help="filters of the WHOLE configs[3] Hybrid-EKF ensemble (8M), run once on one GPU when world == 1 (0 = skip)")
     ap.add_argument("--mc-total", type=int, default=8 << 20, help="runs of the WHOLE configs[3] ensemble (8M): every rank takes mc_total / world of them as "
                     "consecutive shards of --mc-runs runs (one rank: eight shards one after the other); 0 = skip extra.mc.ensemble")
     ap.add_argument("--hybrid-filters", type=int, default=1 << 20, help="Hybrid EKF filters per GPU for extra.hybrid_ekf (0 = skip)")
@@ -643,6 +644,51 @@ def main():
                                                            *rl.load_traffic(ROOT, "hybrid_reg_kernel<double, 6, 2, true, false, true")),
                                "filters_with_error_status": int(hbad.item())}
         del hb, Phi, Ht, real, comp
+        # ---- configs[3] D(ii) at its stated size on ONE GPU: world x M filters = 8 388 608 by default, the
+        # same generator; the first 4096 filters must come out bit-identical to the same filters run as a 4096-filter batch (a filter's
+        # result may not depend on where in the grid it was computed), nobody may fail
+        if world == 1 and args.hybrid_total > M:
+            MT = args.hybrid_total
+            g2 = torch.Generator(device=dev); g2.manual_seed(11)
+            x0t = np.random.default_rng(12).standard_normal((MT, hn))
+            P0t = np.zeros((MT, hn, hn)); P0t[:, np.arange(hn), np.arange(hn)] = [10, 10, 10, 1, 1, 1]
+            big = ga.FilterBatch(k.HYBRID, hn, hp, 0, MT, device=local_rank)
+            big.set(k.X, x0t, 1); big.set(k.P, P0t, 2); big.set(k.R, np.diag([1e-6, 1e-6]), 2, p_rows=hp); big.init(); big.enable_ekf()
+            SM = 4096
+            small = ga.FilterBatch(k.HYBRID, hn, hp, 0, SM, device=local_rank)
+            small.set(k.X, x0t[:SM], 1); small.set(k.P, P0t[:SM], 2); small.set(k.R, np.diag([1e-6, 1e-6]), 2, p_rows=hp); small.init(); small.enable_ekf()
+            del x0t, P0t
+            PhiT = (torch.eye(hn, dtype=torch.float64, device=dev).reshape(hn * hn, 1)
+                    + 1e-2 * torch.randn(hn * hn, MT, dtype=torch.float64, device=dev, generator=g2)).contiguous()
+            HtT = torch.randn(hp * hn, MT, dtype=torch.float64, device=dev, generator=g2)
+            realT = torch.randn(hp, MT, dtype=torch.float64, device=dev, generator=g2)
+            compT = realT + 1e-3 * torch.randn(hp, MT, dtype=torch.float64, device=dev, generator=g2)
+            torch.cuda.synchronize()
+            bs = torch.cuda.ExternalStream(big.stream(), device=dev)
+
+            def bstep(b_, ld):
+                k.check(k.lib().kb_prepare_dev(b_._h, PhiT.data_ptr(), HtT.data_ptr(), ld))
+                k.check(k.lib().kb_update_nl_dev(b_._h, realT.data_ptr(), compT.data_ptr(), ld))
+            KT = 10
+            for _ in range(KT):   # (the same steps on both batches: the timed repetitions below continue from here)
+                bstep(big, MT); bstep(small, MT)
+            big.synchronize(); small.synchronize()
+            same = bool(np.array_equal(big.get(k.STATE, 0, SM), small.get(k.STATE)) and np.array_equal(big.get(k.COVAR, 0, SM), small.get(k.COVAR)))
+            warm_clocks()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record(bs)
+            for _ in range(KT):
+                bstep(big, MT)
+            b1.record(bs)
+            big.synchronize()
+            bms = b0.elapsed_time(b1) / KT
+            extra["hybrid_ekf"]["ensemble"] = {"config": "configs[3] D(ii) at its stated size on one GPU: %d Hybrid EKF filters, %.1f GB of Phi / Htilde / observations per step read in place" % (MT, MT * (hn * hn + hp * hn + 2 * hp) * 8 / 1e9),
+                                               "filters_total": MT, "steps": KT, "kernel_ms": bms, "value": MT / (bms * 1e-3), "unit": "filter-update steps/s (1 GPU)",
+                                               "roofline": rl.hbm_roofline(bms, MT, rl.algorithmic_bytes("hybrid", hn, hp), rl.moved_bytes("hybrid", hn, hp), None, {"analytic": "packed working set"}),
+                                               "first_4096_filters_bit_identical_to_a_4096_filter_batch": same,
+                                               "filters_with_error_status": int(np.count_nonzero(big.status()))}
+            del big, small, PhiT, HtT, realT, compT
+            torch.cuda.empty_cache()
 
     # ---- extra: configs C (SquareRoot 6/3 fp64 on the headline's batch) and E (SRIF 12/6 fp32), one shard per rank --------
     def timed_leg(batch, fn, reps):
