@@ -757,7 +757,8 @@ def main():
         extra["shared_model"] = {"config": "%d Vanilla 6/3 fp64 filters per GPU sharing ONE model (F, H, Q, R uploaded with broadcast = 1)" % M,
                                  "filters_total": world * M, "steps": K5, "value": world * M * K5 / h_s,
                                  "unit": "filter-update steps/s (whole job)", "kernel_ms": hms,
-                                 "roofline": rl.hbm_roofline(hms, M, rl.algorithmic_bytes("vanilla", n, p), moved),
+                                 "roofline": rl.hbm_roofline(hms, M, rl.algorithmic_bytes("vanilla", n, p), moved,
+                                                             *rl.load_traffic(ROOT, "vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, false, true>")),
                                  "filters_with_error_status": hbad,
                                  "note": "the model block (672 B) is read from the L2 by every wave; moved bytes = x, P read and written + y"}
         del sh, yq

@@ -22,9 +22,9 @@ run bench_write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_w
 run bench_sq      rocprofv3 --pmc $SQ --output-format csv -d $OUT/bench_sq -- python3 bench.py $B
 run kinds_plain   python3 scripts/bench_kinds.py
 run kinds_stats   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kinds_stats -- python3 scripts/bench_kinds.py
-run kinds_fetch   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kinds_fetch -- python3 scripts/bench_kinds.py vsplit vpad sqsplit infsplit vnoise sqrt info srif hybrid
-run kinds_write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kinds_write -- python3 scripts/bench_kinds.py vsplit vpad sqsplit infsplit vnoise sqrt info srif hybrid
-run kinds_sq      rocprofv3 --pmc $SQ --output-format csv -d $OUT/kinds_sq -- python3 scripts/bench_kinds.py vsplit vpad sqsplit infsplit vnoise sqrt info srif hybrid mc
+run kinds_fetch   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/kinds_fetch -- python3 scripts/bench_kinds.py vsplit vpad sqsplit infsplit vnoise vshared sqrt info srif srifpad hybrid --srif-shapes=16x6,14x4,11x4,7x3
+run kinds_write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/kinds_write -- python3 scripts/bench_kinds.py vsplit vpad sqsplit infsplit vnoise vshared sqrt info srif srifpad hybrid --srif-shapes=16x6,14x4,11x4,7x3
+run kinds_sq      rocprofv3 --pmc $SQ --output-format csv -d $OUT/kinds_sq -- python3 scripts/bench_kinds.py vsplit vpad sqsplit infsplit vnoise vshared sqrt info srif srifpad hybrid mc --srif-shapes=16x6,14x4,11x4,7x3
 run chisq_plain   python3 scripts/bench_chisq.py
 run chisq_sq      rocprofv3 --pmc $SQ --output-format csv -d $OUT/chisq_sq -- python3 scripts/bench_chisq.py
 hipcc --offload-arch=gfx950 -O3 scripts/diag_stream.hip -o /tmp/diag_stream 2> /dev/null && /tmp/diag_stream > $OUT/diag_stream.out 2>&1

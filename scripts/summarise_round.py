@@ -100,7 +100,8 @@ def main():
                "vanilla_reg_kernel<double, 6, 3, 0": 1 << 20, "squareroot_reg_kernel<double, 6, 3": 1 << 20, "information_reg_kernel<double, 6, 3": 1 << 20,
                "hybrid_reg_kernel<double, 6, 2": 1 << 20, "srif_pair_kernel<float, 12, 6": 1 << 18, "srif_pair_kernel<double, 12, 6": 1 << 18,
                "vanilla_split_kernel<double, 12, 6": 1 << 18, "squareroot_split_kernel<double, 12, 6": 1 << 18, "information_split_kernel<double, 12, 6": 1 << 18,
-               "vanilla_split_kernel<double, 12, 4": 1 << 18, "vanilla_split_kernel<double, 16, 4": 1 << 18, "squareroot_split_kernel<double, 8, 4": 1 << 18, "information_split_kernel<double, 8, 4": 1 << 18}
+               "vanilla_split_kernel<double, 12, 4": 1 << 18, "vanilla_split_kernel<double, 16, 4": 1 << 18, "squareroot_split_kernel<double, 8, 4": 1 << 18, "information_split_kernel<double, 8, 4": 1 << 18,
+               "srif_split_kernel<": 1 << 18}
     for fkey, wkey in (("bench_fetch", "bench_write"), ("kinds_fetch", "kinds_write")):
         fe, wr = c["pmc"].get(fkey, {}), c["pmc"].get(wkey, {})
         for kn, e in fe.items():
@@ -167,7 +168,7 @@ def main():
         json.dump({"tag": tag, "head": head, "source_hash": c["source_hash"], "kernels": named, "note": "SQ_INSTS_VALU / SQ_WAVES per launch"},
                   open(os.path.join(ROOT, "profiles", "valu_latest.json"), "w"), indent=1)
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resource_usage.py"), "--md", os.path.join(DST, "resource_usage.md"),
-                    "reg_kernel", "srif_", "mc_kernel", "chisq_kernel"], stdout=subprocess.DEVNULL)
+                    "reg_kernel", "srif_", "mc_kernel", "chisq_", "split_kernel"], stdout=subprocess.DEVNULL)
     print("\n".join(md))
 
 
