@@ -51,7 +51,10 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
     T *lq = lf + q * FPW;            // slot (e + q): own column / own entry of a vector
     T *lqn = lf + q * NS * FPW;      // slot (e + q n): own row q + L r of a row-major n-column matrix starts at slot (L r) n from here
     auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
-    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
+    // (model streams: non-temporal where a lane group reads whole 128-byte segments (L <= 4); with eight lanes per filter a group reads HALF
+    // a line and the part next door the other half a little later -- the streaming hint lets the line leave the L2 in between and it comes
+    // from memory twice (kb_srif_split.h: 1.36x the packed reads with the hint, 1.04x without), so there the default policy)
+    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { if constexpr (L == 8) return *(ep(ubase, rt, c) + off); else return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
     bool rowok[RP], rowany[RP];
 #pragma unroll
     for (int r = 0; r < RP; r++) { rowok[r] = !GEN || q + L * r < rn; rowany[r] = !GEN || L * r < rn; }

@@ -73,7 +73,10 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     T *lf = lds + f;
     T *lq = lf + q * FPW;
     auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
-    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
+    // (model streams: non-temporal where a lane group reads whole 128-byte segments (L <= 4); with eight lanes per filter a group reads HALF
+    // a line and the part next door the other half a little later -- the streaming hint lets the line leave the L2 in between and it comes
+    // from memory twice (kb_srif_split.h: 1.36x the packed reads with the hint, 1.04x without), so there the default policy)
+    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { if constexpr (L == 8) return *(ep(ubase, rt, c) + off); else return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
     bool colok[RP], colany[RP];   // own column / row j_r = q + L r is a real one; some lane's is (wave-uniform)
 #pragma unroll
     for (int r = 0; r < RP; r++) { colok[r] = !GEN || q + L * r < rn; colany[r] = !GEN || L * r < rn; }

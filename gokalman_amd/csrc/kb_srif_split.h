@@ -152,6 +152,11 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
     const int64_t xoff = ext ? (int64_t)q * a.ext_ld + (tile * KB_TILE + (active ? slot : part * FPW)) : 0;
     T *const lf = lds + f;
     auto ep = [&](const T *ubase, int rt, int c) -> cgptr { return anchored(ubase, rt, c); };
+    // Read-once streams (Phi, Htilde, chol R, observations): non-temporal at four lanes per filter, where a lane group reads a whole
+    // 128-byte segment.  At eight lanes a group reads HALF a line and the part next door reads the other half a little later: with the
+    // streaming hint the line is gone from the L2 by then and comes from memory twice (counters, 16/6: 5837 B read per filter-step against
+    // 4296 B packed; two-wave workgroups over neighbouring parts did not help and cost 8 % -- NOTES.md), so there the default policy.
+    auto ldstream = [&](auto ptr) __attribute__((always_inline)) { if constexpr (L == 8) return *ptr; else return __builtin_nontemporal_load(ptr); };
     int jr[RP];
     bool colok[RP];
 #pragma unroll
@@ -198,13 +203,13 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int i = 0; i < NS; i++)
-                    if (i < N && L * r < N) Pc[r][i] = __builtin_nontemporal_load(xp + ((int64_t)(i * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld)));
+                    if (i < N && L * r < N) Pc[r][i] = ldstream(xp + ((int64_t)(i * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld)));
         } else {
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int i = 0; i < NS; i++)
-                    if (i < N && L * r < N) Pc[r][i] = __builtin_nontemporal_load(ep(mo, 0, i * N + L * r) + (colok[r] ? umq : um));
+                    if (i < N && L * r < N) Pc[r][i] = ldstream(ep(mo, 0, i * N + L * r) + (colok[r] ? umq : um));
         }
 #pragma unroll
         for (int r = 0; r < RP; r++)
@@ -519,13 +524,13 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int m = 0; m < NM; m++)
-                    Hc[r][m] = (L * r < N && m < rp) ? __builtin_nontemporal_load(xh + ((int64_t)(m * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld))) : T(0);
+                    Hc[r][m] = (L * r < N && m < rp) ? ldstream(xh + ((int64_t)(m * N + L * r) * a.ext_ld + (colok[r] ? xoff : xoff - (int64_t)q * a.ext_ld))) : T(0);
         } else {
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int m = 0; m < NM; m++)
-                    Hc[r][m] = (L * r < N && m < rp) ? __builtin_nontemporal_load(ep(mo, 0, N * N + m * N + L * r) + (colok[r] ? umq : um)) : T(0);
+                    Hc[r][m] = (L * r < N && m < rp) ? ldstream(ep(mo, 0, N * N + m * N + L * r) + (colok[r] ? umq : um)) : T(0);
         }
 #pragma unroll
         for (int r = 0; r < RP; r++)

@@ -302,7 +302,10 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     // ep(base, rt, c): element (rt + c) of a block as (opaque scalar anchor) + (immediate): kb_device.h anchored()
     typedef __attribute__((address_space(1))) T *gptr;
     auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
-    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
+    // (model streams: non-temporal where a lane group reads whole 128-byte segments (L <= 4); with eight lanes per filter a group reads HALF
+    // a line and the part next door the other half a little later -- the streaming hint lets the line leave the L2 in between and it comes
+    // from memory twice (kb_srif_split.h: 1.36x the packed reads with the hint, 1.04x without), so there the default policy)
+    auto ldg = [&](const T *ubase, int rt, int c, unsigned off) { if constexpr (L == 8) return *(ep(ubase, rt, c) + off); else return __builtin_nontemporal_load(ep(ubase, rt, c) + off); };
 #ifndef KB_SPLIT_LATE_COND   // (A/B: 3-4 % at 9..12 states, 12 % at 12/8; issuing the FIRST burst this way as well costs more than it gains: profiles/NOTES.md)
     // GEN, the loads BEHIND the first burst (Q, H, R): issued always -- from element 0 of the same field (which every shape has) when the
     // shape does not have the element (the run-time part of the element index takes the stand-in: scalar-base form kept), the value
@@ -310,7 +313,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     auto ldg_if = [&](bool need, const T *ubase, int field, int rt, int c, unsigned off, unsigned off_alt) {   // need: wave-uniform
         if constexpr (!GEN) return need ? ldg(ubase, rt, c, off) : T(0);
         else {
-            const T v = __builtin_nontemporal_load(ep(ubase, need ? rt : field - c, c) + (need ? off : off_alt));
+            const auto pe_ = ep(ubase, need ? rt : field - c, c) + (need ? off : off_alt);
+            const T v = L == 8 ? *pe_ : __builtin_nontemporal_load(pe_);
             return need ? v : T(0);
         }
     };
