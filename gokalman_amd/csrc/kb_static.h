@@ -50,7 +50,9 @@ __device__ __forceinline__ void smv(const T (&A)[R * C], const T (&x)[C], T (&y)
 struct AllRowsActive {
     static constexpr bool active(int, int) { return true; }
 };
-template <typename T, int M, int N, typename ACT = AllRowsActive>
+// FASTDIV: f from recip() (kb_device.h: within an ulp of the quotient, a third of its instructions) -- the time-fused SquareRoot kernel,
+// which is bound by instruction issue and does not promise the one-step kernel's bits anyway.
+template <typename T, int M, int N, typename ACT = AllRowsActive, bool FASTDIV = false>
 __device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
     constexpr int KMAX = M < N ? M : N;
 #pragma unroll
@@ -68,7 +70,7 @@ __device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
         const T alpha = a[i * N + i];
         const T beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
         const T u0 = alpha - beta;
-        const T f = refl ? T(1) / (beta * u0) : T(0);
+        const T f = refl ? (FASTDIV ? recip(beta * u0) : T(1) / (beta * u0)) : T(0);
         a[i * N + i] = refl ? beta : alpha;
 #pragma unroll
         for (int c = i + 1; c < N; c++) {
