@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(256) chisq_cov_kernel(const ChiArgs a, int n, 
 }
 
 template <typename T, int NS>
-__global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int n, int p, int nc, const T *__restrict__ table) {
+__global__ void __launch_bounds__(256, 2) chisq_shared_kernel(const ChiArgs a, int n, int p, int nc, const T *__restrict__ table) {
     constexpr int TQ = tri(NS), PM = 8, TP = tri(PM);
     __shared__ T sF[NS * NS], sLQ[TQ], sG[NS * 2], sH[PM * NS], sLR[TP], kF[NS * NS], kG[NS * 2], kH[PM * NS];
     {
@@ -718,6 +718,7 @@ __global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int 
             }
             y[r2] = sacc + v;
         }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);   // (phase by phase: interleaved, the broadcast operands of all phases are alive together)
         T xtn[NS], z[NS];
 #pragma unroll
         for (int k2 = 0; k2 < NS; k2 += 2) {
@@ -746,9 +747,12 @@ __global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int 
 #pragma unroll
             for (int k2 = 0; k2 <= i; k2++) w += sLQ[symi(k2, i)] * z[k2];
             xtn[i] = sacc + w;
+            pin(xtn[i]);
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two rows of broadcast operands in flight at a time
         }
 #pragma unroll
         for (int i = 0; i < NS; i++) xt[i] = xtn[i];
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);   // (phase by phase: interleaved, the broadcast operands of all phases are alive together)
         // ---- filter: the state half of Vanilla.Update(y, u), Noiseless (vanilla.go:138-146, :183-195); K from the table
         T xm[NS], innov[PM];
 #pragma unroll
@@ -763,7 +767,10 @@ __global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int 
                 sacc = sacc + g;
             }
             xm[i] = sacc;
+            pin(xm[i]);
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two rows of broadcast operands in flight at a time
         }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);   // (phase by phase: interleaved, the broadcast operands of all phases are alive together)
 #pragma unroll
         for (int r2 = 0; r2 < PM; r2++) {
             T sacc = T(0);
@@ -779,7 +786,10 @@ __global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int 
             if (i < n)
                 for (int c = 0; c < p; c++) sacc += row[i * p + c] * innov[c];
             x[i] = xm[i] + sacc;
+            pin(x[i]);
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two rows of broadcast operands in flight at a time
         }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);   // (phase by phase: interleaved, the broadcast operands of all phases are alive together)
         // ---- statistics (chisquare.go:46-77)
         double nis = 0.0, nees = 0.0;
         if (a.with_nis) {
@@ -792,6 +802,7 @@ __global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int 
             }
             nis = (double)sacc;
         }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);   // (phase by phase: interleaved, the broadcast operands of all phases are alive together)
         if (a.with_nees) {
             const T *pi = row + n * p;
             T dlt[NS];
@@ -806,7 +817,9 @@ __global__ void __launch_bounds__(256) chisq_shared_kernel(const ChiArgs a, int 
                     for (int j = 0; j < NS; j++)
                         if (j < n) v += pi[i * n + j] * dlt[j];
                     sacc += dlt[i] * v;
+                    pin(sacc);
                 }
+                if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two rows of broadcast operands in flight at a time
             }
             nees = (double)sacc;
         }
