@@ -835,3 +835,27 @@ def test_shared_model_squareroot_and_information_equal_the_per_filter_batch(kind
     run(steps)
     shared.set(k.H, H[0], 2, p_rows=p); perf.set(k.H, tile(H[0]), 2, p_rows=p)
     run(2 * steps)
+
+
+@pytest.mark.parametrize("n,p,m", [(12, 6, 0), (9, 3, 1), (16, 8, 2), (7, 2, 0)])
+def test_chisquare_shared_covariance_path_equals_the_per_run_kernel(n, p, m):
+    """NewChiSquare beyond (6,3) (round 5): with ONE filter fanned out the covariance recursion runs once (chisq_cov_kernel) and a lane
+    advances only the two states (chisq_shared_kernel); a batch given N per-run copies of the same model takes the per-run kernel
+    (chisq_gen_kernel: the whole Update per lane).  Same draws, same sums: the NIS / NEES means agree to rounding."""
+    rng = np.random.default_rng(77 * n + p)
+    runs, steps = 300, 12
+    F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); H = rng.standard_normal((p, n)); G = 0.3 * rng.standard_normal((n, m)) if m else None
+    A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n)
+    B = 0.2 * rng.standard_normal((p, p)); R = B @ B.T + 1e-2 * np.eye(p)
+    x0, P0 = 0.1 * rng.standard_normal(n), 1.5 * np.eye(n)
+    controls = rng.standard_normal((steps, m)) if m else np.zeros((1, 1))
+    tile = lambda M: None if M is None else np.ascontiguousarray(np.broadcast_to(M, (runs,) + M.shape))
+    out = []
+    for per_run in (False, True):
+        w = tile if per_run else (lambda M: M)
+        truth = ga.FilterBatch.new_ldkf(k.VANILLA_PREDICT, w(x0), w(P0), w(F), w(G), w(H), w(Q), w(R), nfilters=runs, noise=k.NOISE_AWGN, seed=11)
+        kf = ga.FilterBatch.new_ldkf(k.VANILLA, w(x0), w(P0), w(F), w(G), w(H), w(Q), w(R), nfilters=runs)
+        out.append(ga.new_chi_square(kf, truth, controls, steps=steps))
+    (nis_s, nees_s), (nis_g, nees_g) = out
+    assert np.all(np.isfinite(nis_s)) and np.all(np.isfinite(nees_s)) and nis_s.min() > 0
+    assert np.allclose(nis_s, nis_g, rtol=1e-10) and np.allclose(nees_s, nees_g, rtol=1e-9), (np.max(np.abs(nis_s / nis_g - 1)), np.max(np.abs(nees_s / nees_g - 1)))
