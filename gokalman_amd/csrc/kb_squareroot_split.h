@@ -24,6 +24,9 @@
 namespace kb {
 
 #define KB_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef KB_SQSPLIT_ACC
+#define KB_SQSPLIT_ACC 1   // (4: the column norms in four partial sums -- A/B, profiles/NOTES.md round 5)
+#endif
 
 template <int NS, int NM>
 constexpr int sqsplit_lds_elems() { return (tri(NS) > NS * NM ? tri(NS) : NS * NM) + 2 * NS + 2 + NS + NM + NM * NM; }   // S / Uc packed | the reflector of one column step (u0, f, then <= 2 n rows; n + p <= 2 n)
@@ -193,11 +196,26 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     sfor<0, NS>([&](auto KK) __attribute__((always_inline)) {
         constexpr int k = KK, rk = k / L, qk = k % L;
         {   // the owner's part, computed by every lane on its local column rk; only lane group qk publishes it
-            T xn2 = T(0);
+            T xn2;
+            if constexpr (KB_SQSPLIT_ACC > 1) {   // (partial sums: the dependent chain of n + p FMAs in front of the square root is the step's longest)
+                T x4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-            for (int i = k + 1; i < NS; i++) xn2 += Ct[rk][i] * Ct[rk][i];
+                for (int i = k + 1; i < NS; i++) x4[(i - (k + 1)) & 3] += Ct[rk][i] * Ct[rk][i];
+                xn2 = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+            } else {
+                xn2 = T(0);
 #pragma unroll
-            for (int i = 0; i <= k; i++) xn2 += Cb[rk][i] * Cb[rk][i];
+                for (int i = k + 1; i < NS; i++) xn2 += Ct[rk][i] * Ct[rk][i];
+            }
+            if constexpr (KB_SQSPLIT_ACC > 1) {
+                T y2[2] = {T(0), T(0)};
+#pragma unroll
+                for (int i = 0; i <= k; i++) y2[i & 1] += Cb[rk][i] * Cb[rk][i];
+                xn2 += y2[0] + y2[1];
+            } else {
+#pragma unroll
+                for (int i = 0; i <= k; i++) xn2 += Cb[rk][i] * Cb[rk][i];
+            }
             T u0, fr;
             const T dg = reflector<T>(Ct[rk][k], xn2, true, u0, fr);
             if (q == qk) {
@@ -362,9 +380,17 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     sfor<0, NM>([&](auto KK) __attribute__((always_inline)) {
         constexpr int k = KK, rk = k / L, qk = k % L;
         {
-            T xn2 = T(0);
+            T xn2;
+            if constexpr (KB_SQSPLIT_ACC > 1) {   // (partial sums: the dependent chain of n + p FMAs in front of the square root is the step's longest)
+                T x4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-            for (int i = NM; i < DD; i++) xn2 += Dm[rk][i] * Dm[rk][i];
+                for (int i = NM; i < DD; i++) x4[(i - (NM)) & 3] += Dm[rk][i] * Dm[rk][i];
+                xn2 = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+            } else {
+                xn2 = T(0);
+#pragma unroll
+                for (int i = NM; i < DD; i++) xn2 += Dm[rk][i] * Dm[rk][i];
+            }
             T u0, fr;
             const T dg = reflector<T>(Dm[rk][k], xn2, true, u0, fr);
             if (q == qk) {
@@ -480,9 +506,17 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     sfor<0, NS>([&](auto KK) __attribute__((always_inline)) {
         constexpr int kk = KK, k = NM + kk, rk = kk / L, qk = kk % L;
         {
-            T xn2 = T(0);
+            T xn2;
+            if constexpr (KB_SQSPLIT_ACC > 1) {   // (partial sums: the dependent chain of n + p FMAs in front of the square root is the step's longest)
+                T x4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-            for (int i = k + 1; i < DD; i++) xn2 += Ds[rk][i] * Ds[rk][i];
+                for (int i = k + 1; i < DD; i++) x4[(i - (k + 1)) & 3] += Ds[rk][i] * Ds[rk][i];
+                xn2 = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+            } else {
+                xn2 = T(0);
+#pragma unroll
+                for (int i = k + 1; i < DD; i++) xn2 += Ds[rk][i] * Ds[rk][i];
+            }
             T u0, fr;
             const T dg = reflector<T>(Ds[rk][k], xn2, k + 1 < DD, u0, fr);
             if (q == qk) {

@@ -151,7 +151,10 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     const T *eh = EXT ? (const T *)a.ext_h + first : nullptr;
     const T *yr = (const T *)a.y + tile * a.y_ts + half * 32;
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + half * 32;
-    T *es = FULL ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + half * 32 : nullptr;
+    // (beyond 12 states ONE instantiation serves batches with and without KB_FLAG_FULL_ESTIMATE -- srif_pair_launch: half the kernels of
+    // the largest translation units for shapes no benchmark times -- so the stores are gated at run time as well)
+    const bool full_rt = FULL && (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
+    T *es = full_rt ? (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + half * 32 : nullptr;
     auto ld_st = [&](int e) { return st[(unsigned)(e * KB_TILE) + vf]; };            // state element e of this lane's filter
     auto ld_row = [&](int e) { return st[(unsigned)(e * KB_TILE) + vrow]; };         // ... of the own row
     auto ld_mo = [&](int e) { return __builtin_nontemporal_load(mo + ((unsigned)(e * KB_TILE) + vf)); };
@@ -475,7 +478,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     // column by column.  Found by bisection (profiles/NOTES.md).
     auto store_rbar = [&]() __attribute__((always_inline)) {
         if constexpr (FULL) {
-            if (ok) {
+            if (ok && full_rt) {
 #pragma unroll
                 for (int s = 0; s < HS; s++)
 #pragma unroll
@@ -524,7 +527,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     }
     if constexpr (MEAS_LATE) { __builtin_amdgcn_sched_barrier(0); whiten(); }
     if constexpr (FULL) {
-        if (ok) {
+        if (ok && full_rt) {
 #pragma unroll
             for (int t = 0; t < HM; t++) {
                 if (PADM && 2 * t + (is_hi ? 1 : 0) >= rp) continue;   // (the padded row has no slot in the Estimate)
@@ -624,7 +627,7 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         }
     }
     if constexpr (FULL) {
-        if (ok) {
+        if (ok && full_rt) {
 #pragma unroll
             for (int t = 0; t < HM; t++) {
                 if (PADM && 2 * t + (is_hi ? 1 : 0) >= rp) continue;
@@ -694,7 +697,7 @@ template <typename T, int NS, int NM, bool PADM = false>
 static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
     if (a.n != NS || (PADM ? (a.p != NM && a.p != NM - 1) : a.p != NM) || a.predict) return false;
     if (a.ext_phi && a.ext_ld >= (int64_t(1) << 28)) return false;   // the upper half's Phi offset (+ ld elements) is a 32-bit byte offset
-    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
+    const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;   // (NS > 12: always the FULL instantiation, its stores gated at run time)
     const dim3 grid((unsigned)((2 * a.ntiles + KB_PAIR_WPB - 1) / KB_PAIR_WPB)), block(64 * KB_PAIR_WPB);
     const dim3 dgrid((unsigned)(2 * a.ntiles)), dblock(64);
 #define KB_P(F_, E_)                                                                                                                         \
@@ -702,8 +705,11 @@ static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
         if (a.srif_tri) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_, PADM>), grid, block, 0, b.stream, a);                             \
         if (!a.srif_tri || a.srif_leftover) hipLaunchKernelGGL((srif_pair_dense_kernel<T, NS, NM, F_, E_, PADM>), dgrid, dblock, 0, b.stream, a); \
     } while (0)
-    if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
-    else      { if (ext) KB_P(false, true); else KB_P(false, false); }
+    if constexpr (NS > 12) { if (ext) KB_P(true, true); else KB_P(true, false); }
+    else {
+        if (full) { if (ext) KB_P(true, true); else KB_P(true, false); }
+        else      { if (ext) KB_P(false, true); else KB_P(false, false); }
+    }
 #undef KB_P
     return true;
 }
