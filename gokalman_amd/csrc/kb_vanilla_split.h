@@ -348,7 +348,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 T v;
                 if (HYB && a.ext_phi) {   // zero copy (kb_prepare_dev): element e of filter i of the caller's planar array at ext[e ld + i]
                     const T *ephi = (const T *)a.ext_phi + (active ? fi : tile * KB_TILE);
-                    v = (rowany[r] && l < rn) ? __builtin_nontemporal_load(ephi + (int64_t)(((rowok[r] ? q : 0) + L * r) * rn + l) * a.ext_ld) : T(0);
+                    const T *pe_ = ephi + (int64_t)(((rowok[r] ? q : 0) + L * r) * rn + l) * a.ext_ld;
+                    v = (rowany[r] && l < rn) ? (L == 8 ? *pe_ : __builtin_nontemporal_load(pe_)) : T(0);   // (eight lanes: half-line segments, default policy -- see ldg)
                 } else {
                     v = (rowany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, rowok[r] ? uf : um) : T(0);
                 }
@@ -509,7 +510,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 T v;
                 if (HYB && a.ext_phi) {
                     const T *eh = (const T *)a.ext_h + (active ? fi : tile * KB_TILE);
-                    v = (rowany[r] && c < rp) ? __builtin_nontemporal_load(eh + (int64_t)(c * rn + (rowok[r] ? q : 0) + L * r) * a.ext_ld) : T(0);
+                    const T *pe_ = eh + (int64_t)(c * rn + (rowok[r] ? q : 0) + L * r) * a.ext_ld;
+                    v = (rowany[r] && c < rp) ? (L == 8 ? *pe_ : __builtin_nontemporal_load(pe_)) : T(0);
                 } else {
                     v = ldg_if(rowany[r] && c < rp, mo, a.L.mo_H, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um, um);
                 }
