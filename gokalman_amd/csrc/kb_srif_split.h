@@ -601,7 +601,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             const T s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             const T akk = A(r0, k);
             const T sgn = (fabs(akk) <= T(1e-12)) ? T(1) : copysign(T(1), akk);   // helper.go:133-138 Sign
-            const T sigma = sqrt(s) * sgn;
+            const T sigma = sqrt(s) * sgn;   // (a reciprocal-square-root + Newton sequence, 11 instructions for ~25, changed nothing measurable: NOTES.md)
             const T uk = akk + sigma;
             const T beta = recip(sigma * uk);
             if (own) {
@@ -616,7 +616,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             for (int i = k; i < ROWS; i++) u[i] = lf[i * FPW];
             const T bt = lf[ROWS * FPW];
 #pragma unroll
-            for (int r = r0; r < RP; r++) {
+            for (int r = (q0 == L - 1 ? r0 + 1 : r0); r < RP; r++) {   // (q0 = L - 1: no column of slot r0 lies right of k)
                 const bool right = r > r0 || q > q0;   // column j_r lies right of k
                 T g2[2] = {T(0), T(0)};
 #pragma unroll
