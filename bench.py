@@ -187,6 +187,24 @@ def _leg_parity(ga, k, synth, leg):
         out.update({"oracle_filters": M, "max_rel_frobenius_information_vector": ei, "max_rel_frobenius_information_matrix": eI, "tolerance": 1e-9,
                     "ok": bool(ei <= 1e-9 and eI <= 1e-9 and nerr == 0 and not b.status().any())})
         return out
+    if leg == "squareroot_fused":
+        # config C's time-fused kernel (Newton reciprocals, x / S / model resident): against the oracle, and against T one-step launches
+        d = synth.linear_batch(N, N_STATE, N_MEAS, T, seed=synth.SEED + 79)
+        b = ga.FilterBatch.new_ldkf(k.SQUAREROOT, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        b1 = ga.FilterBatch.new_ldkf(k.SQUAREROOT, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
+        y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
+        torch.cuda.synchronize()
+        b.update_steps_dev(y.data_ptr(), N, T)
+        for t in range(T):
+            b1.update_dev(y[t].data_ptr(), N)
+        b.synchronize(); b1.synchronize()
+        xo, Po, nerr = orc.ldkf_batch(orc.SQUAREROOT, d["x0"], d["P0"], d["F"], d["H"], d["Q"], d["R"], d["y"])
+        ex, eP = synth.rel_frobenius(b.get(k.STATE), xo), synth.rel_frobenius(b.get(k.COVAR), Po)
+        out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
+                    "vs_per_step_kernel": {"state": synth.rel_frobenius(b.get(k.STATE), b1.get(k.STATE)),
+                                           "covariance": synth.rel_frobenius(b.get(k.COVAR), b1.get(k.COVAR))},
+                    "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any() and b.step() == T)})
+        return out
     if leg == "fused":
         # kb_update_steps_dev (T steps inside one launch) evaluates the Joseph form in the distributed order with Newton reciprocals:
         # NOT bit-identical to T calls of kb_update_dev (include/gokalman_amd.h) -- held to the oracle like every other leg, and the
@@ -904,6 +922,8 @@ def main():
                     extra[leg]["parity"] = _leg_parity(ga, k, synth, leg)
             if fused:   # the time-fused launch is a different kernel from the headline's: its own gate
                 fused["parity"] = _leg_parity(ga, k, synth, "fused")
+            if "squareroot" in extra and "fused" in extra["squareroot"]:
+                extra["squareroot"]["fused"]["parity"] = _leg_parity(ga, k, synth, "squareroot_fused")
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
             out["cpu_baseline"] = _cpu_baseline(d)
         print(json.dumps(out), flush=True)

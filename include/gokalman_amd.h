@@ -173,12 +173,15 @@ int kb_update_dev(kb_batch *b, const void *meas, int64_t ld_meas,
                   const void *ctrl, int64_t ld_ctrl);
 /* The caller loop `for k { kf.Update(y_k, u_k) }` fused into one launch:
  * meas is planar [T][p][ld] on the device (step t at meas + t*p*ld elements).
- * x, P and the model stay in registers across the T steps where a time-fused register kernel exists (Noiseless Vanilla 6/3
- * and 4/2 without control input); every other kind / shape / noise runs its single-step register kernel T times, back to back
- * on the stream, from this one call.
- * NOT bit-identical to T calls of kb_update_dev where the time-fused kernel runs: it evaluates the Joseph form as
+ * x, P (S) and the model stay in registers across the T steps where a time-fused register kernel exists -- Vanilla 6/3 and 4/2
+ * (Noiseless), Vanilla 6/3 with AWGN or BatchNoise drawn inside the launch, SquareRoot 6/3 (Noiseless); fp64, state-only outputs,
+ * per-filter models, no control input -- every other kind / shape / noise runs its single-step register kernel T times, back to
+ * back on the stream, from this one call.
+ * The Noiseless Vanilla and the SquareRoot time-fused kernels are NOT bit-identical to T calls of kb_update_dev (the AWGN / BatchNoise
+ * one is: it keeps the one-step kernel's operations).  The Noiseless Vanilla kernel evaluates the Joseph form as
  * P+ = AP - (AP H^T - K R) K^T with AP = P- - K (P- H^T)^T and divides by Newton-refined reciprocals, where the per-step kernel
- * keeps the reference's order of operations (vanilla.go:197-205) and IEEE division.  Both are held to the oracle at 1e-9
+ * keeps the reference's order of operations (vanilla.go:197-205) and IEEE division; the SquareRoot kernel replaces the divisions of
+ * the two factorisations by Newton-refined reciprocals (2.5e-15 from T launches).  All are held to the oracle at 1e-9
  * (tests/test_kinds_gpu.py, bench.py `fused.parity`); on degenerate problems (zero noise matrices) use the per-step call. */
 int kb_update_steps_dev(kb_batch *b, const void *meas, int64_t ld_meas,
                         const void *ctrl, int64_t ld_ctrl, int nsteps);
