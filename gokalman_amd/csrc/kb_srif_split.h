@@ -1,8 +1,8 @@
 // kb_srif_split.h -- SRIF Update / Predict (srif.go:101-160, :298-340, helper.go:142-172) in fp64 with ONE FILTER SPLIT OVER L LANES
-// (L = 4 up to 12 states, L = 8 up to 16), any n <= NS and p <= NM at run time (odd n included: the padding is compile-time
-// identity / zero in REGISTERS, only the real bytes move).  Round 5: replaces, for fp64, the two-lane kernel beyond 12 states (panel
-// partly in scratch at one wave per SIMD), the widened shadow copies of kb_srif_odd.hip for odd n, and the statement kernel for
-// Predict() / p = 7, 8 at 13..16 states.
+// (L = 4 up to 12 states, L = 8 up to 16), the state dimension n at compile time (every n = 1 .. 16, odd n included: the padding to
+// the next multiple of L is identity / zero in REGISTERS, only the real bytes move), p <= NM in {4, 6, 8} at run time.  Round 5:
+// replaces, for fp64, the two-lane kernel everywhere but at 12/6 and 6/2 (beyond 12 states its panel sat partly in scratch at one wave
+// per SIMD), the widened shadow copies of kb_srif_odd.hip for odd n, and the statement kernel for Predict() / p = 7, 8 at 13..16 states.
 //
 // Everything is distributed BY COLUMNS (lane = q (64 / L) + f as in kb_vanilla_split.h; lane q of a filter owns columns q, q + L, ...
 // of R, Phi, Htilde and therefore of the Householder panel):
@@ -11,18 +11,20 @@
 //                 by the owner of column i from the lane sum of the partial products, then the owner adds R[:, i] x_i to its partials.
 //                 After a Predict() R is the dense RBar: the part stages R in LDS and one lane per filter runs a pivoted LU solve there
 //                 with rolled loops (cold: once per Predict).
-//   xBar          Phi x: partial products over the own columns + lane sums; every lane ends with all of xBar.
+//   xBar          Phi x: partial products over the own columns, then a reduce-scatter over the lanes: lane q ends with xBar of ITS columns
+//                 (all that bBar = RBar xBar needs of it).
 //   RBar          RBar = R Phi^-1 <=> Phi^T RBar^T = R^T: row j of [Phi^T | R^T] is (column j of Phi | column j of R) -- the lane's own
 //                 data -- so a Gauss-Jordan elimination by ROWS with partial pivoting runs on it with the pivot row handed round
 //                 through LDS (2 n - k values per step) and the elimination local.  Rows are never exchanged physically (the pivot
 //                 row stays where it is, unnormalised, with its scale; LAPACK's row order is tracked as a position per row so that
 //                 ties pick dgetf2's row), a filter that pivoted puts its rows back in order through LDS afterwards (cold).  The lane
-//                 ends with ITS COLUMNS of RBar: exactly the panel's layout.  bBar = RBar xBar: partials + lane sums.
+//                 ends with ITS COLUMNS of RBar: exactly the panel's layout.  bBar = RBar xBar: partials + reduce-scatter, which leaves
+//                 bBar distributed by rows -- where the right-hand side lives (below).
 //   measurement   [L Htilde | L y] (srif.go:146-148; QUIRK :48: chol_L(R), not its inverse): own columns of Htilde, local.
 //   Householder   (helper.go:142-172) by columns as in kb_squareroot_split.h: the ONE lane that owns column k forms sigma, u_k, beta --
-//                 the sums run over the rows in the reference's order -- and hands u and beta to the other lanes of the filter through
-//                 LDS; every lane applies the reflection to its own columns right of k and to the right-hand side, which every lane
-//                 carries (the same instructions a third column slot would cost, and bBar arrives in every lane anyway).
+//                 no sum over lanes; the squares in four partial sums -- and hands u and beta to the other lanes of the filter through
+//                 LDS; every lane applies the reflection to its own columns right of k.  The right-hand side [bBar ; L y] is distributed
+//                 by ROWS (lane q: rows q, q + L, ...): its dot product with u is one lane sum per step, its update 1 / L of the entries.
 //
 // Differences from the statement kernel (rounding level): solves instead of inverse-then-multiply, Newton reciprocals; only exact
 // singularity is flagged (as every register SRIF path, kb_srif_reg.hip).  Failure semantics as everywhere: a singular Phi / R skips
