@@ -11,6 +11,7 @@
 // (__shfl_xor) and adds them to one of 32 replicas with fp64 atomics.  The truth's noise comes
 // from the same Philox stream as kb_mc_run (seed; global run index, step, epoch, draw), so the
 // statistics refer to the same runs as the Monte-Carlo means when the same epoch is replayed.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -848,7 +849,12 @@ int chi_repl() { return CHI_REPL; }
 
 int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc, void *shared_table) {
     bool ok = false;
-    if (tb.dtype == KB_F64)
+    static const bool shared_all = [] { const char *e = getenv("KB_CHISQ_SHARED_ALL"); return e && *e && *e != '0'; }();   // (diagnostic: the fused shapes on the shared-covariance path)
+    // (6,3) with ONE filter fanned out runs the shared-covariance path as well: 10.6 G run-steps/s against 7.5 G on the fused kernel, which
+    // holds a whole Vanilla update per lane in 512 registers at one wave per SIMD (256k runs x 200 steps); the smaller fused shapes stay
+    // ((4,2): 22.3 G fused against 24.0 G shared at 1M runs x 1086 steps, 21.2 against 16.5 at 256k x 200 -- the serial recursion's share)
+    const bool shared_63 = shared_table && n == 6 && p == 3;
+    if (tb.dtype == KB_F64 && !(shared_all && shared_table) && !shared_63)
         ok = chi_try<double, 2, 1>(tb, a, n, p, nc) || chi_try<double, 3, 1>(tb, a, n, p, nc) || chi_try<double, 4, 2>(tb, a, n, p, nc) ||
              chi_try<double, 6, 3>(tb, a, n, p, nc);
     if (!ok && tb.dtype == KB_F64 && n <= 16 && p <= 8 && nc <= 2 && shared_table) {
@@ -856,7 +862,9 @@ int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc, void *
         if (n <= 8) hipLaunchKernelGGL((chisq_cov_kernel<double, 8>), dim3(1), dim3(256), 0, tb.stream, a, n, p, (double *)shared_table);
         else hipLaunchKernelGGL((chisq_cov_kernel<double, 16>), dim3(1), dim3(256), 0, tb.stream, a, n, p, (double *)shared_table);
         const dim3 grid = tile_grid(a.ntiles), block(256);
-        if (n <= 8) hipLaunchKernelGGL((chisq_shared_kernel<double, 8>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
+        if (n <= 4) hipLaunchKernelGGL((chisq_shared_kernel<double, 4>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
+        else if (n <= 6) hipLaunchKernelGGL((chisq_shared_kernel<double, 6>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
+        else if (n <= 8) hipLaunchKernelGGL((chisq_shared_kernel<double, 8>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
         else if (n <= 12) hipLaunchKernelGGL((chisq_shared_kernel<double, 12>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
         else hipLaunchKernelGGL((chisq_shared_kernel<double, 16>), grid, block, 0, tb.stream, a, n, p, nc, (const double *)shared_table);
         ok = true;

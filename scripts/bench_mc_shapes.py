@@ -13,7 +13,7 @@ for (n, p, runs, steps) in [(12, 6, 1 << 18, 200), (16, 8, 1 << 18, 200), (8, 4,
     mc = ga.new_monte_carlo_runs(runs, steps, p, np.zeros((1, 1)), truth, keep_runs=False)
     dt = time.perf_counter() - t0
     print("MC n=%d: %d runs x %d steps in %.1f ms = %.2f G run-steps/s" % (n, runs, steps, dt * 1e3, runs * steps / dt / 1e9), flush=True)
-for (n, p, runs, steps) in [(12, 6, 1 << 18, 200), (8, 4, 1 << 18, 200), (16, 8, 1 << 18, 200), (9, 3, 1 << 18, 200), (12, 6, 1 << 14, 50)]:
+for (n, p, runs, steps) in [(12, 6, 1 << 18, 200), (8, 4, 1 << 18, 200), (16, 8, 1 << 18, 200), (9, 3, 1 << 18, 200), (6, 3, 1 << 18, 200), (4, 2, 1 << 18, 200), (12, 6, 1 << 14, 50)]:
     rng = np.random.default_rng(n)
     F = np.eye(n) + 0.01 * rng.standard_normal((n, n)); H = rng.standard_normal((p, n))
     A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n); R = 1e-2 * np.eye(p)
