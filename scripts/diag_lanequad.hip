@@ -13,6 +13,14 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
+// -DPLAIN: the segment loads with the default cache policy instead of the streaming hint (round 5: with the hint a line whose halves /
+// quarters are read by different workgroups leaves the L2 in between and comes from memory again, kb_srif_split.h)
+#ifdef PLAIN
+#define LDSEG(p) (*(p))
+#else
+#define LDSEG(p) __builtin_nontemporal_load(p)
+#endif
+
 constexpr int E = 340, W = 90, EP = 228;   // EP: words that arrive caller-planar
 
 template <int MODE>
@@ -45,7 +53,7 @@ __global__ void __launch_bounds__(MODE == 1 ? 256 : 64) k(const float *__restric
         const float *con = in + tile * (long)(E * 64) + quarter * (E * 16) + lane;          // [g][4][16] per quarter tile
         constexpr int NSEG = MODE == 5 ? 0 : (MODE == 4 ? EP / 4 : E / 4);
 #pragma unroll 19
-        for (int g = 0; g < NSEG; g++) acc0 += __builtin_nontemporal_load(seg + (4 * g) * 64);
+        for (int g = 0; g < NSEG; g++) acc0 += LDSEG(seg + (4 * g) * 64);
 #pragma unroll 17
         for (int g = NSEG; g < E / 4; g++) acc1 += __builtin_nontemporal_load(con + g * 64);
         if constexpr (MODE >= 4) {
