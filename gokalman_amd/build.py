@@ -9,6 +9,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -34,7 +35,7 @@ _PAIR = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]
 _UNROLL = ["-mllvm", "-pragma-unroll-threshold=200000"]
 EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR, "kb_srif_pair32b.hip": _PAIR, "kb_srif_pair32c.hip": _PAIR, "kb_srif_pair32d.hip": _PAIR, "kb_srif_pair32e.hip": _PAIR, "kb_srif_pair32f.hip": _PAIR, "kb_srif_pair32g.hip": _PAIR, 
          "kb_vanilla_split12.hip": _UNROLL, "kb_vanilla_split16.hip": _UNROLL, "kb_vanilla_split12p.hip": _UNROLL, "kb_hybrid_split.hip": _UNROLL, "kb_hybrid_split8.hip": _UNROLL, "kb_vanilla_split16p.hip": _UNROLL, "kb_squareroot_split12.hip": _UNROLL, "kb_squareroot_split12p.hip": _UNROLL, "kb_squareroot_split16p.hip": _UNROLL, "kb_squareroot_split16.hip": _UNROLL, "kb_information_split12.hip": _UNROLL, "kb_information_split8.hip": _UNROLL, "kb_information_split12f.hip": _UNROLL,
-         "kb_srif_split_a.hip": _UNROLL, "kb_srif_split_b.hip": _UNROLL, "kb_srif_split_c.hip": _UNROLL, "kb_srif_split_d.hip": _UNROLL, "kb_srif_split_e.hip": _UNROLL}
+         "kb_srif_split_a.hip": _UNROLL, "kb_srif_split_b.hip": _UNROLL, "kb_srif_split_c.hip": _UNROLL, "kb_srif_split_d.hip": _UNROLL, "kb_srif_split_e.hip": _UNROLL, "kb_srif_split_f32a.hip": _UNROLL, "kb_srif_split_f32b.hip": _UNROLL, "kb_srif_split_f32c.hip": _UNROLL, "kb_srif_split_f32d.hip": _UNROLL}
 
 
 # file-name prefixes of the kernel families whose translation units MUST have an EXTRA entry
@@ -69,18 +70,23 @@ def _compile(src, force):
             same_cmd = False
         if deps and same_cmd and all(os.path.exists(d) and os.path.getmtime(d) < os.path.getmtime(obj) for d in deps):
             return obj
+    t0 = time.perf_counter()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))
     with open(cmdf, "w") as fh:
         fh.write(" ".join(cmd))
+    _TIMES[base] = time.perf_counter() - t0
     return obj
 
 
+_TIMES = {}   # seconds per translation unit compiled by this process (printed by --times)
+
 # translation units that take the longest to compile (seconds on this image), for the scheduling order of a build from scratch
-_SLOW = {"kb_srif_pair32g.hip": 150, "kb_srif_pair32f.hip": 110, "kb_information_reg.hip": 100, "kb_vanilla_shared.hip": 90, "kb_srif_pair32c.hip": 80,
-         "kb_srif_pair32b.hip": 70, "kb_srif_pair32e.hip": 70, "kb_srif_reg.hip": 60, "kb_srif_pair64.hip": 55, "kb_squareroot_reg.hip": 45,
-         "kb_srif_pair32d.hip": 40, "kb_vanilla_strict.hip": 40, "kb_hybrid_pad8.hip": 35, "kb_srif_pair32.hip": 35}
+_SLOW = {"kb_srif_pair32g.hip": 82, "kb_srif_pair32c.hip": 66, "kb_srif_pair32e.hip": 63, "kb_srif_pair32f.hip": 59, "kb_srif_pair32b.hip": 48,
+         "kb_srif_pair64.hip": 44, "kb_srif_split_e.hip": 44, "kb_srif_split_f32d.hip": 42, "kb_squareroot_split16p.hip": 41, "kb_srif_split_d.hip": 40,
+         "kb_srif_split_f32c.hip": 35, "kb_srif_split_c.hip": 35, "kb_information_reg.hip": 34, "kb_srif_split_b.hip": 33, "kb_squareroot_split12p.hip": 33,
+         "kb_vanilla_shared.hip": 30}
 
 
 def _cost(src):
@@ -97,7 +103,7 @@ def build(force=False, verbose=False):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if (force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", "-s", "--offload-arch=" + ARCH, "-o", LIB] + objs   # (-s: no host symbol table; the C ABI is in .dynsym, the kernels' names in the code objects)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s" % res.stderr[-4000:])
@@ -108,3 +114,6 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--times" in sys.argv:
+        for name, sec in sorted(_TIMES.items(), key=lambda kv: -kv[1])[:16]:
+            print("%6.1f s  %s" % (sec, name))

@@ -204,12 +204,10 @@ static int input_target(Batch &b, int field, int p_rows, FieldTarget &t) {
     const Layout &L = b.L;
     switch (field) {
     case KB_X:
-        b.sh_state_current = false;
         t.block = b.d_state; t.block_elems = L.st_elems; t.src_elems = n;
         map_dense(1, n, L.st_vec, n, t.map);
         return KB_OK;
     case KB_P:
-        b.sh_state_current = false;
         t.block = b.d_state; t.block_elems = L.st_elems; t.src_elems = n * n;
         if (L.st_mat_full) map_dense(n, n, L.st_mat, n, t.map); else map_sym_in(n, L.st_mat, t.map);
         return KB_OK;
@@ -391,7 +389,7 @@ void kb_destroy(kb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_state, b->d_state0, b->d_est, b->d_model, b->d_status,
-                    b->d_sh_state, b->d_sh_model, b->d_sh_est, b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_chi_table, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
+                    b->d_stage, b->d_y, b->d_u, b->d_y2, b->d_xp, b->d_flags, b->d_mc, b->d_chi_table, b->d_ctrl, b->d_bn_proc, b->d_bn_meas, b->d_traj,
                     b->h_lag ? nullptr : (void *)b->d_lag, (void *)b->d_srif_dense};
     for (void *p : ptrs)
         if (p) (void)dev_free(p);
@@ -500,7 +498,6 @@ int kb_init(kb_batch *b) {
         if (required && !b->have[f]) { set_error("kb_init: %s has not been set", names[f]); return KB_ERR_INVALID; }
     }
     int not_pd = 0;
-    b->sh_state_current = false;
     if ((rc = launch_init(*b, &not_pd))) return rc;
     if (not_pd) {
         set_error("constructor: matrix is not positive definite (Cholesky failed for %d filter(s))", not_pd);
@@ -517,7 +514,6 @@ int kb_reset(kb_batch *b) {
     if (!b || !b->initialized) { set_error("batch not initialised"); return KB_ERR_INVALID; }
     int rc = use_device(*b);
     if (rc) return rc;
-    b->sh_state_current = false;
     KB_HIP(hipMemcpyAsync(b->d_state, b->d_state0, b->block_bytes(b->L.st_elems), hipMemcpyDeviceToDevice, b->stream));
     if (b->d_est) KB_HIP(hipMemsetAsync(b->d_est, 0, b->block_bytes(b->L.es_elems), b->stream));
     KB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)b->ntiles * KB_TILE * sizeof(uint32_t), b->stream));

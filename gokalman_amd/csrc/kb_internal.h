@@ -40,8 +40,6 @@ struct Batch {
     hipStream_t stream = nullptr;
     void *d_state = nullptr, *d_state0 = nullptr;  // current / initial estimate
     void *d_est = nullptr;
-    mutable void *d_sh_state = nullptr, *d_sh_model = nullptr, *d_sh_est = nullptr;   // KB_SRIF with an odd n: the widened shadow blocks (kb_srif_odd.hip)
-    mutable bool sh_state_current = false;   // ... the shadow state block equals d_state (last writer: an odd-n step; cleared by every other writer of d_state)
     void *d_model = nullptr;
     uint32_t *d_status = nullptr;
     // kf.step per filter.  The reference returns from a failed Update BEFORE `kf.step++` (vanilla.go:164-167 / :207-215 against
@@ -201,8 +199,6 @@ bool hybrid_split_ok(const Batch &b, const StepArgs &a);
 bool launch_hybrid_split(const Batch &b, const StepArgs &a);     // kb_hybrid_split.hip: 8 < n <= 16, p <= 6, on the split-lane Vanilla kernel (HYB)
 bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_strict.hip: KB_FLAG_STRICT_SYMCHECK on registers (6 / 1..3, fp64)
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
-bool srif_odd_ok(const Batch &b, const StepArgs &a);      // kb_srif_odd.hip: 1..5, 7, 9, 11 states on the next instantiation (6, 8, 10, 12)
-int launch_srif_odd(const Batch &b, const StepArgs &a);
 // kb_srif_split_*.hip: fp64, one filter over 4 (n <= 12) / 8 (n <= 16) lanes, the state dimension at compile time, p at run time (kb_srif_split.h)
 void launch_srif_split_n1(const Batch &b, const StepArgs &a);
 void launch_srif_split_n2(const Batch &b, const StepArgs &a);
@@ -220,6 +216,19 @@ void launch_srif_split_n13(const Batch &b, const StepArgs &a);
 void launch_srif_split_n14(const Batch &b, const StepArgs &a);
 void launch_srif_split_n15(const Batch &b, const StepArgs &a);
 void launch_srif_split_n16(const Batch &b, const StepArgs &a);
+// kb_srif_split_f32*.hip: fp32, four lanes per filter: the shapes the two-lane fp32 kernels do not serve
+void launch_srif_split_f32_n1(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n2(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n3(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n4(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n5(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n7(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n9(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n11(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n13(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n14(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n15(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n16(const Batch &b, const StepArgs &a);
 Layout make_layout(int kind, int n, int pmax, int m, unsigned flags);   // kb_api.hip
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip

@@ -198,13 +198,21 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
     return true;
 }
 
-// fp64 shapes of the split-lane kernel (kb_srif_split.h, round 5): everything up to 16 / 8 except 12/6 and 6/2; Update and Predict.  KB_SRIF_SPLIT_ALL=1 (environment, diagnostic) sends every fp64 shape there.
+// Shapes of the split-lane kernel (kb_srif_split.h, round 5): fp64 everything up to 16 / 8 except 12/6 and 6/2; fp32 what the two-lane kernels do not serve; Update and Predict.  KB_SRIF_SPLIT_ALL=1 (environment, diagnostic) sends every fp64 shape there.
 static bool srif_split_all() {
     static const bool on = [] { const char *e = getenv("KB_SRIF_SPLIT_ALL"); return e && *e && *e != '0'; }();
     return on;
 }
 bool srif_split_ok(const Batch &b, const StepArgs &a) {
-    if (b.dtype != KB_F64 || (a.flags & KB_FLAG_STATEMENT_KERNELS) || a.n < 1 || a.n > 16 || a.p < 1 || a.p > 8) return false;
+    if ((a.flags & KB_FLAG_STATEMENT_KERNELS) || a.n < 1 || a.n > 16 || a.p < 1 || a.p > 8) return false;
+    if (b.dtype == KB_F32) {
+        // fp32: the two-lane kernels keep the even state dimensions 6 .. 16 (14, 16: Update with p <= 6 only); everything else -- odd n,
+        // n < 6 (round 4: widened shadow copies, ~2x the bytes: 7/3 116 us, 11/4 258 us), Predict() and p = 7, 8 at 14 / 16 states
+        // (round 4: the statement kernel) -- runs the split kernel on four lanes per filter
+        if ((a.n & 1) || a.n < 6) return true;
+        // (p = 7, 8 at the even n up to 12 stays two-lane: 6/8 45 us against 74 on the split kernel, 8/8 57 / 87, 10/8 83 / 159, 12/8 116 / 172)
+        return a.n > 12 && (a.predict || a.p > 6);
+    }
     // (measured, 256k filters, us per step, split / two-lane kernel: 12/8 232 / 390, 8/8 140 / 172, 12/5 201 / 234, 12/2 181 / 182, 10/8
     // 201 / 204, 10/6 183 / 177, 10/4 166 / 152, 8/2 83 / 71, 12/6 235 / 214, 6/2 64 / 39.  The two-lane fp64 kernel keeps the benchmark shape
     // 12/6 and the reference tests' 6/2; everything else takes the split kernel -- within 15 % where it loses, and eighteen two-lane
@@ -217,8 +225,11 @@ static int launch_srif_split(const Batch &b, const StepArgs &a) {
                                       launch_srif_split_n6, launch_srif_split_n7, launch_srif_split_n8, launch_srif_split_n9, launch_srif_split_n10,
                                       launch_srif_split_n11, launch_srif_split_n12, launch_srif_split_n13, launch_srif_split_n14, launch_srif_split_n15,
                                       launch_srif_split_n16};
-    if (a.state == b.d_state) b.sh_state_current = false;
-    by_n[a.n](b, a);
+    static const launch_t by_n32[17] = {nullptr, launch_srif_split_f32_n1, launch_srif_split_f32_n2, launch_srif_split_f32_n3, launch_srif_split_f32_n4,
+                                        launch_srif_split_f32_n5, nullptr, launch_srif_split_f32_n7, nullptr, launch_srif_split_f32_n9, nullptr,
+                                        launch_srif_split_f32_n11, nullptr, launch_srif_split_f32_n13, launch_srif_split_f32_n14, launch_srif_split_f32_n15,
+                                        launch_srif_split_f32_n16};
+    (b.dtype == KB_F32 ? by_n32 : by_n)[a.n](b, a);
     KB_HIP(hipGetLastError());
     return KB_OK;
 }
@@ -227,7 +238,6 @@ static int launch_srif_split(const Batch &b, const StepArgs &a) {
 bool srif_reg_ok(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return false;
     if (srif_split_ok(b, a)) return true;
-    if ((a.n & 1) || a.n < 6) return srif_odd_ok(b, a);
     if (!a.predict && a.ext_ld >= (int64_t(1) << 28)) return false;   // the two-lane kernel's 32-bit byte offsets (kb_srif_pair.h)
     if (a.n == 14 || a.n == 16) return b.dtype == KB_F32 && !a.predict && a.p >= 1 && a.p <= 6;   // (fp32, Update only: kb_srif_pair32f.hip ...)
     if (a.n != 6 && a.n != 8 && a.n != 10 && a.n != 12) return false;
@@ -237,8 +247,6 @@ bool srif_reg_ok(const Batch &b, const StepArgs &a) {
 int launch_srif(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_srif_gen(b, a);
     if (srif_split_ok(b, a)) return launch_srif_split(b, a);   // kb_srif_split.h
-    if (((a.n & 1) || a.n < 6) && srif_odd_ok(b, a)) return launch_srif_odd(b, a);   // kb_srif_odd.hip
-    if (a.state == b.d_state) b.sh_state_current = false;   // (every other kernel writes the state block itself: a widened copy of it is stale)
     bool done = false;
     if (!a.predict) done = b.dtype == KB_F32 ? (launch_srif_pair_f32(b, a) || launch_srif_pair_f32b(b, a) || launch_srif_pair_f32c(b, a) || launch_srif_pair_f32d(b, a) || launch_srif_pair_f32e(b, a) || launch_srif_pair_f32f(b, a) || launch_srif_pair_f32g(b, a))
                                              : launch_srif_pair_f64(b, a);   // kb_srif_pair.h

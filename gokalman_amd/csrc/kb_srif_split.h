@@ -43,6 +43,30 @@ __device__ __forceinline__ void argmax_pick(double v0, unsigned t0, double v1, u
     v = take1 ? v1 : v0;
     t = take1 ? t1 : t0;
 }
+__device__ __forceinline__ void argmax_pick(float v0, unsigned t0, float v1, unsigned t1, float &v, unsigned &t) {
+    const bool take1 = v1 > v0 || (v1 == v0 && (t1 & 0xffu) < (t0 & 0xffu));
+    v = take1 ? v1 : v0;
+    t = take1 ? t1 : t0;
+}
+template <int L>
+__device__ __forceinline__ void argmax_lanes(float &v, unsigned &tag) {
+    {
+        const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const auto t = __builtin_amdgcn_permlane32_swap(tag, tag, false, false);
+        argmax_pick(__uint_as_float(x[0]), t[0], __uint_as_float(x[1]), t[1], v, tag);
+    }
+    if constexpr (L >= 4) {
+        const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const auto t = __builtin_amdgcn_permlane16_swap(tag, tag, false, false);
+        argmax_pick(__uint_as_float(x[0]), t[0], __uint_as_float(x[1]), t[1], v, tag);
+    }
+    if constexpr (L >= 8) {
+        const float ov = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));
+        const unsigned ot = (unsigned)__builtin_amdgcn_update_dpp(0, (int)tag, 0x128, 0xf, 0xf, false);
+        const bool up = (threadIdx.x & 8u) != 0u;
+        argmax_pick(up ? ov : v, up ? ot : tag, up ? v : ov, up ? tag : ot, v, tag);
+    }
+}
 template <int L>
 __device__ __forceinline__ void argmax_lanes(double &v, unsigned &tag) {
     {
@@ -88,16 +112,29 @@ __device__ __forceinline__ double rs8(double a, double b) {    // lanes with bit
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), 0x128, 0xf, 0xf, false);
     return keep + __hiloint2double(hi, lo);
 }
-template <int L, int NS>
-__device__ __forceinline__ void reduce_scatter(const double (&v)[NS], double (&own)[NS / L]) {
+__device__ __forceinline__ float rs32(float a, float b) {
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(x[0]) + __uint_as_float(x[1]);
+}
+__device__ __forceinline__ float rs16(float a, float b) {
+    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(x[0]) + __uint_as_float(x[1]);
+}
+__device__ __forceinline__ float rs8(float a, float b) {
+    const bool up = (threadIdx.x & 8u) != 0u;
+    const float send = up ? a : b, keep = up ? b : a;
+    return keep + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(send), 0x128, 0xf, 0xf, false));
+}
+template <int L, int NS, typename T>
+__device__ __forceinline__ void reduce_scatter(const T (&v)[NS], T (&own)[NS / L]) {
     static_assert(L == 4 || L == 8, "lanes per filter");
     constexpr int RP = NS / L;
-    double w1[NS / 2];
+    T w1[NS / 2];
 #pragma unroll
     for (int r = 0; r < RP; r++)
 #pragma unroll
         for (int qq = 0; qq < L / 2; qq++) w1[qq + (L / 2) * r] = rs32(v[qq + L * r], v[qq + L / 2 + L * r]);
-    double w2[NS / 4];
+    T w2[NS / 4];
 #pragma unroll
     for (int r = 0; r < RP; r++)
 #pragma unroll
@@ -122,9 +159,8 @@ constexpr int srif_split_lds_elems() {
 
 // N: the state dimension, exact (the panel is padded to NS = the next multiple of L in registers: identity / zero, never loaded or
 // stored); NM >= p, the measurement dimension at run time.
-template <int N, int NM, int L>
-__device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t gw, double *lds) {
-    typedef double T;
+template <typename T, int N, int NM, int L>
+__device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     constexpr int NS = (N + L - 1) / L * L;
     static_assert(N >= 1 && NS <= 16 && NM <= 8, "columns are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, ROWS = NS + NM, rn = N;
@@ -158,7 +194,9 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
     // 128-byte segment.  At eight lanes a group reads HALF a line and the part next door reads the other half a little later: with the
     // streaming hint the line is gone from the L2 by then and comes from memory twice (counters, 16/6: 5837 B read per filter-step against
     // 4296 B packed; two-wave workgroups over neighbouring parts did not help and cost 8 % -- NOTES.md), so there the default policy.
-    auto ldstream = [&](auto ptr) __attribute__((always_inline)) { if constexpr (L == 8) return *ptr; else return __builtin_nontemporal_load(ptr); };
+    // (fp32: four lanes per filter are 64-byte segments as well -- scripts/diag_lanequad.hip -DPLAIN: 6.2 TB/s with the default policy, 4.6 with the hint)
+    constexpr bool PART_LINE = FPW * (int)sizeof(T) < 128;
+    auto ldstream = [&](auto ptr) __attribute__((always_inline)) { if constexpr (PART_LINE) return *ptr; else return __builtin_nontemporal_load(ptr); };
     int jr[RP];
     bool colok[RP];
 #pragma unroll
@@ -318,7 +356,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             for (int r = 0; r < RP; r++) s += Pc[r][i] * xs[r];
             xb[i] = s;
         }
-        reduce_scatter<L, NS>(xb, xbo);
+        reduce_scatter<L, NS, T>(xb, xbo);
 #pragma unroll
         for (int r = 0; r < RP; r++) pin(xbo[r]);
     }
@@ -469,7 +507,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             for (int r = 0; r < RP; r++) s += Rc[r][i] * xbo[r];
             part[i] = s;
         }
-        reduce_scatter<L, NS>(part, bbo);   // bBar[j_r] in the owner of column j_r
+        reduce_scatter<L, NS, T>(part, bbo);   // bBar[j_r] in the owner of column j_r
     }
     err = sum_lanes<L>(err);   // a failure anywhere fails the filter (flags: OR)
     const bool ok = active && err == 0;   // failed: (b, R) stay as they are, srif.go:111-114 returns before any assignment and before kf.step++
@@ -541,13 +579,13 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 #pragma unroll
         for (int m = 0; m < NM; m++)
 #pragma unroll
-            for (int l = 0; l <= m; l++) LR[symi(l, m)] = m < rp ? __builtin_nontemporal_load(ep(mo, a.L.mo_LR, symi(l, m)) + um) : T(0);
+            for (int l = 0; l <= m; l++) LR[symi(l, m)] = m < rp ? ldstream(ep(mo, a.L.mo_LR, symi(l, m)) + um) : T(0);
         {
             const T *yr = (const T *)a.y + tile * a.y_ts, *yc = (const T *)a.y2 + tile * a.y2_ts;
 #pragma unroll
             for (int m = 0; m < NM; m++) {
-                const T re = m < rp ? __builtin_nontemporal_load(yr + ((int64_t)m * a.y_es + us)) : T(0);
-                const T co = m < rp ? __builtin_nontemporal_load(yc + ((int64_t)m * a.y2_es + us)) : T(0);
+                const T re = m < rp ? ldstream(yr + ((int64_t)m * a.y_es + us)) : T(0);
+                const T co = m < rp ? ldstream(yc + ((int64_t)m * a.y2_es + us)) : T(0);
                 real[m] = re;
                 yv[m] = re - co;   // srif.go:143-144
             }
@@ -680,24 +718,37 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
     }
 }
 
-template <int N, int NM, int L>
+template <typename T, int N, int NM, int L>
 __global__ void __launch_bounds__(64, (N <= 8 && NM <= 4) ? 3 : 2) srif_split_kernel(const StepArgs a) {
-    __shared__ double lds[srif_split_lds_elems<(N + L - 1) / L * L, NM, L>()];
-    srif_split_part<N, NM, L>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
+    __shared__ T lds[srif_split_lds_elems<(N + L - 1) / L * L, NM, L>()];
+    srif_split_part<T, N, NM, L>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
 }
 
-// four lanes per filter up to 12 states, eight beyond (LDS: (NS^2 + NS) doubles per filter; registers: NS / L rows of 2 NS values)
-template <int N, int NM>
+// fp64: four lanes per filter up to 12 states, eight beyond (LDS: (NS^2 + NS) elements per filter; registers: NS / L rows of 2 NS values).
+// fp32: four lanes throughout (half the registers and half the LDS per value).
+template <typename T, int N, int NM>
 static void srif_split_launch(const Batch &b, const StepArgs &a) {
-    constexpr int L = N <= 12 ? 4 : 8;
-    hipLaunchKernelGGL((srif_split_kernel<N, NM, L>), dim3((unsigned)(a.ntiles * L)), dim3(64), 0, b.stream, a);
+    constexpr int L = (N <= 12 || sizeof(T) == 4) ? 4 : 8;
+    hipLaunchKernelGGL((srif_split_kernel<T, N, NM, L>), dim3((unsigned)(a.ntiles * L)), dim3(64), 0, b.stream, a);
 }
 // one translation unit per group of state dimensions (kb_srif_split_*.hip): p <= 4, p <= 6 and p <= 8 instantiations of each
 #define KB_SRIF_SPLIT_TU(N_)                                                                                              \
     void launch_srif_split_n##N_(const Batch &b, const StepArgs &a) {                                                     \
-        if (a.p <= 4) srif_split_launch<N_, 4>(b, a);                                                                     \
-        else if (a.p <= 6) srif_split_launch<N_, 6>(b, a);                                                                \
-        else srif_split_launch<N_, 8>(b, a);                                                                              \
+        if (a.p <= 4 || a.predict) srif_split_launch<double, N_, 4>(b, a);   /* (Predict() never sees the measurement) */ \
+        else if (a.p <= 6) srif_split_launch<double, N_, 6>(b, a);                                                        \
+        else srif_split_launch<double, N_, 8>(b, a);                                                                      \
+    }
+// n < 6: no p <= 6 instantiation (p = 5, 6 beside fewer than six states is no shape anybody times: library size)
+#define KB_SRIF_SPLIT_TU_SMALL(N_)                                                                                        \
+    void launch_srif_split_n##N_(const Batch &b, const StepArgs &a) {                                                     \
+        if (a.p <= 4 || a.predict) srif_split_launch<double, N_, 4>(b, a);                                                \
+        else srif_split_launch<double, N_, 8>(b, a);                                                                      \
+    }
+// fp32 (kb_srif_split_f32*.hip): the shapes the two-lane fp32 kernels do not serve -- odd n, n < 6, and Predict() / p = 7, 8 at 14, 16 states
+#define KB_SRIF_SPLIT_TU_F32(N_)                                                                                          \
+    void launch_srif_split_f32_n##N_(const Batch &b, const StepArgs &a) {                                                 \
+        if (a.p <= 4 || a.predict) srif_split_launch<float, N_, 4>(b, a);                                                 \
+        else srif_split_launch<float, N_, 8>(b, a);   /* (no p <= 6 instantiation in fp32: library size) */               \
     }
 #undef KB_SB
 

@@ -3,11 +3,11 @@
 
 namespace kb {
 
-KB_SRIF_SPLIT_TU(1)
-KB_SRIF_SPLIT_TU(2)
-KB_SRIF_SPLIT_TU(3)
-KB_SRIF_SPLIT_TU(4)
-KB_SRIF_SPLIT_TU(5)
+KB_SRIF_SPLIT_TU_SMALL(1)
+KB_SRIF_SPLIT_TU_SMALL(2)
+KB_SRIF_SPLIT_TU_SMALL(3)
+KB_SRIF_SPLIT_TU_SMALL(4)
+KB_SRIF_SPLIT_TU_SMALL(5)
 KB_SRIF_SPLIT_TU(6)
 
 }  // namespace kb

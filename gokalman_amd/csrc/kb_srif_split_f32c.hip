@@ -1,0 +1,10 @@
+// kb_srif_split_f32c.hip -- SRIF Update / Predict in fp32, one filter over four lanes (kb_srif_split.h): n = 13 14 -- shapes the two-lane
+// fp32 kernels (kb_srif_pair32*.hip) do not serve (odd n, n < 6; at 14 / 16 states Predict() and p = 7, 8); p <= 4, 6 and 8.
+#include "kb_srif_split.h"
+
+namespace kb {
+
+KB_SRIF_SPLIT_TU_F32(13)
+KB_SRIF_SPLIT_TU_F32(14)
+
+}  // namespace kb

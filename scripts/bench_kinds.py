@@ -256,16 +256,16 @@ if "srifpad" in which:
         for flags, nm in ((0, "two lanes per filter"), (k.FLAG_STATEMENT_KERNELS, "statement kernel")):
             if flags and "--with-statement" not in sys.argv:
                 continue
-            b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=k.F64, flags=flags)
+            b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=(k.F32 if "--srif-f32" in sys.argv else k.F64), flags=flags)
             b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
-            Phi = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=torch.float64, device="cuda")).contiguous()
-            Ht = torch.randn(p * n, N, dtype=torch.float64, device="cuda")
-            real = torch.randn(p, N, dtype=torch.float64, device="cuda"); comp = real + 1e-2 * torch.randn(p, N, dtype=torch.float64, device="cuda")
+            Phi = (torch.eye(n, dtype=(torch.float32 if "--srif-f32" in sys.argv else torch.float64), device="cuda").reshape(n * n, 1) + 1e-2 * torch.randn(n * n, N, dtype=(torch.float32 if "--srif-f32" in sys.argv else torch.float64), device="cuda")).contiguous()
+            Ht = torch.randn(p * n, N, dtype=(torch.float32 if "--srif-f32" in sys.argv else torch.float64), device="cuda")
+            real = torch.randn(p, N, dtype=(torch.float32 if "--srif-f32" in sys.argv else torch.float64), device="cuda"); comp = real + 1e-2 * torch.randn(p, N, dtype=(torch.float32 if "--srif-f32" in sys.argv else torch.float64), device="cuda")
             def step():
                 k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
                 k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
             ms = timed(b, step, K=10 if not flags else 3, warm=3 if not flags else 1)
-            report("SRIF %d/%d f64, %s (prepare_dev + update_nl_dev)" % (n, p, "register kernel" if not flags else nm), N, ms, rl.algorithmic_bytes("srif", n, p), {"errors": int(np.count_nonzero(b.status()))},
+            report("SRIF %d/%d %s, %s (prepare_dev + update_nl_dev)" % (n, p, "f32" if "--srif-f32" in sys.argv else "f64", "register kernel" if not flags else nm), N, ms, rl.algorithmic_bytes("srif", n, p), {"errors": int(np.count_nonzero(b.status()))},
                    moved=rl.moved_bytes("srif", n, p))
             del b
 

@@ -27,8 +27,10 @@ RULES = [
     (r"^void vanilla_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "Vanilla 12/6 exact, four lanes"),
     (r"^void squareroot_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "SquareRoot 12/6 exact"),
     (r"^void information_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "Information 12/6 exact"),
-    (r"^void srif_split_kernel<\d+, (4|6), (4|8)>", 0, 2, "SRIF fp64 split, p <= 6 (every n)"),
-    (r"^void srif_split_kernel<\d+, 8, (4|8)>", 16, 2, "SRIF fp64 split, p = 7, 8"),
+    (r"^void srif_split_kernel<double, \d+, (4|6), (4|8)>", 0, 2, "SRIF fp64 split, p <= 6 (every n)"),
+    (r"^void srif_split_kernel<double, \d+, 8, (4|8)>", 16, 2, "SRIF fp64 split, p = 7, 8"),
+    (r"^void srif_split_kernel<float, ([1-9]|11|15), (4|8), 4>", 0, 2, "SRIF fp32 split, odd n and n < 6"),
+    (r"^void srif_split_kernel<float, (13|14|16), (4|8), 4>", 64, 2, "SRIF fp32 split at 13 / 14 / 16 states (16 filters per wave: the elimination rows fill the register file)"),
     (r"^void mc_kernel<double, 4, 2, ", 0, 2, "config D(i): Monte-Carlo statOD5044"),
 ]
 
