@@ -1,7 +1,7 @@
 """Every shape of the north star's envelope once: n = 1..16 states x p = 1..8 measurements (m = 0, 1, 2 controls and
 KB_FLAG_FULL_ESTIMATE alternating with the shape), Vanilla / SquareRoot / Information / HybridKF / SRIF, a batch that ends inside a tile,
 three steps, against the CPU oracle.  The other GPU tests pick shapes per kernel; this one is about the DISPATCH -- whichever kernel a
-shape lands on (exact, padded, split-lane, widened, statement), the result is the reference's."""
+shape lands on (exact, padded, split-lane, statement), the result is the reference's."""
 import numpy as np
 import pytest
 

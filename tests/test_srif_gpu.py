@@ -108,7 +108,7 @@ def test_srif_singular_phi_skips_only_that_step(n, p, dtype, tol, fail_step):
     Predict() on the generic kernel between Updates on the two-lane one; 8 / 10 / 12 states with 2 / 4 measurements run further
     instantiations of the two-lanes-per-filter kernel (kb_srif_pair*b.hip, *c.hip) and of the Predict() kernel; an odd number of measurements runs
     the next even instantiation with a padded row (kb_srif_pair.h PADM); an odd number of states (5 with p != 2, 7, 9, 11) the next even
-    one as diag(filter, one uncoupled state) (kb_srif_odd.hip)."""
+    one as diag(filter, one uncoupled state) (round 4: kb_srif_odd.hip; round 5: natively on kb_srif_split.h)."""
     rng = np.random.default_rng(100 * n + fail_step)
     N, steps = 130, 6
     bad = [7, 70, 129]
@@ -234,7 +234,8 @@ def test_srif_leftover_dense_tiles_and_a_new_failure_update_every_filter_once(n,
 
 @pytest.mark.parametrize("n,p,dtype,tol", [(7, 3, k.F64, 1e-9), (11, 4, k.F64, 1e-9), (9, 2, k.F32, SRIF_F32_TOL)])
 def test_srif_odd_states_shadow_follows_every_other_writer_of_the_state(n, p, dtype, tol):
-    """kb_srif_odd.hip keeps the widened copy of the state between consecutive steps; kb_reset and a step that fails for some filters
+    """(Written for round 4's kb_srif_odd.hip, which kept a widened copy of the state between consecutive steps; the odd shapes now run
+    natively on kb_srif_split.h and the sequence stays as a regression test.)  kb_reset and a step that fails for some filters
     have to show in the step after them, and a second handle has its own copy."""
     rng = np.random.default_rng(4242 + n)
     N, steps = 100, 3
