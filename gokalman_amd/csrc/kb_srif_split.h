@@ -541,7 +541,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
                 if (colok[r]) *((gptr)ep(st, 0, L * r) + uq) = bbo[r];
             if (full) {
 #pragma unroll
-                for (int m = 0; m < NM; m++)
+                for (int m = 0; m < 8; m++)   // (every row up to p: a Predict() runs on the p <= 4 instantiation whatever p is)
                     if (m < rp && q == m % L) {
                         __builtin_nontemporal_store(T(0), (gptr)ep(es, a.L.es_yhat, m) + us);
                         __builtin_nontemporal_store(T(0), (gptr)ep(es, a.L.es_dobs, m) + us);
