@@ -91,62 +91,7 @@ __device__ __forceinline__ void argmax_lanes(double &v, unsigned &tag) {
     }
 }
 
-// Reduce-scatter over the L lanes of a filter: v[i] holds this lane's PART of the i-th sum, i = q' + L r; afterwards lane q holds the
-// totals of ITS indices q + L r in own[r].  Each stage halves the live values: one v_permlane*_swap hands the pair member a lane does
-// not keep to its partner and receives the partner's part of the one it keeps (kb_vanilla_split.h pair32 / pair16, first half):
-// 50 instructions for 16 fp64 values over 8 lanes where 16 all-lane sums take 240.
-__device__ __forceinline__ double rs32(double a, double b) {   // lanes < 32 get a's total over the two halves, lanes >= 32 b's
-    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-}
-__device__ __forceinline__ double rs16(double a, double b) {   // even rows of 16 lanes get a's total over the row pair, odd rows b's
-    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-}
-__device__ __forceinline__ double rs8(double a, double b) {    // lanes with bit 3 clear get a's total over the lane pair 8 apart, the others b's
-    const bool up = (threadIdx.x & 8u) != 0u;
-    const double send = up ? a : b, keep = up ? b : a;
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), 0x128, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), 0x128, 0xf, 0xf, false);
-    return keep + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float rs32(float a, float b) {
-    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(x[0]) + __uint_as_float(x[1]);
-}
-__device__ __forceinline__ float rs16(float a, float b) {
-    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(x[0]) + __uint_as_float(x[1]);
-}
-__device__ __forceinline__ float rs8(float a, float b) {
-    const bool up = (threadIdx.x & 8u) != 0u;
-    const float send = up ? a : b, keep = up ? b : a;
-    return keep + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(send), 0x128, 0xf, 0xf, false));
-}
-template <int L, int NS, typename T>
-__device__ __forceinline__ void reduce_scatter(const T (&v)[NS], T (&own)[NS / L]) {
-    static_assert(L == 4 || L == 8, "lanes per filter");
-    constexpr int RP = NS / L;
-    T w1[NS / 2];
-#pragma unroll
-    for (int r = 0; r < RP; r++)
-#pragma unroll
-        for (int qq = 0; qq < L / 2; qq++) w1[qq + (L / 2) * r] = rs32(v[qq + L * r], v[qq + L / 2 + L * r]);
-    T w2[NS / 4];
-#pragma unroll
-    for (int r = 0; r < RP; r++)
-#pragma unroll
-        for (int qq = 0; qq < L / 4; qq++) w2[qq + (L / 4) * r] = rs16(w1[qq + (L / 2) * r], w1[qq + L / 4 + (L / 2) * r]);
-    if constexpr (L == 4) {
-#pragma unroll
-        for (int r = 0; r < RP; r++) own[r] = w2[r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < RP; r++) own[r] = rs8(w2[2 * r], w2[2 * r + 1]);
-    }
-}
+// (rs32 / rs16 / rs8 and reduce_scatter: kb_vanilla_split.h)
 
 // [R | b] staged for the dense State(prev) / the rows put back in order: NS^2 + NS; two pivot-row buffers: 4 NS; two reflector buffers
 template <int NS, int NM, int L>

@@ -219,6 +219,168 @@ __device__ __forceinline__ void lu_inverse_column(const T (&a)[P * P], unsigned 
     }
 }
 
+// Reduce-scatter over the L lanes of a filter: v[i] holds this lane's PART of the i-th sum, i = q' + L r; afterwards lane q holds the
+// totals of ITS indices q + L r in own[r].  Each stage halves the live values: one v_permlane*_swap hands the pair member a lane does
+// not keep to its partner and receives the partner's part of the one it keeps (pair32 / pair16, first half):
+// 50 instructions for 16 fp64 values over 8 lanes where 16 all-lane sums take 240.
+__device__ __forceinline__ double rs32(double a, double b) {   // lanes < 32 get a's total over the two halves, lanes >= 32 b's
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double rs16(double a, double b) {   // even rows of 16 lanes get a's total over the row pair, odd rows b's
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double rs8(double a, double b) {    // lanes with bit 3 clear get a's total over the lane pair 8 apart, the others b's
+    const bool up = (threadIdx.x & 8u) != 0u;
+    const double send = up ? a : b, keep = up ? b : a;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), 0x128, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), 0x128, 0xf, 0xf, false);
+    return keep + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float rs32(float a, float b) {
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(x[0]) + __uint_as_float(x[1]);
+}
+__device__ __forceinline__ float rs16(float a, float b) {
+    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(x[0]) + __uint_as_float(x[1]);
+}
+__device__ __forceinline__ float rs8(float a, float b) {
+    const bool up = (threadIdx.x & 8u) != 0u;
+    const float send = up ? a : b, keep = up ? b : a;
+    return keep + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(send), 0x128, 0xf, 0xf, false));
+}
+template <int L, int NS, typename T>
+__device__ __forceinline__ void reduce_scatter(const T (&v)[NS], T (&own)[NS / L]) {
+    static_assert(L == 4 || L == 8, "lanes per filter");
+    constexpr int RP = NS / L;
+    T w1[NS / 2];
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int qq = 0; qq < L / 2; qq++) w1[qq + (L / 2) * r] = rs32(v[qq + L * r], v[qq + L / 2 + L * r]);
+    T w2[NS / 4];
+#pragma unroll
+    for (int r = 0; r < RP; r++)
+#pragma unroll
+        for (int qq = 0; qq < L / 4; qq++) w2[qq + (L / 4) * r] = rs16(w1[qq + (L / 2) * r], w1[qq + L / 4 + (L / 2) * r]);
+    if constexpr (L == 4) {
+#pragma unroll
+        for (int r = 0; r < RP; r++) own[r] = w2[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < RP; r++) own[r] = rs8(w2[2 * r], w2[2 * r + 1]);
+    }
+}
+
+// The p x p inverse ONCE per filter (p = 8): lu_factor_any / lu_inverse_column above run in every lane of the filter on all p^2 values
+// (64 doubles of registers, ~2600 instructions with the row exchanges).  Here lane q owns COLUMNS q, q + L, ... of S and the L lanes run
+// an in-place Gauss-Jordan inversion with partial pivoting by rows: at step j the owner of column j finds the pivot row in its own
+// registers (no lane reduction) and publishes the column and the row number through LDS; every lane exchanges the two rows in its
+// columns, scales row j and eliminates column j from its columns; the owner's column becomes column j of the inverse (it is preset to
+// e_j, so that the same statements produce it).  The columns of the result leave in the order the row exchanges imply
+// (A^-1 = (Pi A)^-1 Pi: the exchanges applied to the COLUMNS in reverse order), to sb[(c NM + k) FPW] = (S^-1)[k][c].
+// Error conditions as mat64.Dense.Inverse (kb_device.h inverse_lu): an exact zero pivot; the caller forms |S| |S^-1| from the returned
+// |S|_1 (= |S|_inf up to rounding: S is symmetric up to rounding) and the inverse it reads back.
+template <int NM, int L> constexpr bool split_dist() {
+#ifdef KB_SPLIT_NODIST
+    return false;
+#else
+    return NM == 8;
+#endif
+}
+template <typename T, int NM, int L>
+__device__ __forceinline__ bool dist_inverse(T (&A)[NM / L][NM], const int q, T *sb, const int nreal, T &anorm) {
+    static_assert(NM % L == 0 && NM <= 8, "columns are dealt out cyclically; the row numbers are kept three bits each");
+    constexpr int CP = NM / L, FPW = 64 / L;
+    T *const cb = sb + NM * NM * FPW;   // the pivot column, its row number, then L slots for |S|_1
+    T an = T(0);
+#pragma unroll
+    for (int tt = 0; tt < CP; tt++) {
+        T s = T(0);
+#pragma unroll
+        for (int r = 0; r < NM; r++) s += fabs(A[tt][r]);
+        an = (q + L * tt < nreal && (s > an || s != s)) ? s : an;
+    }
+    bool bad = false;
+    unsigned perm = 0u;
+    sfor<0, NM>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = J, t = j / L, oq = j % L;
+        T best = fabs(A[t][j]);
+        int pr = j;
+#pragma unroll
+        for (int r = j + 1; r < NM; r++) {
+            const T v = fabs(A[t][r]);
+            const bool g = v > best;   // (the first of equal maxima: idamax)
+            best = g ? v : best;
+            pr = g ? r : pr;
+        }
+        wave_lds_fence();
+        if (q == oq) {
+#pragma unroll
+            for (int r = 0; r < NM; r++) cb[r * FPW] = A[t][r];
+            cb[NM * FPW] = (T)pr;
+        }
+        wave_lds_fence();
+        T col[NM];
+#pragma unroll
+        for (int r = 0; r < NM; r++) col[r] = cb[r * FPW];
+        const int prj = (int)cb[NM * FPW] & 7;
+        perm |= (unsigned)prj << (3 * j);
+        if (__any(prj != j)) {
+#pragma unroll
+            for (int r = j + 1; r < NM; r++) {
+                const bool sw = prj == r;
+                { const T t0 = col[j], t1 = col[r]; col[j] = sw ? t1 : t0; col[r] = sw ? t0 : t1; }
+#pragma unroll
+                for (int tt = 0; tt < CP; tt++) { const T t0 = A[tt][j], t1 = A[tt][r]; A[tt][j] = sw ? t1 : t0; A[tt][r] = sw ? t0 : t1; }
+            }
+        }
+        const T piv = col[j];
+        bad = bad || (piv == T(0));
+        const T rp = recip(piv);
+        const bool own = q == oq;
+#pragma unroll
+        for (int r = 0; r < NM; r++) A[t][r] = own ? (r == j ? T(1) : T(0)) : A[t][r];
+#pragma unroll
+        for (int tt = 0; tt < CP; tt++) {
+            const T sc = A[tt][j] * rp;
+#pragma unroll
+            for (int r = 0; r < NM; r++)
+                if (r != j) A[tt][r] -= col[r] * sc;
+            A[tt][j] = sc;
+#pragma unroll
+            for (int r = 0; r < NM; r++) pin(A[tt][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    wave_lds_fence();
+#pragma unroll
+    for (int tt = 0; tt < CP; tt++) {
+        int c = q + L * tt;
+#pragma unroll
+        for (int j = NM - 1; j >= 0; j--) {
+            const int pj = (int)((perm >> (3 * j)) & 7u);
+            c = (c == j) ? pj : (c == pj ? j : c);
+        }
+        T *const dst = sb + c * (NM * FPW);
+#pragma unroll
+        for (int r = 0; r < NM; r++) dst[r * FPW] = A[tt][r];
+    }
+    cb[(NM + 1 + q) * FPW] = an;
+    wave_lds_fence();
+    anorm = T(0);
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        const T s = cb[(NM + 1 + l) * FPW];
+        anorm = (s > anorm || s != s) ? s : anorm;
+    }
+    return bad;
+}
+
 template <int NS, int NM>
 constexpr int split_lds_elems() { return NS * NS > tri(NS) + NM * NS ? NS * NS : tri(NS) + NM * NS; }
 template <typename T, int NS, int NM, int L>
@@ -251,11 +413,23 @@ constexpr int split_waves_per_simd() { return (int)sizeof(T) * split_lds_elems<N
 // operands of chunk c + 1 are requested, a scheduling barrier, the arithmetic of chunk c, a scheduling barrier -- and the global
 // loads of a later phase are requested where the registers for them are free: F, P, x first; Q when T = F P is done; H when the first
 // rows of P- are done; R, y, G, u behind that.  The other wave of the SIMD covers what latency this leaves exposed.
+// HSPLIT (S^-1 once per filter, four lanes): H passes through LDS HALF at a time in the P- H^T loop, and P- H^T, H, K take turns at
+// the front of the region in the Joseph form (the lane keeps its own columns of H in registers and writes them back when they are
+// needed): 155 doubles per filter at 12 / 8 where P- | H | P- H^T side by side are 270 -- two waves per SIMD.
+template <int NM, int L> constexpr bool split_hsplit() { return split_dist<NM, L>() && L == 4; }
 template <typename T, int NS, int NM, int L, bool GEN, bool FULLT>
 constexpr int split_lds_total() {
     constexpr int KP = (tri(NS) + L - 1) / L;
+    if constexpr (split_hsplit<NM, L>()) {
+        constexpr int SB = NM * NM + NM + 1 + L, HH = (NM / 2) * NS;
+        int e = NS * NS;                                            // F
+        if (tri(NS) + (SB > HH ? SB : HH) > e) e = tri(NS) + (SB > HH ? SB : HH);   // P- | half of H, then S^-1 and the pivot column
+        if (NS * NM > e) e = NS * NM;                              // P- H^T, H, K in turn
+        if (KP * L > e) e = KP * L;
+        return e * (64 / L);
+    }
     constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;
-    return (XOFF + (NS * NM > tri(NS) ? NS * NM : 0)) * (64 / L);
+    return (XOFF + (NS * NM > tri(NS) ? NS * NM : 0) + (split_dist<NM, L>() ? tri(NM) : 0)) * (64 / L);   // (+ R for K R: see the Joseph form)
 }
 // one wave's part of one tile: filters [64 tile + (gw % L) 64 / L, ... + 64 / L), gw = L tile + part
 // HYB: the HybridKF measurement update (hybrid.go:104-204; CKF or EKF by StepArgs::ekf, no SNC, no Predict()) -- the same algebra on
@@ -268,7 +442,12 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     constexpr int HOFF = TR;                       // LDS element offset of H (later: K) next to the packed P-
     constexpr int KP = (TR + L - 1) / L;           // packed elements of P per lane
     constexpr int XOFF = split_lds_elems<NS, NM>() > KP * L ? split_lds_elems<NS, NM>() : KP * L;
-    constexpr int GOFF = NS * NM > TR ? XOFF : 0;   // P- H^T for the Joseph form: over P-, unless its n p elements would reach into H behind it
+    constexpr bool DIST = split_dist<NM, L>();   // S^-1 once per filter (dist_inverse) instead of once per lane
+    constexpr int CP = DIST ? NM / L : 1;
+    constexpr bool HSPLIT = split_hsplit<NM, L>();
+    constexpr int NMH = HSPLIT ? NM / 2 : NM;       // rows of H in LDS at a time while P- H^T is formed
+    constexpr int GOFF = HSPLIT ? 0 : (NS * NM > TR ? XOFF : 0);   // P- H^T for the Joseph form: over P-, unless its n p elements would reach into H behind it
+    constexpr int HJ = HSPLIT ? 0 : HOFF;           // H and K in the Joseph form
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
     const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
     const bool predict = RT ? a.predict != 0 : PREDT;
@@ -310,16 +489,16 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     // GEN, the loads BEHIND the first burst (Q, H, R): issued always -- from element 0 of the same field (which every shape has) when the
     // shape does not have the element (the run-time part of the element index takes the stand-in: scalar-base form kept), the value
     // masked after -- so that the s_waitcnt counters stay exact there (behind a branch the compiler assumes the worst at the join)
-    auto ldg_if = [&](bool need, const T *ubase, int field, int rt, int c, unsigned off, unsigned off_alt) {   // need: wave-uniform
-        if constexpr (!GEN) return need ? ldg(ubase, rt, c, off) : T(0);
+    auto ldg_if = [&](bool need, const T *ubase, int field, int rt, int c, unsigned off, unsigned off_alt, bool keep = false) {   // need: wave-uniform; keep: the value is read again later (default policy)
+        if constexpr (!GEN) return need ? ((L == 8 || keep) ? *(ep(ubase, rt, c) + off) : ldg(ubase, rt, c, off)) : T(0);
         else {
             const auto pe_ = ep(ubase, need ? rt : field - c, c) + (need ? off : off_alt);
-            const T v = L == 8 ? *pe_ : __builtin_nontemporal_load(pe_);
+            const T v = (L == 8 || keep) ? *pe_ : __builtin_nontemporal_load(pe_);
             return need ? v : T(0);
         }
     };
 #else
-    auto ldg_if = [&](bool need, const T *ubase, int, int rt, int c, unsigned off, unsigned) { return need ? ldg(ubase, rt, c, off) : T(0); };
+    auto ldg_if = [&](bool need, const T *ubase, int, int rt, int c, unsigned off, unsigned, bool = false) { return need ? ldg(ubase, rt, c, off) : T(0); };
 #endif
     auto ldst = [&](auto NT, int rt, int c, unsigned off) {   // state block, cache policy NT (kb_vanilla_reg.h)
         const gptr pe = ep(st, rt, c) + off;
@@ -340,21 +519,26 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     T Fo[RP][NS], x[NS];
     {
         T Pp[KP];
+        if (HYB && a.ext_phi) {   // zero copy (kb_prepare_dev): element e of filter i of the caller's planar array at ext[e ld + i]
+            const T *ephi = (const T *)a.ext_phi + (active ? fi : tile * KB_TILE);
 #pragma unroll
-        for (int r = 0; r < RP; r++)
+            for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int l = 0; l < NS; l++) {
-                // (a lane whose row is padding reads lane-group 0's row, which is real whenever rowany[r])
-                T v;
-                if (HYB && a.ext_phi) {   // zero copy (kb_prepare_dev): element e of filter i of the caller's planar array at ext[e ld + i]
-                    const T *ephi = (const T *)a.ext_phi + (active ? fi : tile * KB_TILE);
+                for (int l = 0; l < NS; l++) {
                     const T *pe_ = ephi + (int64_t)(((rowok[r] ? q : 0) + L * r) * rn + l) * a.ext_ld;
-                    v = (rowany[r] && l < rn) ? (L == 8 ? *pe_ : __builtin_nontemporal_load(pe_)) : T(0);   // (eight lanes: half-line segments, default policy -- see ldg)
-                } else {
-                    v = (rowany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, rowok[r] ? uf : um) : T(0);
+                    const T v = (rowany[r] && l < rn) ? (L == 8 ? *pe_ : __builtin_nontemporal_load(pe_)) : T(0);   // (eight lanes: half-line segments, default policy -- see ldg)
+                    Fo[r][l] = rowok[r] ? v : T(0);
                 }
-                Fo[r][l] = rowok[r] ? v : T(0);
-            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int l = 0; l < NS; l++) {
+                    // (a lane whose row is padding reads lane-group 0's row, which is real whenever rowany[r])
+                    const T v = (rowany[r] && l < rn) ? ldg(mo, a.L.mo_F + (GEN ? L * r * rn : 0), (GEN ? 0 : L * r * NS) + l, rowok[r] ? uf : um) : T(0);
+                    Fo[r][l] = rowok[r] ? v : T(0);
+                }
+        }
         auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h
 #pragma unroll
             for (int k = 0; k < KP; k++) {
@@ -502,19 +686,31 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     wave_lds_fence();
     KB_SB();
     T Hp[NM][RP];   // H[c][i_r]: the lane's own columns of H
-    auto request_H = [&]() {
+    // (DIST: S^-1 and the pivot columns use H's place in LDS, and the own columns of H are read a SECOND time for the Joseph form -- carried
+    // through the p x p inversion they are 16-24 doubles of scratch; the first read keeps the lines in the caches)
+    auto request_H = [&](bool again = false) {
+        if (HYB && a.ext_phi) {   // (one branch per request, not one per element)
+            // (the second request forms its addresses anew, from values the optimiser cannot tie to the first one's: kept from there, the
+            // 24 sign-extended element indices and the predicates of both branches wait in scratch -- 320 B per lane at 12 / 8)
+            int64_t ld = a.ext_ld;
+            int rn_ = rn, q_ = q;
+            if (again) { asm volatile("" : "+s"(ld)); asm volatile("" : "+s"(rn_)); asm volatile("" : "+v"(q_)); }
+            const T *eh = (const T *)a.ext_h + (active ? fi : tile * KB_TILE);
+#pragma unroll
+            for (int c = 0; c < NM; c++)
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    const T *pe_ = eh + (int64_t)(c * rn_ + (rowok[r] ? q_ : 0) + L * r) * ld;
+                    const T v = (rowany[r] && c < rp) ? ((L == 8 || (DIST && !again)) ? *pe_ : __builtin_nontemporal_load(pe_)) : T(0);
+                    Hp[c][r] = rowok[r] ? v : T(0);
+                }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NM; c++)
 #pragma unroll
             for (int r = 0; r < RP; r++) {
-                T v;
-                if (HYB && a.ext_phi) {
-                    const T *eh = (const T *)a.ext_h + (active ? fi : tile * KB_TILE);
-                    const T *pe_ = eh + (int64_t)(c * rn + (rowok[r] ? q : 0) + L * r) * a.ext_ld;
-                    v = (rowany[r] && c < rp) ? (L == 8 ? *pe_ : __builtin_nontemporal_load(pe_)) : T(0);
-                } else {
-                    v = ldg_if(rowany[r] && c < rp, mo, a.L.mo_H, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um, um);
-                }
+                const T v = ldg_if(rowany[r] && c < rp, mo, a.L.mo_H, a.L.mo_H + (GEN ? c * rn : 0), (GEN ? 0 : c * NS) + L * r, rowok[r] ? umq : um, um, DIST && !again);
                 Hp[c][r] = rowok[r] ? v : T(0);
             }
     };
@@ -673,7 +869,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         }
     }
 #pragma unroll
-    for (int c = 0; c < NM; c++)
+    for (int c = 0; c < NMH; c++)
 #pragma unroll
         for (int r = 0; r < RP; r++) lf[(HOFF + c * NS + q + L * r) * FPW] = Hp[c][r];
     wave_lds_fence();
@@ -695,7 +891,8 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     for (int r = 0; r < RP; r++)
 #pragma unroll
         for (int c = 0; c < NM; c++) PHt[r][c] = T(0);
-    T R1[TM], y[NM];   // requested here, used behind the P- H^T loop
+    T R1[DIST ? 1 : TM], y[NM];   // requested here, used behind the P- H^T loop
+    [[maybe_unused]] T Rown[CP][NM];   // DIST: R[.][q + L t], the lane's own columns
     [[maybe_unused]] T yreal[HYB ? NM : 1];
     [[maybe_unused]] T xo[RP];   // x_prev[i_r] (FULL: yhat = H x_prev, vanilla.go:155-157): read a second time, not carried from the top
     auto request_Ry = [&]() {
@@ -706,7 +903,21 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 xo[r] = rowok[r] ? v : T(0);
             }
         }
-        load_R(R1, std::false_type{});
+        if constexpr (DIST) {
+#pragma unroll
+            for (int tt = 0; tt < CP; tt++) {
+                const int c = q + L * tt;
+#pragma unroll
+                for (int rr = 0; rr < NM; rr++) {
+                    const bool okr = c < rp && rr < rp;
+                    const int e = rr <= c ? c * (c + 1) / 2 + rr : rr * (rr + 1) / 2 + c;   // packed element (min, max)
+                    const T v = *(ep(mo, a.L.mo_R, 0) + (um + (unsigned)((okr ? e : 0) * KB_TILE)));
+                    Rown[tt][rr] = okr ? v : (rr == c ? T(1) : T(0));
+                }
+            }
+        } else {
+            load_R(R1, std::false_type{});
+        }
         const T *yp = (const T *)a.y + tile * a.y_ts;
 #pragma unroll
         for (int r = 0; r < NM; r++) y[r] = (!predict && active && r < rp) ? ldnt_at(&(yp + (int64_t)r * a.y_es)[us]) : T(0);
@@ -720,7 +931,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         }
     };
     if (!KB_SPLIT_R1LATE) request_Ry();
-    {
+    if constexpr (!HSPLIT) {
         constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
         T hb[2][CH][NM], pb[2][CH][RP];
         auto fetch = [&](int ch, int b) {
@@ -754,14 +965,81 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 for (int c = 0; c < NM; c++) pin(PHt[r][c]);
             KB_SB();
         }
-    }
+    } else
+    sfor<0, NM / NMH>([&](auto HH) __attribute__((always_inline)) {
+        constexpr int c0 = HH * NMH;   // rows c0 .. c0 + NMH - 1 of H are in LDS
+        if constexpr (HH > 0) {
+            wave_lds_fence();
+#pragma unroll
+            for (int c = 0; c < NMH; c++)
+#pragma unroll
+                for (int r = 0; r < RP; r++) lf[(HOFF + c * NS + q + L * r) * FPW] = Hp[c0 + c][r];
+            wave_lds_fence();
+            KB_SB();
+        }
+        constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+        T hb[2][CH][NMH], pb[2][CH][RP];
+        auto fetch = [&](int ch, int b) {
+#pragma unroll
+            for (int d = 0; d < CH; d++) {
+                const int l = ch * CH + d;
+                if (l < NS) {
+#pragma unroll
+                    for (int c = 0; c < NMH; c++) hb[b][d][c] = lf[(HOFF + c * NS + l) * FPW];
+#pragma unroll
+                    for (int r = 0; r < RP; r++) pb[b][d][r] = pm_own(r, l);
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            if (ch + 1 < NCH) fetch(ch + 1, (ch + 1) & 1);
+            KB_SB();
+#pragma unroll
+            for (int d = 0; d < CH; d++)
+                if (ch * CH + d < NS) {
+#pragma unroll
+                    for (int c = 0; c < NMH; c++)
+#pragma unroll
+                        for (int r = 0; r < RP; r++) PHt[r][c0 + c] += pb[ch & 1][d][r] * hb[ch & 1][d][c];
+                }
+#pragma unroll
+            for (int r = 0; r < RP; r++)
+#pragma unroll
+                for (int c = 0; c < NMH; c++) pin(PHt[r][c0 + c]);
+            KB_SB();
+        }
+    });
     // ---- S = H P- H^T + R (upper triangle), H x-, [H x_prev]: partial sums over the own rows, then over the L lanes --------
-    T S[NM * NM], innov[NM];
+    T S[DIST ? 1 : NM * NM], innov[NM];
+    [[maybe_unused]] T Sown[CP][NM];   // DIST: S[.][q + L t]
     {
         if (KB_SPLIT_R1LATE) { request_Ry(); KB_SB(); }
         // the partial sums: S (upper triangle) | H x- | [H x_prev], summed over the L lanes two at a time
+        // (DIST: S row by row, every entry -- the reference's H P- H^T is not mirrored either -- and reduce-scattered: a lane ends up with
+        // the totals of its own columns only; the triangle's slots of `part` stay unused)
         constexpr int NV = TM + NM, NVF = NV + NM;
         T part[NVF];
+        if constexpr (DIST) {
+#pragma unroll
+            for (int c1 = 0; c1 < NM; c1++) {
+                T prow[NM], orow[CP];
+#pragma unroll
+                for (int c2 = 0; c2 < NM; c2++) {
+                    T s = T(0);
+#pragma unroll
+                    for (int r = 0; r < RP; r++) s += Hp[c1][r] * PHt[r][c2];
+                    prow[c2] = s;
+                }
+                reduce_scatter<L, NM, T>(prow, orow);
+#pragma unroll
+                for (int tt = 0; tt < CP; tt++) { Sown[tt][c1] = orow[tt] + Rown[tt][c1]; pin(Sown[tt][c1]); }
+                if (c1 & 1) KB_SB();
+            }
+#pragma unroll
+            for (int e = 0; e < TM; e++) part[e] = T(0);
+        } else {
 #pragma unroll
         for (int c2 = 0; c2 < NM; c2++)
 #pragma unroll
@@ -771,6 +1049,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 for (int r = 0; r < RP; r++) s += Hp[c1][r] * PHt[r][c2];
                 part[symi(c1, c2)] = s;
             }
+        }
 #pragma unroll
         for (int c = 0; c < NM; c++) {
             T s = T(0), s2 = T(0);
@@ -786,12 +1065,12 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             part[NV + c] = s2;
         }
 #pragma unroll
-        for (int e = 0; e + 1 < NV; e += 2) {
+        for (int e = DIST ? TM : 0; e + 1 < NV; e += 2) {
             sum_lanes2<L>(part[e], part[e + 1]);
             pin(part[e]); pin(part[e + 1]);
             if ((e & 6) == 6) KB_SB();   // a few at a time: interleaved, the chains keep all their temporaries alive
         }
-        if (NV & 1) part[NV - 1] = sum_lanes<L>(part[NV - 1]);
+        if ((NV - (DIST ? TM : 0)) & 1) part[NV - 1] = sum_lanes<L>(part[NV - 1]);
         KB_SB();
 #pragma unroll
         for (int c = 0; c < NM; c++) {
@@ -822,6 +1101,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 }
             }
         }
+        if constexpr (!DIST) {
 #pragma unroll
         for (int c2 = 0; c2 < NM; c2++)
 #pragma unroll
@@ -830,20 +1110,33 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 S[c1 * NM + c2] = v;
                 S[c2 * NM + c1] = v;
             }
+        }
     }
     KB_SB();
     // ---- K = P- H^T S^-1 (own rows), column by column of the inverse; the same bits in the L lanes of a filter ---------------
-    unsigned err = 0, swaps;
+    unsigned err = 0;
+    [[maybe_unused]] unsigned swaps = 0u;
     T K[RP][NM];
     {
         T anorm, inorm = T(0), rows[NM];
-        if (lu_factor_any<T, NM>(S, swaps, anorm, rp)) err = KB_ST_SINGULAR;
+        T *const sb = lf + HOFF * FPW;   // DIST: H has been consumed (it returns from the registers below); S^-1 and the pivot columns take its place
+        if constexpr (DIST) {
+            static_assert((HOFF + NM * NM + NM + 1 + L) * FPW <= split_lds_total<T, NS, NM, L, GEN, FULLT>(), "S^-1 and the pivot column fit behind P-");
+            if (dist_inverse<T, NM, L>(Sown, q, sb, rp, anorm)) err = KB_ST_SINGULAR;
+        } else {
+            if (lu_factor_any<T, NM>(S, swaps, anorm, rp)) err = KB_ST_SINGULAR;
+        }
 #pragma unroll
         for (int i = 0; i < NM; i++) rows[i] = T(0);
         sfor<0, NM>([&](auto C) __attribute__((always_inline)) {
             constexpr int c = C;
             T v[NM];
-            lu_inverse_column<T, NM, c>(S, swaps, v);
+            if constexpr (DIST) {
+#pragma unroll
+                for (int k = 0; k < NM; k++) v[k] = sb[(c * NM + k) * FPW];
+            } else {
+                lu_inverse_column<T, NM, c>(S, swaps, v);
+            }
 #pragma unroll
             for (int i = 0; i < NM; i++) rows[i] += fabs(v[i]);
 #pragma unroll
@@ -897,7 +1190,11 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         // ---- Joseph form (see the header): AP = (I - K H) P- = P- - K (P- H^T)^T for the own rows.  The own rows of P- are read
         // into AP, then P- H^T -- every row of it is needed -- goes to LDS in P-'s place (behind everything else when its n p
         // elements would not fit in front of H); two columns of AP per chunk
-        T AP[RP][NS], R[TM];
+        // (HSPLIT: R for K R passes through LDS -- each lane loads a quarter of the triangle, 9 values where the whole of it is 36 per lane,
+        // and the product reads it column by column; its padding may be anything finite: those columns of K are exact zeros)
+        constexpr int RSH = DIST ? (TM + L - 1) / L : 1, ROFF = HSPLIT ? NS * NM : XOFF + (NS * NM > TR ? NS * NM : 0);
+        T AP[RP][NS], R[DIST ? 1 : TM];
+        [[maybe_unused]] T Rsh[RSH];
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
@@ -909,8 +1206,18 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             for (int c = 0; c < NM; c++) lrows()[(GOFF + L * r * NM + c) * FPW] = PHt[r][c];
         wave_lds_fence();
         KB_SB();
+        if constexpr (DIST) {   // on their way while P- H^T is consumed
+            request_H(true);
+#pragma unroll
+            for (int k = 0; k < RSH; k++) {
+                const bool okp = q + L * k < tri(rp);
+                const T v = L * k < tri(rp) ? ldg(mo, a.L.mo_R, L * k, okp ? umq : um) : T(0);
+                Rsh[k] = okp ? v : T(0);
+            }
+        }
+        KB_SB();
         {
-            constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+            constexpr int CH = DIST ? 1 : 2, NCH = (NS + CH - 1) / CH;
             T gb[2][CH][NM];
             auto fetch = [&](int ch, int b) {
 #pragma unroll
@@ -946,19 +1253,31 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         }
         // V = K R - AP H^T (own rows): W = AP H^T first, two columns of H per chunk, with R on its way again
         T V[RP][NM];
+        if constexpr (DIST) {   // HSPLIT: P- H^T is consumed, H takes its place; R behind
+            wave_lds_fence();
+#pragma unroll
+            for (int c = 0; c < NM; c++)
+#pragma unroll
+                for (int r = 0; r < RP; r++) lf[(HJ + c * NS + q + L * r) * FPW] = Hp[c][r];
+#pragma unroll
+            for (int k = 0; k < RSH; k++)
+                if (L * k + L - 1 < TM || q + L * k < TM) lf[(ROFF + q + L * k) * FPW] = Rsh[k];
+            wave_lds_fence();
+            KB_SB();
+        }
         {
-            constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+            constexpr int CH = DIST ? 1 : 2, NCH = (NS + CH - 1) / CH;
             T hb[2][CH][NM];
             auto fetch = [&](int ch, int b) {
 #pragma unroll
                 for (int d = 0; d < CH; d++)
                     if (ch * CH + d < NS) {
 #pragma unroll
-                        for (int c = 0; c < NM; c++) hb[b][d][c] = lf[(HOFF + c * NS + ch * CH + d) * FPW];
+                        for (int c = 0; c < NM; c++) hb[b][d][c] = lf[(HJ + c * NS + ch * CH + d) * FPW];
                     }
             };
             fetch(0, 0);
-            if (KB_SPLIT_RL >= NS) load_R(R, std::true_type{});
+            if constexpr (!DIST) { if (KB_SPLIT_RL >= NS) load_R(R, std::true_type{}); }
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
@@ -985,12 +1304,30 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int c = 0; c < NM; c++) {
+                    if constexpr (DIST) continue;
                     T s = V[r][c];
 #pragma unroll
                     for (int k = 0; k < NM; k++) s += K[r][k] * R[symi(k, c)];
                     V[r][c] = s;
                     pin(V[r][c]);
                 }
+            if constexpr (DIST) {
+#pragma unroll
+                for (int c = 0; c < NM; c++) {
+                    T rc[NM];
+#pragma unroll
+                    for (int k = 0; k < NM; k++) rc[k] = lf[(ROFF + symi(k, c)) * FPW];
+#pragma unroll
+                    for (int r = 0; r < RP; r++) {
+                        T sacc = V[r][c];
+#pragma unroll
+                        for (int k = 0; k < NM; k++) sacc += K[r][k] * rc[k];
+                        V[r][c] = sacc;
+                        pin(V[r][c]);
+                    }
+                    if (c & 1) KB_SB();
+                }
+            }
             KB_SB();
         }
         // K takes H's place in LDS, P+ = AP + V K^T, two rows of K per chunk
@@ -998,18 +1335,18 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) lrows()[(HOFF + L * r * NM + c) * FPW] = K[r][c];
+            for (int c = 0; c < NM; c++) lrows()[(HJ + L * r * NM + c) * FPW] = K[r][c];
         wave_lds_fence();
         KB_SB();
         {
-            constexpr int CH = 2, NCH = (NS + CH - 1) / CH;
+            constexpr int CH = DIST ? 1 : 2, NCH = (NS + CH - 1) / CH;
             T kb[2][CH][NM];
             auto fetch = [&](int ch, int b) {
 #pragma unroll
                 for (int d = 0; d < CH; d++)
                     if (ch * CH + d < NS) {
 #pragma unroll
-                        for (int c = 0; c < NM; c++) kb[b][d][c] = lf[(HOFF + (ch * CH + d) * NM + c) * FPW];
+                        for (int c = 0; c < NM; c++) kb[b][d][c] = lf[(HJ + (ch * CH + d) * NM + c) * FPW];
                     }
             };
             fetch(0, 0);
@@ -1081,7 +1418,12 @@ __device__ __forceinline__ int64_t split_part_of_block(unsigned b, unsigned nblo
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, bool NOISET = false, bool HYB = false>
-__global__ void __launch_bounds__(64, (((RT || NM > 6) && L == 4) ? 1 : split_waves_per_simd<T, NS, NM, L>())) vanilla_split_kernel(const StepArgs a) {
+#ifdef KB_SPLIT_HYB1
+#define KB_HYB1_ HYB
+#else
+#define KB_HYB1_ false
+#endif
+__global__ void __launch_bounds__(64, (((RT || (NM > 6 && (KB_HYB1_ || !split_hsplit<NM, L>()))) && L == 4) ? 1 : ((int)sizeof(T) * split_lds_total<T, NS, NM, L, RT, FULLT>() * 8 <= 160 * 1024 ? 2 : 1))) vanilla_split_kernel(const StepArgs a) {
     __shared__ T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
     if constexpr (PERSIST) {
         const int64_t nparts = a.ntiles * L;

@@ -32,6 +32,7 @@ bool launch_vanilla_split12(const Batch &b, const StepArgs &a) {
     // Information split launchers already decide).
     if (a.noise_kind == KB_NOISE_BATCH) return false;
     if (split_exact<double, 12, 6, 0, 4>(b, a)) return true;
+    if (split_exact<double, 12, 8, 0, 4>(b, a)) return true;   // (the corner of the four-lane envelope)
     if (launch_vanilla_split12_plain(b, a)) return true;
     hipLaunchKernelGGL((vanilla_split_kernel<double, 12, 8, 2, 4, true, false, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     return true;

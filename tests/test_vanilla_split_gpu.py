@@ -139,6 +139,51 @@ def test_split_singular_innovation_skips_that_filter_only(n, p):
         assert b.filter_step(i) == steps - (1 if i in bad else 0)
 
 
+@pytest.mark.parametrize("n,p", [(12, 8), (14, 7), (16, 8), (11, 8)])
+def test_split_distributed_inverse_row_exchanges_and_a_late_zero_pivot(n, p):
+    """p = 7, 8 beyond 8 states: the p x p inverse of H P- H^T + R is formed ONCE per filter by its lanes (kb_vanilla_split.h
+    dist_inverse: Gauss-Jordan by columns, pivot rows chosen by the column's owner).  R = D C D with row scales over two decades in a
+    different order per filter: partial pivoting exchanges rows, differently in every lane group of a wave (scipy's LU of the first 16
+    filters' S is checked to pivot in at least half of them).  Then two EQUAL rows of H with R = 0 in some filters: the zero pivot appears at the last
+    column, not the first -- (nil, err) for those filters only (vanilla.go:164-167), as the oracle reports."""
+    import scipy.linalg as sl
+    N, steps = 200, 4
+    d = _model(N, n, p, 0, steps, 31 * n + p)
+    rng = np.random.default_rng(n + p)
+    sc = 10.0 ** (np.array([rng.permutation(p) for _ in range(N)]) / 4.0)
+    C = 0.9 * np.ones((p, p)) + 0.1 * np.eye(p)
+    d["R"] = 30.0 * sc[:, :, None] * C[None] * sc[:, None, :]
+    exchanging = 0   # filters of the first wave whose first-step S makes LU exchange rows
+    for i in range(16):
+        Pm = d["F"][i] @ d["P0"][i] @ d["F"][i].T + d["Q"][i]
+        perm = np.argmax(sl.lu(d["H"][i] @ Pm @ d["H"][i].T + d["R"][i])[0], axis=0)
+        exchanging += int(np.count_nonzero(perm != np.arange(p)) >= 2)
+    assert exchanging >= 8
+    bad = [5, 16, 17, 130, 199]
+    Hbad, Rbad = d["H"].copy(), d["R"].copy()
+    Hbad[bad, p - 1] = Hbad[bad, 2]
+    Rbad[bad] = 0.0
+    b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=k.FLAG_FULL_ESTIMATE)
+    fs = [orc.Filter.ldkf(orc.VANILLA, d["x0"][i], d["P0"][i], d["F"][i], None, d["H"][i], d["Q"][i], d["R"][i]) for i in range(N)]
+    for t in range(steps):
+        if t == 2:
+            b.set_measurement_matrix(Hbad); b.set_noise(d["Q"], Rbad)
+        if t == 3:
+            b.set_measurement_matrix(d["H"]); b.set_noise(d["Q"], d["R"])
+        est = b.update(d["y"][t])
+        for i, f in enumerate(fs):
+            if t == 2 and i in bad:
+                f.set_measurement_matrix(Hbad[i]); f.set_noise(d["Q"][i], Rbad[i])
+            if t == 3 and i in bad:
+                f.set_measurement_matrix(d["H"][i]); f.set_noise(d["Q"][i], d["R"][i])
+            assert f.update(d["y"][t, i]) == (orc.ERR_SINGULAR if (t == 2 and i in bad) else orc.OK)
+        assert sorted(np.nonzero(b.status())[0].tolist()) == (bad if t >= 2 else [])
+        assert within(synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])), TOL), t
+        assert within(synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])), TOL), t
+        good = [i for i in range(N) if not (t == 2 and i in bad)]
+        assert within(synth.rel_frobenius(est.gain()[good], np.array([fs[i].gain() for i in good])), TOL), t
+
+
 def test_split_batches_keep_the_other_kernels_bits_for_small_shapes():
     """Shapes the one-filter-per-lane kernels cover stay on them: an 8 / 4 batch run with KB_FLAG_STATEMENT_KERNELS and without agree
     to rounding, and a 12 / 6 batch equals the statement kernel to 1e-12 (different summation order, same arithmetic)."""
