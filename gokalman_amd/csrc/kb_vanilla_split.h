@@ -449,6 +449,10 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     constexpr int GOFF = HSPLIT ? 0 : (NS * NM > TR ? XOFF : 0);   // P- H^T for the Joseph form: over P-, unless its n p elements would reach into H behind it
     constexpr int HJ = HSPLIT ? 0 : HOFF;           // H and K in the Joseph form
     const int rn = GEN ? a.n : NS, rp = GEN ? a.p : NM, rm = GEN ? (a.need_ctrl ? a.m : 0) : NC;
+    if constexpr (GEN) {   // (the launcher's conditions, for the optimiser: lane offsets such as q rn 64 then provably fit 32 bits -- the scalar-base form of global_load)
+        __builtin_assume(rn >= 1 && rn <= NS);
+        __builtin_assume(rp >= 1 && rp <= NM);
+    }
     const bool full = RT ? (a.flags & KB_FLAG_FULL_ESTIMATE) != 0 : FULLT;
     const bool predict = RT ? a.predict != 0 : PREDT;
     const unsigned lane = threadIdx.x;

@@ -25,6 +25,10 @@ RULES = [
     (r"^void srif_pair_kernel<float, 12, 6, false, (true|false), false>", 0, 2, "config E: SRIF 12/6 fp32"),
     (r"^void srif_pair_kernel<double, 12, 6, ", 0, 1, "SRIF 12/6 fp64, two lanes"),
     (r"^void vanilla_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "Vanilla 12/6 exact, four lanes"),
+    (r"^void vanilla_split_kernel<double, 12, 8, 0, 4, false, ", 0, 2, "Vanilla 12/8 exact, four lanes, S^-1 once per filter"),
+    (r"^void vanilla_split_kernel<double, 16, 8, 0, 8, false, ", 0, 2, "Vanilla 16/8 exact, eight lanes, S^-1 once per filter"),
+    (r"^void vanilla_split_kernel<double, 12, 8, 2, 4, true, false, false, false, false, false, false>", 32, 2, "Vanilla n <= 12, p = 7, 8 padded (round 4: one wave per SIMD, 340 registers)"),
+    (r"^void vanilla_split_kernel<double, 16, 8, 2, 8, true, false, false, false, false, false, false>", 16, 2, "Vanilla n <= 16, p = 7, 8 padded (round 4: 192 B)"),
     (r"^void squareroot_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "SquareRoot 12/6 exact"),
     (r"^void information_split_kernel<double, 12, 6, 0, 4, false, ", 0, 2, "Information 12/6 exact"),
     (r"^void srif_split_kernel<double, \d+, (4|6), (4|8)>", 0, 2, "SRIF fp64 split, p <= 6 (every n)"),
