@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/ldsprobe; mkdir -p $O
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $O/a -- python3 scripts/bench_kinds.py vsplit vpad > $O/a.out 2> $O/a.log
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES --output-format csv -d $O/b -- python3 scripts/bench_kinds.py vsplit vpad > $O/b.out 2> $O/b.log
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $O/a -- python3 scripts/bench_kinds.py ${KINDS:-vsplit vpad} > $O/a.out 2> $O/a.log
+rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_BUSY_CYCLES --output-format csv -d $O/b -- python3 scripts/bench_kinds.py ${KINDS:-vsplit vpad} > $O/b.out 2> $O/b.log
 python3 - <<'PY'
 import csv,glob,collections
 for tag in ('a','b'):
@@ -13,7 +13,7 @@ for tag in ('a','b'):
             if r['Counter_Name']=='SQ_BUSY_CYCLES': cnt[k]+=1
     with open('gpurun_out/ldsprobe/%s_summary.txt'%tag,'w') as out:
         for k,v in agg.items():
-            if 'split' not in k: continue
+            if "split" not in k and "srif" not in k and "vanilla_reg" not in k: continue
             n=max(cnt[k],1)
             out.write(k+' | launches %d | '%n+' '.join('%s=%.4g'%(c,x/n) for c,x in sorted(v.items()))+'\n')
 PY
