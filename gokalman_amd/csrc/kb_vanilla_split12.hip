@@ -6,9 +6,10 @@
 
 namespace kb {
 
-template <typename T, int NS, int NM, int NC, int L>
+template <typename T, int NS, int NM, int NC, int L, bool WITH_PREDICT = true>
 static bool split_exact(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    if (!WITH_PREDICT && a.predict) return false;   // (pure predictors of this shape: the run-time-everything kernel)
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
 #ifdef KB_SPLIT_PERSIST
     const int64_t slots = (int64_t)KB_SPLIT_PERSIST;
@@ -18,7 +19,7 @@ static bool split_exact(const Batch &b, const StepArgs &a) {
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
 #define KB_GO(F_, P_) hipLaunchKernelGGL((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_>), grid, block, 0, b.stream, a)
 #endif
-    if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
+    if (a.predict) { if constexpr (WITH_PREDICT) { if (full) KB_GO(true, true); else KB_GO(false, true); } }
     else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
 #undef KB_GO
     return true;
@@ -32,7 +33,7 @@ bool launch_vanilla_split12(const Batch &b, const StepArgs &a) {
     // Information split launchers already decide).
     if (a.noise_kind == KB_NOISE_BATCH) return false;
     if (split_exact<double, 12, 6, 0, 4>(b, a)) return true;
-    if (split_exact<double, 12, 8, 0, 4>(b, a)) return true;   // (the corner of the four-lane envelope)
+    if (split_exact<double, 12, 8, 0, 4, false>(b, a)) return true;   // (the corner of the four-lane envelope)
     if (launch_vanilla_split12_plain(b, a)) return true;
     hipLaunchKernelGGL((vanilla_split_kernel<double, 12, 8, 2, 4, true, false, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     return true;

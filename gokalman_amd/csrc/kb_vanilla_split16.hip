@@ -7,12 +7,11 @@ namespace kb {
 // exact 16 / 8 / 0, Noiseless: the corner of the eight-lane envelope without the run-time dimensions (a third fewer instructions)
 template <typename T, int NS, int NM, int NC, int L>
 static bool split_exact(const Batch &b, const StepArgs &a) {
-    if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC || a.noise_kind != KB_NOISE_NOISELESS) return false;
+    if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC || a.noise_kind != KB_NOISE_NOISELESS || a.predict) return false;   // (pure predictors: the run-time-everything kernel)
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
 #define KB_GO(F_, P_) hipLaunchKernelGGL((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_>), grid, block, 0, b.stream, a)
-    if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
-    else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
+    if (full) KB_GO(true, false); else KB_GO(false, false);
 #undef KB_GO
     return true;
 }

@@ -8,7 +8,7 @@ template <int NS, int NM, int L>
 static void split_plain(const Batch &b, const StepArgs &a) {
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
     if (a.noise_kind == KB_NOISE_AWGN) {
-        if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false, true>), grid, block, 0, b.stream, a);
+        if (a.flags & KB_FLAG_FULL_ESTIMATE) { if constexpr (NM <= 6) hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false, true>), grid, block, 0, b.stream, a); }
         else hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, false, false, false, false, true>), grid, block, 0, b.stream, a);
     } else if (a.flags & KB_FLAG_FULL_ESTIMATE) {
         hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false>), grid, block, 0, b.stream, a);
@@ -20,6 +20,7 @@ static void split_plain(const Batch &b, const StepArgs &a) {
 bool launch_vanilla_split16_plain(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
     if ((a.noise_kind != KB_NOISE_NOISELESS && a.noise_kind != KB_NOISE_AWGN) || a.predict) return false;
+    if (a.noise_kind == KB_NOISE_AWGN && (a.flags & KB_FLAG_FULL_ESTIMATE) && a.p > 6) return false;   // (AWGN with FULL at 7, 8 measurements: the run-time-everything kernel)
     if (a.p <= 4) split_plain<16, 4, 8>(b, a);
     else if (a.p <= 6) split_plain<16, 6, 8>(b, a);
     else split_plain<16, 8, 8>(b, a);
