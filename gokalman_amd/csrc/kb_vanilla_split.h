@@ -475,9 +475,21 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     const unsigned umq = um + (unsigned)(q * KB_TILE);
     const unsigned uf = um + (unsigned)(q * rn * KB_TILE);
     T *lf = lds + f;
+    // PAIRED: the regions read as CONTIGUOUS runs -- rows of F, columns of H (stored transposed), rows of P- H^T and of K --
+    // keep TWO consecutive elements per lane (16 bytes): a run is read with ds_read_b128, which the LDS array serves at 256 B/clk; the pairs
+    // of 8-byte reads the compiler otherwise forms (ds_read2_b64) go at 128 B/clk (MI355X_MICROARCH.md; NOTES.md: the array is busy 50-55 %
+    // of the kernel).  Element e of such a region: lp[PX(e)], lp = lds + 2 f.
+#ifdef KB_SPLIT_UNPAIRED   // (A/B: 14/7 587 -> 555 us, 16/8 606 -> 575, 16/4 459 -> 451, 12/6 232 -> 229, 9/3 170 -> 166 with the pairs; NOTES.md)
+    constexpr bool PAIRED = false;
+#else
+    constexpr bool PAIRED = true;
+#endif
+    T *const lp = PAIRED ? lds + 2 * f : lds + f;
+    auto PX = [](int e) constexpr -> int { return PAIRED ? (e >> 1) * (2 * FPW) + (e & 1) : e * FPW; };
+    auto HX = [](int c, int l, int nmrow) constexpr -> int { return PAIRED ? l * nmrow + c : c * NS + l; };   // H: [l][c] when paired
     auto lrows = [&]() -> T * {   // lf + q NM FPW: row q of an n x p matrix in LDS (late_lane: formed where it is used)
         const unsigned t = late_lane();
-        return lds + (t & (FPW - 1)) + ((t / FPW) & (L - 1)) * (NM * FPW);
+        return lds + (PAIRED ? 2 : 1) * (t & (FPW - 1)) + ((t / FPW) & (L - 1)) * (NM * FPW);
     };
     // ep(base, rt, c): element (rt + c) of a block -- rt wave-uniform at run time, c a compile-time constant -- as (scalar anchor,
     // made opaque to the optimiser) + (immediate within +-8 elements): left alone, instruction selection adds the part of c that
@@ -667,7 +679,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
     for (int r = 0; r < RP; r++)
 #pragma unroll
-        for (int l = 0; l < NS; l++) lf[((q + L * r) * NS + l) * FPW] = Fo[r][l];
+        for (int l = 0; l < NS; l++) (lp + q * (NS * FPW))[PX(L * r * NS + l)] = Fo[r][l];
     if constexpr (NC > 0) {   // G u while F settles in LDS
         if (rm > 0) {
             const T *up = (const T *)a.u + tile * a.u_ts;
@@ -721,12 +733,12 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     {
         T row[2][NS];
 #pragma unroll
-        for (int k = 0; k < NS; k++) row[0][k] = lf[(0 * NS + k) * FPW];
+        for (int k = 0; k < NS; k++) row[0][k] = lp[PX(0 * NS + k)];
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             if (j + 1 < NS) {
 #pragma unroll
-                for (int k = 0; k < NS; k++) row[(j + 1) & 1][k] = lf[((j + 1) * NS + k) * FPW];
+                for (int k = 0; k < NS; k++) row[(j + 1) & 1][k] = lp[PX((j + 1) * NS + k)];
             }
             if (j == KB_SPLIT_HJ) request_H();
             KB_SB();
@@ -875,7 +887,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
     for (int c = 0; c < NMH; c++)
 #pragma unroll
-        for (int r = 0; r < RP; r++) lf[(HOFF + c * NS + q + L * r) * FPW] = Hp[c][r];
+        for (int r = 0; r < RP; r++) (lp + HOFF * FPW + q * ((PAIRED ? NMH : 1) * FPW))[PX(HX(c, L * r, NMH))] = Hp[c][r];
     wave_lds_fence();
     KB_SB();
     // P- from here on: the mirrored upper triangle in LDS (what AsSymDense returns, helper.go:65-84).  Own row i_r, column l:
@@ -944,7 +956,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 const int l = ch * CH + d;
                 if (l < NS) {
 #pragma unroll
-                    for (int c = 0; c < NM; c++) hb[b][d][c] = lf[(HOFF + c * NS + l) * FPW];
+                    for (int c = 0; c < NM; c++) hb[b][d][c] = (lp + HOFF * FPW)[PX(HX(c, l, NM))];
 #pragma unroll
                     for (int r = 0; r < RP; r++) pb[b][d][r] = pm_own(r, l);
                 }
@@ -977,7 +989,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int c = 0; c < NMH; c++)
 #pragma unroll
-                for (int r = 0; r < RP; r++) lf[(HOFF + c * NS + q + L * r) * FPW] = Hp[c0 + c][r];
+                for (int r = 0; r < RP; r++) (lp + HOFF * FPW + q * ((PAIRED ? NMH : 1) * FPW))[PX(HX(c, L * r, NMH))] = Hp[c0 + c][r];
             wave_lds_fence();
             KB_SB();
         }
@@ -989,7 +1001,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 const int l = ch * CH + d;
                 if (l < NS) {
 #pragma unroll
-                    for (int c = 0; c < NMH; c++) hb[b][d][c] = lf[(HOFF + c * NS + l) * FPW];
+                    for (int c = 0; c < NMH; c++) hb[b][d][c] = (lp + HOFF * FPW)[PX(HX(c, l, NMH))];
 #pragma unroll
                     for (int r = 0; r < RP; r++) pb[b][d][r] = pm_own(r, l);
                 }
@@ -1207,7 +1219,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) lrows()[(GOFF + L * r * NM + c) * FPW] = PHt[r][c];
+            for (int c = 0; c < NM; c++) (lrows() + GOFF * FPW)[PX(L * r * NM + c)] = PHt[r][c];
         wave_lds_fence();
         KB_SB();
         if constexpr (DIST) {   // on their way while P- H^T is consumed
@@ -1229,7 +1241,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                     const int k = ch * CH + d;
                     if (k < NS) {
 #pragma unroll
-                        for (int c = 0; c < NM; c++) gb[b][d][c] = lf[(GOFF + k * NM + c) * FPW];
+                        for (int c = 0; c < NM; c++) gb[b][d][c] = (lp + GOFF * FPW)[PX(k * NM + c)];
                     }
                 }
             };
@@ -1262,7 +1274,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
             for (int c = 0; c < NM; c++)
 #pragma unroll
-                for (int r = 0; r < RP; r++) lf[(HJ + c * NS + q + L * r) * FPW] = Hp[c][r];
+                for (int r = 0; r < RP; r++) (lp + HJ * FPW + q * ((PAIRED ? NM : 1) * FPW))[PX(HX(c, L * r, NM))] = Hp[c][r];
 #pragma unroll
             for (int k = 0; k < RSH; k++)
                 if (L * k + L - 1 < TM || q + L * k < TM) lf[(ROFF + q + L * k) * FPW] = Rsh[k];
@@ -1277,7 +1289,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 for (int d = 0; d < CH; d++)
                     if (ch * CH + d < NS) {
 #pragma unroll
-                        for (int c = 0; c < NM; c++) hb[b][d][c] = lf[(HJ + c * NS + ch * CH + d) * FPW];
+                        for (int c = 0; c < NM; c++) hb[b][d][c] = (lp + HJ * FPW)[PX(HX(c, ch * CH + d, NM))];
                     }
             };
             fetch(0, 0);
@@ -1339,7 +1351,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) lrows()[(HJ + L * r * NM + c) * FPW] = K[r][c];
+            for (int c = 0; c < NM; c++) (lrows() + HJ * FPW)[PX(L * r * NM + c)] = K[r][c];
         wave_lds_fence();
         KB_SB();
         {
@@ -1350,7 +1362,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                 for (int d = 0; d < CH; d++)
                     if (ch * CH + d < NS) {
 #pragma unroll
-                        for (int c = 0; c < NM; c++) kb[b][d][c] = lf[(HJ + (ch * CH + d) * NM + c) * FPW];
+                        for (int c = 0; c < NM; c++) kb[b][d][c] = (lp + HJ * FPW)[PX((ch * CH + d) * NM + c)];
                     }
             };
             fetch(0, 0);
@@ -1428,7 +1440,7 @@ template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool 
 #define KB_HYB1_ false
 #endif
 __global__ void __launch_bounds__(64, (((RT || (NM > 6 && (KB_HYB1_ || !split_hsplit<NM, L>()))) && L == 4) ? 1 : ((int)sizeof(T) * split_lds_total<T, NS, NM, L, RT, FULLT>() * 8 <= 160 * 1024 ? 2 : 1))) vanilla_split_kernel(const StepArgs a) {
-    __shared__ T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
+    __shared__ __attribute__((aligned(16))) T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
     if constexpr (PERSIST) {
         const int64_t nparts = a.ntiles * L;
         for (int64_t gw = blockIdx.x; gw < nparts; gw += gridDim.x) {
