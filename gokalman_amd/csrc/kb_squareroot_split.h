@@ -73,8 +73,25 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     const unsigned um = a.mo_ts ? (unsigned)slot : 0u;
     const unsigned uq = us + (unsigned)(q * KB_TILE);
     const unsigned uf = um + (unsigned)(q * rn * KB_TILE);   // row q of an n-column matrix of the model block (F, and H's row q)
-    T *lf = lds + f;
-    T *lq = lf + q * FPW;
+    // LDS layout: TWO consecutive elements per lane (16 bytes), element e at lp[PX(e)]: the contiguous runs this kernel reads -- a reflector, a
+    // row of the packed factor -- go as ds_read_b128, which the LDS array serves at twice the bytes per clock of the ds_read2_b64 pairs the
+    // compiler forms from 8-byte neighbours (kb_vanilla_split.h PAIRED; NOTES.md: the array is busy ~50 % of the kernel).
+#ifdef KB_SQSPLIT_UNPAIRED
+    constexpr bool PAIRED = false;
+#else
+    constexpr bool PAIRED = true;
+#endif
+    T *const lp = PAIRED ? lds + 2 * f : lds + f;
+    auto PX = [](int e) constexpr -> int { return PAIRED ? (e >> 1) * (2 * FPW) + (e & 1) : e * FPW; };
+    // element (B + c), B a per-lane element number and c a compile-time constant: one base for even c, one for odd c
+    struct DynBase { T *e, *o; };
+    auto dyn = [&](int B) -> DynBase {
+        if (!PAIRED) return DynBase{lp + B * FPW, lp + B * FPW};
+        const int pb = (B >> 1) * (2 * FPW) + (B & 1);
+        return DynBase{lp + pb, lp + ((B & 1) ? ((B + 1) >> 1) * (2 * FPW) : pb + 1)};
+    };
+    auto at = [&](const DynBase &d, int c) -> T & { if (!PAIRED) return d.e[c * FPW]; return (c & 1) ? d.o[PX(c - 1)] : d.e[PX(c)]; };
+    const DynBase dq = dyn(q);
     auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
     // (model streams: non-temporal where a lane group reads whole 128-byte segments (L <= 4); with eight lanes per filter a group reads HALF
     // a line and the part next door the other half a little later -- the streaming hint lets the line leave the L2 in between and it comes
@@ -117,11 +134,11 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         KB_SB();
 #pragma unroll
         for (int k = 0; k < KP; k++)
-            if (L * k + L - 1 < TR || L * k + q < TR) lf[(L * k + q) * FPW] = Sp[k];
+            if (L * k + L - 1 < TR || L * k + q < TR) at(dq, L * k) = Sp[k];
         if constexpr (XPARK) {   // FULL: x_prev waits in Syy's slots (free until the second factorisation) for yhat = H x_prev
             if (full) {
 #pragma unroll
-                for (int l = 0; l < NS; l++) lf[(SYOFF + l) * FPW] = x[l];   // (the L lanes of a filter write the same values)
+                for (int l = 0; l < NS; l++) lp[PX(SYOFF + l)] = x[l];   // (the L lanes of a filter write the same values)
             }
         }
     }
@@ -164,7 +181,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         auto fetch = [&](int l, int b) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < NS; i++)
-                if (i <= l) row[b][i] = lf[(l * (l + 1) / 2 + i) * FPW];
+                if (i <= l) row[b][i] = lp[PX(l * (l + 1) / 2 + i)];
         };
         fetch(0, 0);
         // (sfor, kb_device.h: the bounds of the triangular inner loops are compile-time constants from the start; as `#pragma unroll`
@@ -219,23 +236,23 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
             T u0, fr;
             const T dg = reflector<T>(Ct[rk][k], xn2, true, u0, fr);
             if (q == qk) {
-                lf[(BOFF + 0) * FPW] = u0;
-                lf[(BOFF + 1) * FPW] = fr;
+                lp[PX(BOFF + 0)] = u0;
+                lp[PX(BOFF + 1)] = fr;
 #pragma unroll
-                for (int i = k + 1; i < NS; i++) lf[(BOFF + 2 + i) * FPW] = Ct[rk][i];
+                for (int i = k + 1; i < NS; i++) lp[PX(BOFF + 2 + i)] = Ct[rk][i];
 #pragma unroll
-                for (int i = 0; i <= k; i++) lf[(BOFF + 2 + NS + i) * FPW] = Cb[rk][i];   // (the bottom rows sit behind the n top slots)
+                for (int i = 0; i <= k; i++) lp[PX(BOFF + 2 + NS + i)] = Cb[rk][i];   // (the bottom rows sit behind the n top slots)
                 Ct[rk][k] = dg;
             }
         }
         wave_lds_fence();
         {
-            const T u0 = lf[(BOFF + 0) * FPW], fr = lf[(BOFF + 1) * FPW];
+            const T u0 = lp[PX(BOFF + 0)], fr = lp[PX(BOFF + 1)];
             T ut[NS], ub[NS];
 #pragma unroll
-            for (int i = k + 1; i < NS; i++) ut[i] = lf[(BOFF + 2 + i) * FPW];
+            for (int i = k + 1; i < NS; i++) ut[i] = lp[PX(BOFF + 2 + i)];
 #pragma unroll
-            for (int i = 0; i <= k; i++) ub[i] = lf[(BOFF + 2 + NS + i) * FPW];
+            for (int i = 0; i <= k; i++) ub[i] = lp[PX(BOFF + 2 + NS + i)];
 #pragma unroll
             for (int r = rk; r < RP; r++) {
                 const bool upd = r > rk || q > qk;   // own column q + L r lies right of k
@@ -265,7 +282,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     for (int r = 0; r < RP; r++)
 #pragma unroll
         for (int i = 0; i < L * r + L; i++)
-            if (i <= q + L * r) (lf + (utri[r] / KB_TILE) * FPW)[i * FPW] = Ct[r][i];
+            if (i <= q + L * r) at(dyn((q + L * r) * (q + L * r + 1) / 2), i) = Ct[r][i];
     if (full && active) {
         T *const es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems);
 #pragma unroll
@@ -311,7 +328,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
                 T s = T(0);
 #pragma unroll
                 for (int l = 0; l < NS; l++) {
-                    if constexpr (XPARK) s += Hrow[r2][l] * lf[(SYOFF + l) * FPW];
+                    if constexpr (XPARK) s += Hrow[r2][l] * lp[PX(SYOFF + l)];
                     else s += Hrow[r2][l] * ((l < rn) ? *(ep(st, 0, l) + us) : T(0));
                 }
                 hxp[r2] = s;
@@ -324,7 +341,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         auto fetch = [&](int i, int b) __attribute__((always_inline)) {
 #pragma unroll
             for (int l = 0; l < NS; l++)
-                if (l <= i) col[b][l] = lf[(i * (i + 1) / 2 + l) * FPW];
+                if (l <= i) col[b][l] = lp[PX(i * (i + 1) / 2 + l)];
         };
         fetch(0, 0);
         sfor<0, NS>([&](auto II) __attribute__((always_inline)) {
@@ -345,20 +362,20 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
         // measurement rows are formed here, and gathered below
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < RP; r++) lq[(XOFF + L * r) * FPW] = xm[r];
+        for (int r = 0; r < RP; r++) at(dq, XOFF + L * r) = xm[r];
         wave_lds_fence();
         T hx[PC];
 #pragma unroll
         for (int r2 = 0; r2 < PC; r2++) {
             T s = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) s += Hrow[r2][l] * lf[(XOFF + l) * FPW];
+            for (int l = 0; l < NS; l++) s += Hrow[r2][l] * lp[PX(XOFF + l)];
             hx[r2] = s;
         }
         wave_lds_fence();
 #pragma unroll
         for (int r2 = 0; r2 < PC; r2++)
-            if (mcol[r2]) lq[(XOFF + NS + L * r2) * FPW] = hx[r2];
+            if (mcol[r2]) at(dq, XOFF + NS + L * r2) = hx[r2];
     }
     // state columns p + j, j = j_r: top zero, bottom S-^T[i][j] = Uc[j][i] for i >= j (element tri(i) + j of the packed Uc)
 #pragma unroll
@@ -368,7 +385,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             T v = T(0);
-            if (i >= L * r) v = lq[(i * (i + 1) / 2 + L * r) * FPW];
+            if (i >= L * r) v = at(dq, i * (i + 1) / 2 + L * r);
             Ds[r][NM + i] = (i >= q + L * r) ? v : T(0);
         }
     }
@@ -394,19 +411,19 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
             T u0, fr;
             const T dg = reflector<T>(Dm[rk][k], xn2, true, u0, fr);
             if (q == qk) {
-                lf[(BOFF + 0) * FPW] = u0;
-                lf[(BOFF + 1) * FPW] = fr;
+                lp[PX(BOFF + 0)] = u0;
+                lp[PX(BOFF + 1)] = fr;
 #pragma unroll
-                for (int i = NM; i < DD; i++) lf[(BOFF + 2 + i) * FPW] = Dm[rk][i];
+                for (int i = NM; i < DD; i++) lp[PX(BOFF + 2 + i)] = Dm[rk][i];
                 Dm[rk][k] = dg;
             }
         }
         wave_lds_fence();
         {
-            const T u0 = lf[(BOFF + 0) * FPW], fr = lf[(BOFF + 1) * FPW];
+            const T u0 = lp[PX(BOFF + 0)], fr = lp[PX(BOFF + 1)];
             T u[DD];
 #pragma unroll
-            for (int i = NM; i < DD; i++) u[i] = lf[(BOFF + 2 + i) * FPW];
+            for (int i = NM; i < DD; i++) u[i] = lp[PX(BOFF + 2 + i)];
 #pragma unroll
             for (int r2 = rk; r2 < PC; r2++) {
                 const bool upd = r2 > rk || q > qk;
@@ -429,12 +446,12 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
                 for (int i = NM; i < DD; i++) { Ds[r][i] += fs * u[i]; pin(Ds[r][i]); }
                 // row k of the state columns is final (W[j_r][k] = UD[k][p + j_r]): it waits in LDS for the gain, not in a register
-                lf[((L * r) * NM + k) * FPW + q * NM * FPW] = Ds[r][k];
+                (lp + q * NM * FPW)[PX((L * r) * NM + k)] = Ds[r][k];
             }
             // ... and so is row k of the measurement columns c >= k (Syy[c][k] = UD[k][c]): slot NM c + k of the Syy region
 #pragma unroll
             for (int r2 = rk; r2 < PC; r2++)
-                if (mcol[r2] && (r2 > rk || q >= qk)) lf[(SYOFF + NM * (L * r2) + k) * FPW + NM * q * FPW] = Dm[r2][k];
+                if (mcol[r2] && (r2 > rk || q >= qk)) (lp + q * NM * FPW)[PX(SYOFF + NM * (L * r2) + k)] = Dm[r2][k];
         }
         wave_lds_fence();
         KB_SB();
@@ -451,7 +468,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
         for (int i = 0; i < NM; i++)
 #pragma unroll
-            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lf[(SYOFF + NM * i + j) * FPW] : T(0);   // Syy[i][j] = UD[j][i]
+            for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? lp[PX(SYOFF + NM * i + j)] : T(0);   // Syy[i][j] = UD[j][i]
         unsigned swaps;
         T anorm;
         (void)lu_factor_any<T, NM>(Syy, swaps, anorm, rp);
@@ -459,7 +476,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int k2 = 0; k2 < NM; k2++) Wr[r][k2] = lf[((L * r) * NM + k2) * FPW + q * NM * FPW];   // W[j_r][k2], parked above
+            for (int k2 = 0; k2 < NM; k2++) Wr[r][k2] = (lp + q * NM * FPW)[PX((L * r) * NM + k2)];   // W[j_r][k2], parked above
         sfor<0, NM>([&](auto CC) __attribute__((always_inline)) {
             constexpr int c = CC;
             T v[NM];
@@ -480,14 +497,14 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
     {
         const T *yp = (const T *)a.y + tile * a.y_ts;
 #pragma unroll
-        for (int c = 0; c < NM; c++) innov[c] = ((active && c < rp) ? ldnt_at(&(yp + (int64_t)c * a.y_es)[us]) : T(0)) - lf[(XOFF + NS + c) * FPW];
+        for (int c = 0; c < NM; c++) innov[c] = ((active && c < rp) ? ldnt_at(&(yp + (int64_t)c * a.y_es)[us]) : T(0)) - lp[PX(XOFF + NS + c)];
     }
 #pragma unroll
     for (int r = 0; r < RP; r++) {
         T s = T(0);
 #pragma unroll
         for (int c = 0; c < NM; c++) s += K[r][c] * innov[c];
-        xn[r] = lq[(XOFF + L * r) * FPW] + s;   // x-[j_r], parked in LDS until here
+        xn[r] = at(dq, XOFF + L * r) + s;   // x-[j_r], parked in LDS until here
         pin(xn[r]);
     }
     if (full) {   // the Estimate's gain and innovation wait in LDS (W's and Syy's slots: both consumed) for the end of the step
@@ -495,10 +512,10 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int c = 0; c < NM; c++) lf[((L * r) * NM + c) * FPW + q * NM * FPW] = K[r][c];
+            for (int c = 0; c < NM; c++) (lp + q * NM * FPW)[PX((L * r) * NM + c)] = K[r][c];
         if (q == 0) {
 #pragma unroll
-            for (int c = 0; c < NM; c++) lf[(SYOFF + c) * FPW] = innov[c];
+            for (int c = 0; c < NM; c++) lp[PX(SYOFF + c)] = innov[c];
         }
     }
     KB_SB();
@@ -520,19 +537,19 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
             T u0, fr;
             const T dg = reflector<T>(Ds[rk][k], xn2, k + 1 < DD, u0, fr);
             if (q == qk) {
-                lf[(BOFF + 0) * FPW] = u0;
-                lf[(BOFF + 1) * FPW] = fr;
+                lp[PX(BOFF + 0)] = u0;
+                lp[PX(BOFF + 1)] = fr;
 #pragma unroll
-                for (int i = k + 1; i < DD; i++) lf[(BOFF + 2 + i) * FPW] = Ds[rk][i];
+                for (int i = k + 1; i < DD; i++) lp[PX(BOFF + 2 + i)] = Ds[rk][i];
                 Ds[rk][k] = dg;
             }
         }
         wave_lds_fence();
         {
-            const T u0 = lf[(BOFF + 0) * FPW], fr = lf[(BOFF + 1) * FPW];
+            const T u0 = lp[PX(BOFF + 0)], fr = lp[PX(BOFF + 1)];
             T u[DD];
 #pragma unroll
-            for (int i = k + 1; i < DD; i++) u[i] = lf[(BOFF + 2 + i) * FPW];
+            for (int i = k + 1; i < DD; i++) u[i] = lp[PX(BOFF + 2 + i)];
 #pragma unroll
             for (int r = rk; r < RP; r++) {
                 const bool upd = r > rk || q > qk;
@@ -570,14 +587,14 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
                     double z0, z1;
                     box_muller(rr, z0, z1);
                     if (L * it + L - 1 < NB || blk < NB) {
-                        lf[(BOFF + 2 * blk) * FPW] = (T)z0;
-                        if (2 * (L * it + L - 1) + 1 < NV || 2 * blk + 1 < NV) lf[(BOFF + 2 * blk + 1) * FPW] = (T)z1;
+                        lp[PX(BOFF + 2 * blk)] = (T)z0;
+                        if (2 * (L * it + L - 1) + 1 < NV || 2 * blk + 1 < NV) lp[PX(BOFF + 2 * blk + 1)] = (T)z1;
                     }
                     KB_SB();
                 }
                 wave_lds_fence();
 #pragma unroll
-                for (int kk = 0; kk < NV; kk++) zv[kk] = lf[(BOFF + kk) * FPW];
+                for (int kk = 0; kk < NV; kk++) zv[kk] = lp[PX(BOFF + kk)];
                 wave_lds_fence();
             };
             {
@@ -651,11 +668,11 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
             for (int r = 0; r < RP; r++)
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (colok[r] && c < rp) __builtin_nontemporal_store(lf[((L * r) * NM + c) * FPW + q * NM * FPW], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
+                    if (colok[r] && c < rp) __builtin_nontemporal_store((lp + q * NM * FPW)[PX((L * r) * NM + c)], ep(es, a.L.es_gain + L * r * a.pmax, c) + (us + (unsigned)(q * a.pmax * KB_TILE)));
             if (q == 0) {
 #pragma unroll
                 for (int c = 0; c < NM; c++)
-                    if (c < rp) __builtin_nontemporal_store(lf[(SYOFF + c) * FPW], ep(es, a.L.es_innov, c) + us);
+                    if (c < rp) __builtin_nontemporal_store(lp[PX(SYOFF + c)], ep(es, a.L.es_innov, c) + us);
             }
         }
     }
@@ -672,7 +689,7 @@ __device__ __forceinline__ void squareroot_split_part(const StepArgs &a, const i
 
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool RT = GEN, bool NOISET = false>
 __global__ void __launch_bounds__(64, ((RT || NM > 6) && L == 4) ? 1 : 2) squareroot_split_kernel(const StepArgs a) {
-    __shared__ T lds[sqsplit_lds_elems<NS, NM>() * (64 / L)];
+    __shared__ __attribute__((aligned(16))) T lds[(sqsplit_lds_elems<NS, NM>() + 1) / 2 * 2 * (64 / L)];   // (whole pairs)
     squareroot_split_part<T, NS, NM, NC, L, GEN, FULLT, RT, NOISET>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);   // (kb_vanilla_split.h: XCD-aware for L = 8)
 }
 #undef KB_SB
