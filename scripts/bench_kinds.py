@@ -113,7 +113,9 @@ if "vpad" in which:
     # Vanilla with KB_FLAG_FULL_ESTIMATE (the Estimate's extras leave where they are formed)
     N = Nopt or (1 << 18)
     for kind, kname, n, p, flags in ((k.VANILLA, "Vanilla", 10, 4, 0), (k.SQUAREROOT, "SquareRoot", 8, 4, 0), (k.INFORMATION, "Information", 8, 4, k.FLAG_INFO_FROM_STATE),
-                                     (k.VANILLA, "Vanilla", 16, 4, 0), (k.VANILLA, "Vanilla FULL", 12, 6, k.FLAG_FULL_ESTIMATE)):
+                                     (k.VANILLA, "Vanilla", 16, 4, 0), (k.VANILLA, "Vanilla FULL", 12, 6, k.FLAG_FULL_ESTIMATE),
+                                     # (round 5: S^-1 once per filter at p = 7, 8 -- the exact 12 / 8 and 16 / 8 kernels, the padded <16, 8> one at 14 / 7)
+                                     (k.VANILLA, "Vanilla", 12, 8, 0), (k.VANILLA, "Vanilla", 14, 7, 0), (k.VANILLA, "Vanilla", 16, 8, 0)):
         d = synth.linear_batch(N, n, p, 1)
         y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
         b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=flags)

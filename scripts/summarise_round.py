@@ -100,7 +100,7 @@ def main():
                "vanilla_reg_kernel<double, 6, 3, 0": 1 << 20, "squareroot_reg_kernel<double, 6, 3": 1 << 20, "information_reg_kernel<double, 6, 3": 1 << 20,
                "hybrid_reg_kernel<double, 6, 2": 1 << 20, "srif_pair_kernel<float, 12, 6": 1 << 18, "srif_pair_kernel<double, 12, 6": 1 << 18,
                "vanilla_split_kernel<double, 12, 6": 1 << 18, "squareroot_split_kernel<double, 12, 6": 1 << 18, "information_split_kernel<double, 12, 6": 1 << 18,
-               "vanilla_split_kernel<double, 12, 4": 1 << 18, "vanilla_split_kernel<double, 16, 4": 1 << 18, "squareroot_split_kernel<double, 8, 4": 1 << 18, "information_split_kernel<double, 8, 4": 1 << 18,
+               "vanilla_split_kernel<double, 12, 4": 1 << 18, "vanilla_split_kernel<double, 16, 4": 1 << 18, "vanilla_split_kernel<double, 12, 8": 1 << 18, "vanilla_split_kernel<double, 16, 8": 1 << 18, "squareroot_split_kernel<double, 8, 4": 1 << 18, "information_split_kernel<double, 8, 4": 1 << 18,
                "srif_split_kernel<": 1 << 18}
     for fkey, wkey in (("bench_fetch", "bench_write"), ("kinds_fetch", "kinds_write")):
         fe, wr = c["pmc"].get(fkey, {}), c["pmc"].get(wkey, {})
