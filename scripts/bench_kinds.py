@@ -116,7 +116,13 @@ if "vpad" in which:
                                      (k.VANILLA, "Vanilla", 16, 4, 0), (k.VANILLA, "Vanilla FULL", 12, 6, k.FLAG_FULL_ESTIMATE),
                                      # (round 5: S^-1 once per filter at p = 7, 8 -- the exact 12 / 8 and 16 / 8 kernels, the padded <16, 8> one at 14 / 7)
                                      (k.VANILLA, "Vanilla", 12, 8, 0), (k.VANILLA, "Vanilla", 14, 7, 0), (k.VANILLA, "Vanilla", 16, 8, 0)):
-        d = synth.linear_batch(N, n, p, 1)
+        if p <= n // 2 and n % 2 == 0:
+            d = synth.linear_batch(N, n, p, 1)
+        else:   # (more measurements than position states: scripts/bench_split_shapes.py's dense-H problem)
+            rng = np.random.default_rng(n)
+            sc = (1.0 + 0.01 * rng.random(N))[:, None, None]
+            d = dict(F=np.eye(n) + sc * (0.05 * rng.standard_normal((n, n))), H=sc * rng.standard_normal((p, n)), Q=sc * (1e-3 * np.eye(n)), R=sc * (1e-2 * np.eye(p)),
+                     x0=np.zeros((N, n)), P0=np.broadcast_to(np.eye(n), (N, n, n)), y=rng.standard_normal((1, N, p)))
         y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
         b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], flags=flags)
         ms = timed(b, lambda: b.update_dev(y[0].data_ptr(), N))
