@@ -133,7 +133,15 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
     const unsigned uq = us + (unsigned)(q * KB_TILE), umq = um + (unsigned)(q * KB_TILE);
     // the caller's planar arrays (kb_prepare_dev) end at N: lanes past it re-read the part's first filter; 64-bit lane offsets
     const int64_t xoff = ext ? (int64_t)q * a.ext_ld + (tile * KB_TILE + (active ? slot : part * FPW)) : 0;
-    T *const lf = lds + f;
+    // LDS layout: TWO consecutive elements per lane, element e at lp[PX(e)]: the pivot rows and the reflectors are read as contiguous runs --
+    // ds_read_b128 (fp32: ds_read_b64) at twice the array rate of the pairs of narrow reads the compiler forms (kb_vanilla_split.h PAIRED; NOTES.md)
+#ifdef KB_SRIF_SPLIT_UNPAIRED
+    constexpr bool PAIRED = false;
+#else
+    constexpr bool PAIRED = true;
+#endif
+    T *const lp = PAIRED ? lds + 2 * f : lds + f;
+    auto PX = [](int e) constexpr -> int { return PAIRED ? (e >> 1) * (2 * FPW) + (e & 1) : e * FPW; };
     auto ep = [&](const T *ubase, int rt, int c) -> cgptr { return anchored(ubase, rt, c); };
     // Read-once streams (Phi, Htilde, chol R, observations): non-temporal at four lanes per filter, where a lane group reads a whole
     // 128-byte segment.  At eight lanes a group reads HALF a line and the part next door reads the other half a little later: with the
@@ -215,8 +223,8 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 #pragma unroll
         for (int r = 0; r < RP; r++) {
 #pragma unroll
-            for (int i = 0; i < NS; i++) lf[(i * NS + jr[r]) * FPW] = Rc[r][i];
-            lf[(NS * NS + jr[r]) * FPW] = bo[r];
+            for (int i = 0; i < NS; i++) lp[PX(i * NS + jr[r])] = Rc[r][i];
+            lp[PX(NS * NS + jr[r])] = bo[r];
         }
         wave_lds_fence();
         if (q == 0) {
@@ -224,46 +232,46 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 #pragma unroll 1
             for (int k = 0; k < rn; k++) {
                 int piv = k;
-                T best = fabs(lf[(k * NS + k) * FPW]);
+                T best = fabs(lp[PX(k * NS + k)]);
 #pragma unroll 1
                 for (int i = k + 1; i < rn; i++) {
-                    const T v = fabs(lf[(i * NS + k) * FPW]);
+                    const T v = fabs(lp[PX(i * NS + k)]);
                     if (v > best) { best = v; piv = i; }
                 }
                 if (piv != k) {
 #pragma unroll 1
                     for (int c = 0; c < rn; c++) {
-                        const T t0 = lf[(k * NS + c) * FPW], t1 = lf[(piv * NS + c) * FPW];
-                        lf[(k * NS + c) * FPW] = t1;
-                        lf[(piv * NS + c) * FPW] = t0;
+                        const T t0 = lp[PX(k * NS + c)], t1 = lp[PX(piv * NS + c)];
+                        lp[PX(k * NS + c)] = t1;
+                        lp[PX(piv * NS + c)] = t0;
                     }
-                    const T t0 = lf[(NS * NS + k) * FPW], t1 = lf[(NS * NS + piv) * FPW];
-                    lf[(NS * NS + k) * FPW] = t1;
-                    lf[(NS * NS + piv) * FPW] = t0;
+                    const T t0 = lp[PX(NS * NS + k)], t1 = lp[PX(NS * NS + piv)];
+                    lp[PX(NS * NS + k)] = t1;
+                    lp[PX(NS * NS + piv)] = t0;
                 }
-                const T pv = lf[(k * NS + k) * FPW];
+                const T pv = lp[PX(k * NS + k)];
                 bad = bad || pv == T(0);
                 const T ri = T(1) / pv;
 #pragma unroll 1
                 for (int i = k + 1; i < rn; i++) {
-                    const T l = lf[(i * NS + k) * FPW] * ri;
+                    const T l = lp[PX(i * NS + k)] * ri;
 #pragma unroll 1
-                    for (int c = k + 1; c < rn; c++) lf[(i * NS + c) * FPW] -= l * lf[(k * NS + c) * FPW];
-                    lf[(NS * NS + i) * FPW] -= l * lf[(NS * NS + k) * FPW];
+                    for (int c = k + 1; c < rn; c++) lp[PX(i * NS + c)] -= l * lp[PX(k * NS + c)];
+                    lp[PX(NS * NS + i)] -= l * lp[PX(NS * NS + k)];
                 }
             }
 #pragma unroll 1
             for (int i = rn - 1; i >= 0; i--) {
-                T s = lf[(NS * NS + i) * FPW];
+                T s = lp[PX(NS * NS + i)];
 #pragma unroll 1
-                for (int c = i + 1; c < rn; c++) s -= lf[(i * NS + c) * FPW] * lf[(NS * NS + c) * FPW];
-                lf[(NS * NS + i) * FPW] = s / lf[(i * NS + i) * FPW];
+                for (int c = i + 1; c < rn; c++) s -= lp[PX(i * NS + c)] * lp[PX(NS * NS + c)];
+                lp[PX(NS * NS + i)] = s / lp[PX(i * NS + i)];
             }
             if (bad) err |= KB_ST_SINGULAR;
         }
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < RP; r++) xs[r] = colok[r] ? lf[(NS * NS + jr[r]) * FPW] : T(0);
+        for (int r = 0; r < RP; r++) xs[r] = colok[r] ? lp[PX(NS * NS + jr[r])] : T(0);
         wave_lds_fence();
     } else {
         T rinv[RP], acc[NS];
@@ -329,23 +337,23 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
                 const T pv0 = Pc[r0][k];
                 const T ri = recip(pv0);
                 if (own) {
-                    lf[k * FPW] = pv0;
+                    lp[PX(k)] = pv0;
 #pragma unroll
-                    for (int c = k + 1; c < NS; c++) lf[c * FPW] = Pc[r0][c] * ri;
+                    for (int c = k + 1; c < NS; c++) lp[PX(c)] = Pc[r0][c] * ri;
 #pragma unroll
-                    for (int c = 0; c <= k; c++) lf[(NS + c) * FPW] = Rc[r0][c] * ri;
+                    for (int c = 0; c <= k; c++) lp[PX(NS + c)] = Rc[r0][c] * ri;
                 }
                 wave_lds_fence();
-                const T pvb = fabs(lf[k * FPW]);
+                const T pvb = fabs(lp[PX(k)]);
                 bool need = false;   // a candidate row below with a larger entry (an equal one loses to row k: dgetf2 takes the first)
 #pragma unroll
                 for (int r = r0; r < RP; r++) need = need || ((r > r0 || q > q0) && colok[r] && fabs(Pc[r][k]) > pvb);
                 if (!__any(need)) {
                     T pr[NS], prr[NS];
 #pragma unroll
-                    for (int c = k + 1; c < NS; c++) pr[c] = lf[c * FPW];
+                    for (int c = k + 1; c < NS; c++) pr[c] = lp[PX(c)];
 #pragma unroll
-                    for (int c = 0; c <= k; c++) prr[c] = lf[(NS + c) * FPW];
+                    for (int c = 0; c <= k; c++) prr[c] = lp[PX(NS + c)];
                     if (own && pv0 == T(0)) err |= KB_ST_SINGULAR;
 #pragma unroll
                     for (int r = 0; r < RP; r++) {
@@ -386,17 +394,17 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
                         const T ri = recip(pv);
                         scale[r] = ri;
 #pragma unroll
-                        for (int c = k + 1; c < NS; c++) lf[c * FPW] = Pc[r][c] * ri;
+                        for (int c = k + 1; c < NS; c++) lp[PX(c)] = Pc[r][c] * ri;
 #pragma unroll
-                        for (int c = 0; c < NS; c++) lf[(NS + c) * FPW] = Rc[r][c] * ri;
+                        for (int c = 0; c < NS; c++) lp[PX(NS + c)] = Rc[r][c] * ri;
                     }
                 }
                 wave_lds_fence();
                 T pr[NS], prr[NS];
 #pragma unroll
-                for (int c = k + 1; c < NS; c++) pr[c] = lf[c * FPW];
+                for (int c = k + 1; c < NS; c++) pr[c] = lp[PX(c)];
 #pragma unroll
-                for (int c = 0; c < NS; c++) prr[c] = lf[(NS + c) * FPW];
+                for (int c = 0; c < NS; c++) prr[c] = lp[PX(NS + c)];
 #pragma unroll
                 for (int r = 0; r < RP; r++) {
                     const T m = isp[r] ? T(0) : Pc[r][k];
@@ -429,12 +437,12 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
-                for (int i = 0; i < NS; i++) lf[(dest[r] * NS + i) * FPW] = Rc[r][i];
+                for (int i = 0; i < NS; i++) lp[PX(dest[r] * NS + i)] = Rc[r][i];
             wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < RP; r++)
 #pragma unroll
-                for (int i = 0; i < NS; i++) Rc[r][i] = lf[(jr[r] * NS + i) * FPW];
+                for (int i = 0; i < NS; i++) Rc[r][i] = lp[PX(jr[r] * NS + i)];
             wave_lds_fence();
         }
     }
@@ -590,16 +598,16 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
             const T uk = akk + sigma;
             const T beta = recip(sigma * uk);
             if (own) {
-                lf[k * FPW] = uk;
-                lf[ROWS * FPW] = beta;
+                lp[PX(k)] = uk;
+                lp[PX(ROWS)] = beta;
 #pragma unroll
-                for (int i = k + 1; i < ROWS; i++) lf[i * FPW] = A(r0, i);
+                for (int i = k + 1; i < ROWS; i++) lp[PX(i)] = A(r0, i);
             }
             wave_lds_fence();
             T u[ROWS];
 #pragma unroll
-            for (int i = k; i < ROWS; i++) u[i] = lf[i * FPW];
-            const T bt = lf[ROWS * FPW];
+            for (int i = k; i < ROWS; i++) u[i] = lp[PX(i)];
+            const T bt = lp[PX(ROWS)];
 #pragma unroll
             for (int r = (q0 == L - 1 ? r0 + 1 : r0); r < RP; r++) {   // (q0 = L - 1: no column of slot r0 lies right of k)
                 const bool right = r > r0 || q > q0;   // column j_r lies right of k
@@ -619,7 +627,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
                     const int base = t < RP ? L * t : NS + L * (t - RP);   // first row of slot t
                     if (base + L - 1 >= k && base < ROWS) {
                         const bool in = base + q >= k && base + q < ROWS;
-                        const T v = lf[(in ? base + q : k) * FPW];
+                        const T v = lp[PX(in ? base + q : k)];
                         uo[t] = in ? v : T(0);
                         gp += uo[t] * rv[t];
                     } else {
@@ -665,7 +673,7 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 
 template <typename T, int N, int NM, int L>
 __global__ void __launch_bounds__(64, (N <= 8 && NM <= 4) ? 3 : 2) srif_split_kernel(const StepArgs a) {
-    __shared__ T lds[srif_split_lds_elems<(N + L - 1) / L * L, NM, L>()];
+    __shared__ __attribute__((aligned(16))) T lds[srif_split_lds_elems<(N + L - 1) / L * L, NM, L>()];
     srif_split_part<T, N, NM, L>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
 }
 
