@@ -135,10 +135,11 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
     const int64_t xoff = ext ? (int64_t)q * a.ext_ld + (tile * KB_TILE + (active ? slot : part * FPW)) : 0;
     // LDS layout: TWO consecutive elements per lane, element e at lp[PX(e)]: the pivot rows and the reflectors are read as contiguous runs --
     // ds_read_b128 (fp32: ds_read_b64) at twice the array rate of the pairs of narrow reads the compiler forms (kb_vanilla_split.h PAIRED; NOTES.md)
+    // (A/B, NOTES.md: fp32 -4 ... -9 %, fp64 at eight lanes -1 ... -3 %; fp64 at four lanes nothing, and 8-16 B of scratch more at p = 7, 8: left as it was)
 #ifdef KB_SRIF_SPLIT_UNPAIRED
     constexpr bool PAIRED = false;
 #else
-    constexpr bool PAIRED = true;
+    constexpr bool PAIRED = sizeof(T) == 4 || L == 8;
 #endif
     T *const lp = PAIRED ? lds + 2 * f : lds + f;
     auto PX = [](int e) constexpr -> int { return PAIRED ? (e >> 1) * (2 * FPW) + (e & 1) : e * FPW; };
