@@ -47,9 +47,25 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
     const unsigned uq = us + (unsigned)(q * KB_TILE);
     const unsigned umq = um + (unsigned)(q * KB_TILE);
     const unsigned uf = um + (unsigned)(q * rn * KB_TILE);
-    T *lf = lds + f;
-    T *lq = lf + q * FPW;            // slot (e + q): own column / own entry of a vector
-    T *lqn = lf + q * NS * FPW;      // slot (e + q n): own row q + L r of a row-major n-column matrix starts at slot (L r) n from here
+    // LDS layout: TWO consecutive elements per lane (16 bytes), element e at lp[PX(e)]: the contiguous runs this kernel reads -- the multipliers
+    // of an elimination step, a row of an n x n operand -- go as ds_read_b128 at twice the array rate of the ds_read2_b64 pairs the compiler
+    // forms from 8-byte neighbours (kb_vanilla_split.h PAIRED; NOTES.md).
+#ifdef KB_INFSPLIT_UNPAIRED
+    constexpr bool PAIRED = false;
+#else
+    constexpr bool PAIRED = true;
+#endif
+    T *const lp = PAIRED ? lds + 2 * f : lds + f;
+    auto PX = [](int e) constexpr -> int { return PAIRED ? (e >> 1) * (2 * FPW) + (e & 1) : e * FPW; };
+    struct DynBase { T *e, *o; };   // element (B + c), B per lane, c a compile-time constant: one base for even c, one for odd c
+    auto dyn = [&](int B) -> DynBase {
+        if (!PAIRED) return DynBase{lp + B * FPW, lp + B * FPW};
+        const int pb = (B >> 1) * (2 * FPW) + (B & 1);
+        return DynBase{lp + pb, lp + ((B & 1) ? ((B + 1) >> 1) * (2 * FPW) : pb + 1)};
+    };
+    auto at = [&](const DynBase &d, int c) -> T & { if (!PAIRED) return d.e[c * FPW]; return (c & 1) ? d.o[PX(c - 1)] : d.e[PX(c)]; };
+    const DynBase dq = dyn(q);       // slot (e + q): own column / own entry of a vector
+    T *const lqn = lp + q * NS * FPW;   // slot (e + q n), n even: own row q + L r of a row-major n-column matrix starts at slot (L r) n from here
     auto ep = [&](const T *ubase, int rt, int c) -> gptr { return (gptr)anchored(ubase, rt, c); };
     // (model streams: non-temporal where a lane group reads whole 128-byte segments (L <= 4); with eight lanes per filter a group reads HALF
     // a line and the part next door the other half a little later -- the streaming hint lets the line leave the L2 in between and it comes
@@ -87,23 +103,23 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
                 for (int r2 = k + 1; r2 < NS; r2++) pv = (piv == r2) ? Bm[rk][r2] : pv;
                 const T rpv = T(1) / pv;
                 if (q == qk) {
-                    lf[(BOFF + 0) * FPW] = (T)piv;
-                    lf[(BOFF + 1) * FPW] = pv;
+                    lp[PX(BOFF + 0)] = (T)piv;
+                    lp[PX(BOFF + 1)] = pv;
     #pragma unroll
                     for (int r2 = k + 1; r2 < NS; r2++) {
                         // the multiplier of row r2 AFTER the exchange: the entry that sits in row r2 then is the old row k's if r2 == piv
                         const T e = (piv == r2) ? Bm[rk][k] : Bm[rk][r2];
-                        lf[(BOFF + 1 + r2) * FPW] = e * rpv;
+                        lp[PX(BOFF + 1 + r2)] = e * rpv;
                     }
                 }
             }
             wave_lds_fence();
             {
-                const int piv = (int)lf[(BOFF + 0) * FPW];
-                zero_pivot = zero_pivot || (lf[(BOFF + 1) * FPW] == T(0));
+                const int piv = (int)lp[PX(BOFF + 0)];
+                zero_pivot = zero_pivot || (lp[PX(BOFF + 1)] == T(0));
                 T mult[NS];
     #pragma unroll
-                for (int r2 = k + 1; r2 < NS; r2++) mult[r2] = lf[(BOFF + 1 + r2) * FPW];
+                for (int r2 = k + 1; r2 < NS; r2++) mult[r2] = lp[PX(BOFF + 1 + r2)];
                 // rows k and piv change places in every column: entries k and piv of every own row of B and of M -- only when some filter of the
                 // wave pivots.  (sfor, not `#pragma unroll` loops: inside the conditional block those are unrolled too late for the arrays
                 // to be promoted to registers: 592 B of scratch per lane.)
@@ -146,14 +162,14 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
     #pragma unroll
             for (int r = 0; r < RP; r++)
                 if (L * r + L - 1 >= i) {
-                    if (q + L * r >= i) lq[(BOFF + L * r) * FPW] = Bm[r][i];   // slot c = q + L r holds U[i][c]
+                    if (q + L * r >= i) at(dq, BOFF + L * r) = Bm[r][i];   // slot c = q + L r holds U[i][c]
                 }
             wave_lds_fence();
             {
-                const T rd = T(1) / lf[(BOFF + i) * FPW];
+                const T rd = T(1) / lp[PX(BOFF + i)];
                 T urow[NS];
     #pragma unroll
-                for (int c = i + 1; c < NS; c++) urow[c] = lf[(BOFF + c) * FPW];
+                for (int c = i + 1; c < NS; c++) urow[c] = lp[PX(BOFF + c)];
     #pragma unroll
                 for (int r = 0; r < RP; r++) {
                     T s = Rm[r][i];
@@ -185,12 +201,12 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         // |I|_inf (mat64's condition test, kb_device.h inverse_lu): the own row sums, gathered, the same running maximum in every lane
         auto gathered_max = [&](const T (&rs)[RP]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = rs[r];
+            for (int r = 0; r < RP; r++) at(dq, BOFF + L * r) = rs[r];
             wave_lds_fence();
             T m = T(0);
 #pragma unroll
             for (int i = 0; i < NS; i++) {
-                const T v = lf[(BOFF + i) * FPW];
+                const T v = lp[PX(BOFF + i)];
                 if (i < rn) m = (v > m || v != v) ? v : m;
             }
             wave_lds_fence();
@@ -211,13 +227,13 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) lq[(j * NS + L * r) * FPW] = Er[r][j];
+            for (int j = 0; j < NS; j++) at(dq, j * NS + L * r) = Er[r][j];
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < RP; r++) {
             T sacc = T(0);
 #pragma unroll
-            for (int c = 0; c < NS; c++) sacc += fabs(lqn[((L * r) * NS + c) * FPW]);
+            for (int c = 0; c < NS; c++) sacc += fabs(lqn[PX((L * r) * NS + c)]);
             rs[r] = sacc;
         }
         const T inorm = gathered_max(rs);
@@ -233,16 +249,16 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 #pragma unroll
             for (int j = 0; j < NS; j++) {
                 T pij;
-                if (j >= L * r + L - 1) pij = lqn[((L * r) * NS + j) * FPW];
-                else if (j < L * r) pij = lq[(j * NS + L * r) * FPW];
-                else pij = *(j >= q + L * r ? lqn + ((L * r) * NS + j) * FPW : lq + (j * NS + L * r) * FPW);
+                if (j >= L * r + L - 1) pij = lqn[PX((L * r) * NS + j)];
+                else if (j < L * r) pij = at(dq, j * NS + L * r);
+                else pij = *(j >= q + L * r ? &lqn[PX((L * r) * NS + j)] : &at(dq, j * NS + L * r));
                 sacc += pij * ivp[j];
             }
             rs[r] = bad ? T(0) : sacc;   // (zeros: information.go:286-288)
         }
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = rs[r];
+        for (int r = 0; r < RP; r++) at(dq, BOFF + L * r) = rs[r];
         wave_lds_fence();
         // yhat: lane q forms the measurement rows c = q + L r2 (row c of H, and of chol(R) with AWGN) and stores them
         [[maybe_unused]] T z1[NM];
@@ -259,7 +275,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
             const unsigned urow = real ? um + (unsigned)((q + cbase) * rn * KB_TILE) : um;
             T sacc = T(0);
 #pragma unroll
-            for (int l = 0; l < NS; l++) sacc += ((cbase < rp && l < rn) ? ldg(mo, a.L.mo_H, l, urow) : T(0)) * lf[(BOFF + l) * FPW];
+            for (int l = 0; l < NS; l++) sacc += ((cbase < rp && l < rn) ? ldg(mo, a.L.mo_H, l, urow) : T(0)) * lp[PX(BOFF + l)];
             if (awgn) {
                 const unsigned utr = real ? um + (unsigned)(((q + cbase) * (q + cbase + 1) / 2) * KB_TILE) : um;
                 T v = T(0);
@@ -309,7 +325,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 #pragma unroll
         for (int r = 0; r < RP; r++)
 #pragma unroll
-            for (int l = 0; l < NS; l++) lqn[((L * r) * NS + l) * FPW] = Fr[r][l];   // slot i_r n + l
+            for (int l = 0; l < NS; l++) lqn[PX((L * r) * NS + l)] = Fr[r][l];   // slot i_r n + l
     }
     wave_lds_fence();
     KB_SB();
@@ -324,7 +340,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         T row[2][NS];
         auto fetch = [&](int l, int b) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NS; j++) row[b][j] = lf[(l * NS + j) * FPW];
+            for (int j = 0; j < NS; j++) row[b][j] = lp[PX(l * NS + j)];
         };
         fetch(0, 0);
 #pragma unroll
@@ -343,7 +359,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         T s = T(0);
 #pragma unroll
         for (int l = 0; l < NS; l++) {
-            Fc[r][l] = lq[(l * NS + L * r) * FPW];   // F^-1[l][i_r]
+            Fc[r][l] = at(dq, l * NS + L * r);   // F^-1[l][i_r]
             s += Fc[r][l] * iv[l];
         }
         im[r] = s;   // (F^-T i)[i_r]
@@ -355,7 +371,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 #pragma unroll
     for (int r = 0; r < RP; r++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) lqn[((L * r) * NS + j) * FPW] = T1[r][j];
+        for (int j = 0; j < NS; j++) lqn[PX((L * r) * NS + j)] = T1[r][j];
     wave_lds_fence();
     KB_SB();
     T Mr[RP][NS];   // M[i_r][.]: first as M, then (the right-hand side of the solve) turning into -Z[i_r][.]
@@ -367,7 +383,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         T row[2][NS];
         auto fetch = [&](int l, int b) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NS; j++) row[b][j] = lf[(l * NS + j) * FPW];
+            for (int j = 0; j < NS; j++) row[b][j] = lp[PX(l * NS + j)];
         };
         fetch(0, 0);
 #pragma unroll
@@ -395,7 +411,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 #pragma unroll
     for (int r = 0; r < RP; r++)
 #pragma unroll
-        for (int j = 0; j < NS; j++) lqn[((L * r) * NS + j) * FPW] = Mr[r][j];
+        for (int j = 0; j < NS; j++) lqn[PX((L * r) * NS + j)] = Mr[r][j];
     wave_lds_fence();
     KB_SB();
     bool ignored = false;   // (the reference ignores this inverse's error, :171)
@@ -419,20 +435,20 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
             for (int r = 0; r < RP; r++) {
                 T s = T(0);
 #pragma unroll
-                for (int j = 0; j < NS; j++) s += lqn[((L * r) * NS + j) * FPW] * gu[j];
+                for (int j = 0; j < NS; j++) s += lqn[PX((L * r) * NS + j)] * gu[j];
                 im[r] = im[r] + s;
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < RP; r++) lq[(BOFF + L * r) * FPW] = im[r];
+    for (int r = 0; r < RP; r++) at(dq, BOFF + L * r) = im[r];
     wave_lds_fence();
     T imn[RP];
 #pragma unroll
     for (int r = 0; r < RP; r++) {
         T s = T(0);
 #pragma unroll
-        for (int j = 0; j < NS; j++) s += (((j % L == q && j / L == r) ? T(1) : T(0)) + T(-1) * Mr[r][j]) * lf[(BOFF + j) * FPW];
+        for (int j = 0; j < NS; j++) s += (((j % L == q && j / L == r) ? T(1) : T(0)) + T(-1) * Mr[r][j]) * lp[PX(BOFF + j)];
         imn[r] = s;
         pin(imn[r]);
     }
@@ -441,7 +457,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
         T row[2][NS];
         auto fetch = [&](int j, int b) __attribute__((always_inline)) {
 #pragma unroll
-            for (int l = 0; l < NS; l++) row[b][l] = lf[(j * NS + l) * FPW];
+            for (int l = 0; l < NS; l++) row[b][l] = lp[PX(j * NS + l)];
         };
         fetch(0, 0);
 #pragma unroll
@@ -454,7 +470,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
                     T s = T(0);
 #pragma unroll
                     for (int l = 0; l < NS; l++) s += (T(-1) * Mr[r][l]) * row[j & 1][l];
-                    Im[r][j] = lqn[((L * r) * NS + j) * FPW] + s;   // M[i_r][j] + (Z M^T)[i_r][j]
+                    Im[r][j] = lqn[PX((L * r) * NS + j)] + s;   // M[i_r][j] + (Z M^T)[i_r][j]
                     pin(Im[r][j]);
                 }
             KB_SB();
@@ -491,7 +507,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 #pragma unroll
     for (int c = 0; c < NM; c++)
 #pragma unroll
-        for (int r = 0; r < RP; r++) lq[(c * NS + L * r) * FPW] = Hp[c][r];   // H[c][i_r] at slot c n + i_r
+        for (int r = 0; r < RP; r++) at(dq, c * NS + L * r) = Hp[c][r];   // H[c][i_r] at slot c n + i_r
     wave_lds_fence();
     KB_SB();
     T HTR[RP][NM], ip[RP];
@@ -514,7 +530,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
     for (int j = 0; j < NS; j++) {
         T hcol[NM];
 #pragma unroll
-        for (int l = 0; l < NM; l++) hcol[l] = lf[(l * NS + j) * FPW];
+        for (int l = 0; l < NM; l++) hcol[l] = lp[PX(l * NS + j)];
 #pragma unroll
         for (int r = 0; r < RP; r++)
             if (L * r <= j) {
@@ -561,7 +577,7 @@ __device__ __forceinline__ void information_split_part(const StepArgs &a, const 
 
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT = false>
 __global__ void __launch_bounds__(64, 2) information_split_kernel(const StepArgs a) {
-    __shared__ T lds[infsplit_lds_elems<NS>() * (64 / L)];
+    __shared__ __attribute__((aligned(16))) T lds[(infsplit_lds_elems<NS>() + 1) / 2 * 2 * (64 / L)];   // (whole pairs)
     information_split_part<T, NS, NM, NC, L, GEN, FULLT>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);   // (kb_vanilla_split.h: XCD-aware for L = 8)
 }
 #undef KB_SB
