@@ -13,7 +13,7 @@ for tag in ('a','b'):
             if r['Counter_Name']=='SQ_BUSY_CYCLES': cnt[k]+=1
     with open('gpurun_out/ldsprobe/%s_summary.txt'%tag,'w') as out:
         for k,v in agg.items():
-            if "split" not in k and "srif" not in k and "vanilla_reg" not in k: continue
+            if not any(t in k for t in ("split", "srif", "vanilla_reg", "mc_", "chisq", "shared")): continue
             n=max(cnt[k],1)
             out.write(k+' | launches %d | '%n+' '.join('%s=%.4g'%(c,x/n) for c,x in sorted(v.items()))+'\n')
 PY
