@@ -225,8 +225,8 @@ def _leg_parity(ga, k, synth, leg):
                                            "covariance": synth.rel_frobenius(b.get(k.COVAR), b1.get(k.COVAR))},
                     "ok": bool(ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and not b.status().any() and b.step() == T)})
         return out
-    if leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "vanilla_10x4"):
-        nn, pp = (12, 6) if leg in ("vanilla_12x6", "squareroot_12x6") else ((10, 4) if leg == "vanilla_10x4" else (N_STATE, N_MEAS))
+    if leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "vanilla_10x4", "vanilla_16x8"):
+        nn, pp = (12, 6) if leg in ("vanilla_12x6", "squareroot_12x6") else ((10, 4) if leg == "vanilla_10x4" else ((16, 8) if leg == "vanilla_16x8" else (N_STATE, N_MEAS)))
         d = synth.linear_batch(N, nn, pp, T, seed=synth.SEED + 77)
         if leg == "shared_model":
             for f in ("F", "H", "Q", "R"):
@@ -234,7 +234,7 @@ def _leg_parity(ga, k, synth, leg):
             b = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"][0], None, d["H"][0], d["Q"][0], d["R"][0], nfilters=N)
             okind = orc.VANILLA
         else:
-            kind, okind = (k.VANILLA, orc.VANILLA) if leg in ("vanilla_12x6", "vanilla_10x4") else (k.SQUAREROOT, orc.SQUAREROOT)
+            kind, okind = (k.VANILLA, orc.VANILLA) if leg in ("vanilla_12x6", "vanilla_10x4", "vanilla_16x8") else (k.SQUAREROOT, orc.SQUAREROOT)
             b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"])
         y = torch.from_numpy(np.ascontiguousarray(d["y"].transpose(0, 2, 1))).cuda()
         for t in range(T):
@@ -831,6 +831,19 @@ def main():
                                                              *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 12, 4, 2, 4, true, false, false")),
                                  "filters_with_error_status": pbad}
         del pb, yq
+        # ... and the corner of the envelope: Vanilla 16 / 8, one filter over EIGHT lanes, the 8 x 8 inverse of S formed once per filter by its
+        # lanes (round 5: kb_vanilla_split.h dist_inverse); its counter bytes include H's own columns read a second time
+        dq = synth.linear_batch(M, 16, 8, 1, seed=synth.SEED + 7000 + rank)
+        yq = torch.from_numpy(np.ascontiguousarray(dq["y"][0].T)).to(dev)
+        cb = ga.FilterBatch.new_ldkf(k.VANILLA, dq["x0"], dq["P0"], dq["F"], None, dq["H"], dq["Q"], dq["R"], device=local_rank)
+        c_s, cms, cbad = timed_leg(cb, lambda: cb.update_dev(yq.data_ptr(), M), K6)
+        extra["vanilla_16x8"] = {"config": "%d Vanilla 16/8 fp64 filters per GPU, per-filter models (vanilla_split_kernel<double, 16, 8, 0, 8>: one filter per eight lanes)" % M,
+                                 "filters_total": world * M, "steps": K6, "value": world * M * K6 / c_s,
+                                 "unit": "filter-update steps/s (whole job)", "kernel_ms": cms,
+                                 "roofline": rl.hbm_roofline(cms, M, rl.algorithmic_bytes("vanilla", 16, 8), rl.moved_bytes("vanilla", 16, 8),
+                                                             *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 16, 8, 0, 8, false, false, false")),
+                                 "filters_with_error_status": cbad}
+        del cb, yq
     if args.srif_filters > 0:
         M = args.srif_filters
         sn, sp = 12, 6
@@ -917,7 +930,7 @@ def main():
                                 "note": "%d MB of host measurements per call: H2D copy + pack + step + synchronise" % (N * p * 8 // 1000000)}
         if not args.no_parity:
             out["parity"] = _parity(ga, k, synth)
-            for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6", "vanilla_10x4", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
+            for leg in ("squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6", "vanilla_10x4", "vanilla_16x8", "hybrid_ekf", "srif_fp32"):   # every leg of `extra` proves itself (oracle = checker, untimed)
                 if leg in extra:
                     extra[leg]["parity"] = _leg_parity(ga, k, synth, leg)
             if fused:   # the time-fused launch is a different kernel from the headline's: its own gate
