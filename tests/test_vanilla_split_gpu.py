@@ -184,6 +184,22 @@ def test_split_distributed_inverse_row_exchanges_and_a_late_zero_pivot(n, p):
         assert within(synth.rel_frobenius(est.gain()[good], np.array([fs[i].gain() for i in good])), TOL), t
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_split_p8_structured_innovation_covariances_vs_oracle(case):
+    """scripts/fuzz_split_p8.py, the first twelve cases: measurement rows that are zero / duplicated / scaled over eight decades, R with equal
+    diagonal entries (ties in the pivot search), over sixteen decades, dense, or absent -- every filter the oracle fails (singular or
+    ill-conditioned S) must carry a status bit and no other, the rest agree with it (the bound follows the conditioning: achieved values in
+    the summary)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_split_p8", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_split_p8.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    r = mod.run_case(case)
+    assert r["status_mismatches"] == 0, r
+    assert r["filters_compared"] > 0
+    assert within(r["worst_rel_error"], 1e-7, "%s / %s" % (r["R"], r["H"])), r
+
+
 def test_split_batches_keep_the_other_kernels_bits_for_small_shapes():
     """Shapes the one-filter-per-lane kernels cover stay on them: an 8 / 4 batch run with KB_FLAG_STATEMENT_KERNELS and without agree
     to rounding, and a 12 / 6 batch equals the statement kernel to 1e-12 (different summation order, same arithmetic)."""
