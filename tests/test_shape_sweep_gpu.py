@@ -116,6 +116,48 @@ def test_every_shape_hybrid(ekf):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("n,p", [(12, 8), (16, 8), (14, 7), (9, 8)])
+@pytest.mark.parametrize("ekf", [False, True])
+def test_hybrid_p8_row_exchanges_and_singular_innovation(n, p, ekf):
+    """HybridKF at 7, 8 measurements beyond 8 states (the Vanilla split kernel's HYB mode: S^-1 once per filter by its lanes).  R = D C D with row
+    scales over two decades in a different order per filter (the p x p inverse exchanges rows, differently in the lane groups of a wave); a third
+    of the filters have a noise-free measurement 3 whose row of Htilde is zero at the last step: H P H^T + R is exactly singular -- hybrid.go:149-152 returns the
+    error before kf.step++, the others carry on."""
+    rng = np.random.default_rng(40 * n + p + int(ekf))
+    M = 96
+    x0 = rng.standard_normal((M, n))
+    P0 = np.zeros((M, n, n)); P0[:, np.arange(n), np.arange(n)] = rng.uniform(1.0, 10.0, size=(M, n))
+    sc = 10.0 ** (np.array([rng.permutation(p) for _ in range(M)]) / 4.0)
+    C = 0.9 * np.ones((p, p)) + 0.1 * np.eye(p)
+    R = 0.3 * sc[:, :, None] * C[None] * sc[:, None, :]
+    bad = sorted(rng.choice(M, size=M // 3, replace=False).tolist())
+    R[bad, 3, :] = 0.0; R[bad, :, 3] = 0.0   # (HybridKF takes its noise at construction, hybrid.go:21-47: measurement 3 of these filters is noise-free)
+    b = ga.FilterBatch(k.HYBRID, n, p, 0, M, flags=k.FLAG_FULL_ESTIMATE)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+    fs = [orc.Filter.hybrid(x0[i], P0[i], None, R[i], p) for i in range(M)]
+    if ekf:
+        b.enable_ekf()
+        for f in fs:
+            f.enable_ekf()
+    for t in range(3):
+        Phi = np.eye(n) + 1e-2 * rng.standard_normal((M, n, n))
+        Ht = rng.standard_normal((M, p, n))
+        real = rng.standard_normal((M, p)); comp = real + 1e-2 * rng.standard_normal((M, p))
+        if t == 2:
+            Ht[bad, 3] = 0.0
+        b.prepare(Phi, Ht)
+        est = b.update_nl(real, comp)
+        for i, f in enumerate(fs):
+            f.prepare(Phi[i], Ht[i])
+            assert f.update_nl(real[i], comp[i]) == (orc.ERR_SINGULAR if (t == 2 and i in bad) else orc.OK)
+        assert sorted(np.nonzero(b.status())[0].tolist()) == (bad if t == 2 else [])
+        good = [i for i in range(M) if not (t == 2 and i in bad)]
+        assert within(synth.rel_frobenius(b.get(k.STATE), np.array([f.state() for f in fs])), 1e-9 if p <= n else 1e-7, "hybrid %d/%d state" % (n, p)), t
+        assert synth.rel_frobenius(b.get(k.COVAR), np.array([f.covariance() for f in fs])) <= 1e-9, t
+        assert synth.rel_frobenius(est.gain()[good], np.array([fs[i].gain() for i in good])) <= 1e-9, t
+    assert [b.filter_step(i) for i in (bad[0], good[0])] == [2, 3]
+
+
 @pytest.mark.parametrize("dtype,tol", [(k.F64, 1e-9), (k.F32, 2e-5)])
 def test_every_shape_srif(dtype, tol):
     bad = []
