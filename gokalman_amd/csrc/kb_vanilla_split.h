@@ -15,7 +15,10 @@
 //                  19.2 KB per wave, eight waves per CU = two per SIMD.
 //   sums over rows S = H (P- H^T) + R and H x- run over ALL rows: each lane sums its own rows and the L partial sums are added
 //                  with v_permlane32_swap / v_permlane16_swap (gfx950), identically in every lane; (H P- H^T + R)^-1 (p x p) is
-//                  then formed redundantly by the L lanes.
+//                  then formed redundantly by the L lanes up to p = 6, and ONCE per filter by its lanes at p = 7, 8 (dist_inverse
+//                  below: Gauss-Jordan by columns, the pivot column handed over through LDS).
+//   LDS slots      the regions read as contiguous runs (rows of F, columns of H, rows of P- H^T and K) hold TWO elements per lane
+//                  (16 bytes): ds_read_b128 at twice the array rate of the ds_read2_b64 pairs the compiler forms from 8-byte slots.
 //
 // Arithmetic: the reference's statements in the reference's order, with these rounding-level differences: sums over all rows are
 // added as L partial sums; S is the mirrored upper triangle; P- enters P- H^T with the lane's own computed entries right of
@@ -1434,12 +1437,8 @@ __device__ __forceinline__ int64_t split_part_of_block(unsigned b, unsigned nblo
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
 template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, bool NOISET = false, bool HYB = false>
-#ifdef KB_SPLIT_HYB1
-#define KB_HYB1_ HYB
-#else
-#define KB_HYB1_ false
-#endif
-__global__ void __launch_bounds__(64, (((RT || (NM > 6 && (KB_HYB1_ || !split_hsplit<NM, L>()))) && L == 4) ? 1 : ((int)sizeof(T) * split_lds_total<T, NS, NM, L, RT, FULLT>() * 8 <= 160 * 1024 ? 2 : 1))) vanilla_split_kernel(const StepArgs a) {
+// (Hybrid at 12 / 8 on ONE wave per SIMD without scratch was measured against two waves with 132 B: 1.65 against 1.59 ms per 1M-filter step)
+__global__ void __launch_bounds__(64, (((RT || (NM > 6 && !split_hsplit<NM, L>())) && L == 4) ? 1 : ((int)sizeof(T) * split_lds_total<T, NS, NM, L, RT, FULLT>() * 8 <= 160 * 1024 ? 2 : 1))) vanilla_split_kernel(const StepArgs a) {
     __shared__ __attribute__((aligned(16))) T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];
     if constexpr (PERSIST) {
         const int64_t nparts = a.ntiles * L;
