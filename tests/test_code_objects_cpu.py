@@ -68,3 +68,40 @@ def test_every_translation_unit_of_a_flagged_family_has_its_flags():
     assert flagged and all(s in kb_build.EXTRA for s in flagged), [s for s in flagged if s not in kb_build.EXTRA]
     stale = [s for s in kb_build.EXTRA if s not in srcs]
     assert not stale, "EXTRA names files that no longer exist: %s" % stale
+
+
+def _disassemble(obj_name):
+    """{mangled kernel symbol: {mnemonic: count}} of one translation unit's gfx950 code object."""
+    import collections
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "gokalman_amd", "csrc", "_obj", obj_name)
+    out, cur = {}, None
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--unbundle", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
+        txt = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = out.setdefault(m.group(1), collections.Counter())
+        elif cur is not None and line.startswith("\t"):
+            cur[line.split()[0]] += 1
+    return out
+
+
+def test_paired_lds_slots_are_read_with_16_byte_loads():
+    """Round 5: the split kernels keep two consecutive elements per lane in LDS so that contiguous runs are read with ds_read_b128 -- the LDS array
+    serves the ds_read2_b64 pairs the compiler forms from 8-byte slots at half the bytes per clock (profiles/NOTES.md).  The property lives in index
+    expressions and an alignment attribute: losing either silently brings the pairs back.  Instruction counts of the exact 12/6 kernels."""
+    want = {"kb_vanilla_split12.hip.o": ("_ZN2kb20vanilla_split_kernelIdLi12ELi6ELi0ELi4ELb0ELb0ELb0ELb0ELb0ELb0ELb0EEEvNS_8StepArgsE", 180, 120),
+            "kb_squareroot_split12.hip.o": ("_ZN2kb23squareroot_split_kernelIdLi12ELi6ELi0ELi4ELb0ELb0ELb0ELb0EEEvNS_8StepArgsE", 200, 60),
+            "kb_information_split12.hip.o": ("_ZN2kb24information_split_kernelIdLi12ELi6ELi0ELi4ELb0ELb0EEEvNS_8StepArgsE", 150, 120)}
+    for obj, (sym, min_b128, max_read2) in want.items():
+        ks = _disassemble(obj)
+        assert sym in ks, (obj, [k for k in ks if "split_kernel" in k][:4])
+        c = ks[sym]
+        assert c["ds_read_b128"] >= min_b128 and c["ds_read2_b64"] <= max_read2, (obj, c["ds_read_b128"], c["ds_read2_b64"], c["ds_read_b64"])
