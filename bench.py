@@ -15,7 +15,9 @@ With --gpus N > 1 and no WORLD_SIZE in the environment this process starts N ran
 anything here touches the GPU) and forwards their exit code; under torchrun it is one rank.
 It never reports a 1-rank number for an N-rank request: fewer visible GPUs than ranks is an error.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement): the compact headline object of gokalman_amd/benchline.py
+(<= 8 KB: contract keys, `roofline`, `cpu_baseline`, `parity`, `ranks`, and {value, kernel_ms, frac, parity_ok} per leg under
+`legs`).  The FULL document is written to --full-out (default gpurun_out/bench_full.json) and holds these objects:
   roofline     -- dominant kernel (vanilla_reg_kernel<f64,6,3>) against the HBM roof.  `frac` is
                   PHYSICAL: bytes the launch moves (the packed working set of 1104 B per filter, which
                   the rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE counters of the committed profile confirm)
@@ -83,6 +85,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--init-dist", action="store_true",
                     help="initialise torch.distributed and run every collective even for ONE rank (exercises the RCCL code path on a single GPU)")
+    ap.add_argument("--full-out", default=os.path.join("gpurun_out", "bench_full.json"),
+                    help="where rank 0 writes the FULL result document (every leg with its roofline, provenance, parity details); the "
+                    "final stdout line is the compact headline object of gokalman_amd/benchline.py (<= 8 KB), '' = do not write")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, one GPU per rank) or gloo (testing the N>1 path with several ranks on one GPU)")
     return ap.parse_args(argv)
@@ -470,7 +475,7 @@ def main():
             fused["roofline"] = rl.valu_roofline(fms, (N + 63) // 64, vk["vanilla_fused"]["valu_insts_per_wave_per_step"] * T, vs)
         elif vs:
             fused["roofline"] = {"bound": "valu_issue", "frac": None, "source": vs}
-        # the same loop with the Noise drawn inside the launch (AWGN, noise.go:109-164; round 5): bit-identical to T single steps
+        # the same loop with the Noise drawn inside the launch (AWGN, noise.go:109-164; round 5): bit-identical to T single steps while no filter fails
         if rank == 0:
             ba = ga.FilterBatch.new_ldkf(k.VANILLA, d["x0"], d["P0"], d["F"], None, d["H"], d["Q"], d["R"], device=local_rank,
                                          noise=k.NOISE_AWGN, seed=2016)
@@ -487,6 +492,8 @@ def main():
             ams = a0.elapsed_time(a1) / 3
             fused["awgn"] = {"steps_per_launch": T, "ms_per_launch": ams, "value": N * T / (ams * 1e-3), "errors": int(np.count_nonzero(ba.status())),
                              "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev, AWGN drawn in the kernel)"}
+            if "vanilla_fused_awgn" in vk:   # its own instantiation, its own VALU count (summarise_round.py selects by the full argument list)
+                fused["awgn"]["roofline"] = rl.valu_roofline(ams, (N + 63) // 64, vk["vanilla_fused_awgn"]["valu_insts_per_wave_per_step"] * T, vs)
             del ba
         del yy
     torch.cuda.empty_cache()   # (the headline batch stays: warm_clocks() runs it before every later timed region)
@@ -743,7 +750,8 @@ def main():
                                                            *rl.load_traffic(ROOT, "squareroot_reg_kernel<double, 6, 3, 0, false")),
                                "filters_with_error_status": qbad}
         if args.fused_steps > 0 and rank == 0:
-            # config C with the caller loop inside one launch (round 5): x, S and the model resident over T steps; bit-identical to T launches
+            # config C with the caller loop inside one launch (round 5): x, S and the model resident over T steps; NOT bit-identical to T launches
+            # (FASTDIV Newton reciprocals, held to 1e-12 of them and to 1e-9 of the oracle: `parity` below)
             T = args.fused_steps
             yT = yq.unsqueeze(0).repeat(T, 1, 1).contiguous()   # [T][p][M] (the same measurement every step: throughput only)
             sq.update_steps_dev(yT.data_ptr(), M, T)
@@ -758,7 +766,8 @@ def main():
             sq.synchronize()
             fq = f0.elapsed_time(f1) / 3
             extra["squareroot"]["fused"] = {"steps_per_launch": T, "ms_per_launch": fq, "value": M * T / (fq * 1e-3),
-                                            "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev)", "filters_with_error_status": int(np.count_nonzero(sq.status()))}
+                                            "unit": "filter-update steps/s (1 GPU, kb_update_steps_dev)", "filters_with_error_status": int(np.count_nonzero(sq.status())),
+                                            "config": "the SAME measurement repeated every step on a converged batch: throughput only (steady-state best case)"}
             del yT
         del sq, yq
     if args.shared_filters > 0:
@@ -939,7 +948,20 @@ def main():
                 extra["squareroot"]["fused"]["parity"] = _leg_parity(ga, k, synth, "squareroot_fused")
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
             out["cpu_baseline"] = _cpu_baseline(d)
-        print(json.dumps(out), flush=True)
+        # the full document goes to a side file; the ONE stdout line is its compact headline (round 5's 22.8 KB line was not parsed)
+        from gokalman_amd import benchline
+        full_path = None
+        if args.full_out:
+            full_path = args.full_out if os.path.isabs(args.full_out) else os.path.join(ROOT, args.full_out)
+            try:
+                os.makedirs(os.path.dirname(full_path), exist_ok=True)
+                with open(full_path + ".tmp", "w") as fh:
+                    json.dump(out, fh)
+                os.replace(full_path + ".tmp", full_path)
+            except OSError as exc:   # a read-only tree must not cost the bench line
+                print("bench: could not write %s: %s" % (full_path, exc), file=sys.stderr, flush=True)
+                full_path = None
+        print(benchline.dumps(out, args.full_out if full_path else None), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,12 +12,12 @@ mkdir -p $OUT
 python3 -c "import sys; sys.path.insert(0, '$ROOT'); from gokalman_amd import roofline as rl; print(rl.kernel_source_hash('$ROOT'))" > $OUT/source_hash.txt
 export TMPDIR=/tmp
 cd $ROOT
-B="--steps 40 --warmup 5 --repeat 1 --no-cpu-baseline --no-parity --no-host-path --ooc-filters 0 --mc-runs 0 --chisq-runs 0 --hybrid-filters 0 --sqrt-filters 0 --srif-filters 0 --shared-filters 0 --split-filters 0"
+B="--full-out= --steps 40 --warmup 5 --repeat 1 --no-cpu-baseline --no-parity --no-host-path --ooc-filters 0 --mc-runs 0 --chisq-runs 0 --hybrid-filters 0 --sqrt-filters 0 --srif-filters 0 --shared-filters 0 --split-filters 0"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"
 # ONLY=<prefix> repeats the passes whose name starts with it (e.g. ONLY=kinds after a fix to scripts/bench_kinds.py), keeping the others
 run() { local name=$1; shift; if [ -n "${ONLY:-}" ] && [[ "$name" != ${ONLY}* ]]; then return; fi; echo "== $name"; "$@" > $OUT/$name.out 2> $OUT/$name.log; }
-run bench_plain   python3 bench.py --steps 2000 --warmup 100
-run bench_stats   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 bench.py $B
+run bench_plain   python3 bench.py --steps 2000 --warmup 100 --full-out $OUT/bench_plain.full.json
+run bench_stats   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 bench.py $B --full-out $OUT/bench_stats.full.json
 run bench_fetch   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python3 bench.py $B --fused-steps 0
 run bench_write   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_write -- python3 bench.py $B --fused-steps 0
 run bench_sq      rocprofv3 --pmc $SQ --output-format csv -d $OUT/bench_sq -- python3 bench.py $B

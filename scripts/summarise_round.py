@@ -82,6 +82,9 @@ def main():
             shutil.copy(p, os.path.join(DST, {"bench_plain": "bench.json", "bench_stats": "bench_under_rocprof.json", "kinds_plain": "bench_kinds.jsonl",
                                              "chisq_plain": "bench_chisq.json", "diag_stream": "diag_stream.txt", "diag_lanepair": "diag_lanepair.txt",
                                              "diag_lanequad": "diag_lanequad.txt", "diag_launch_latency": "diag_launch_latency.txt", "latency_n1": "latency_n1.txt"}[name]))
+    for name, dst in (("bench_plain.full.json", "bench_full.json"), ("bench_stats.full.json", "bench_full_under_rocprof.json")):
+        if os.path.exists(os.path.join(SRC, name)):   # the full documents behind the compact stdout lines (gokalman_amd/benchline.py)
+            shutil.copy(os.path.join(SRC, name), os.path.join(DST, dst))
     md = ["# rocprofv3 summary %s (head %s)\n" % (tag, head),
           "Collected by `scripts/profile_round.sh %s` on one MI355X through gpurun; every `--pmc` pass is a separate run.\n" % tag]
     # ---- kernel stats
@@ -142,14 +145,23 @@ def main():
                 valu[kn] = {"waves": la["SQ_WAVES"], "valu_insts_per_wave": la["SQ_INSTS_VALU"] / la["SQ_WAVES"], "dispatch": "last (the timed launch)"}
     named = {}
     for kn, v in valu.items():
-        if "vanilla_reg_kernel<double, 6, 3, 0, false, false, true" in kn:
-            T = 16   # bench.py's --fused-steps of that round (r03b and earlier: 16)
-            try:
-                bj = [json.loads(l) for l in open(os.path.join(DST, "bench_under_rocprof.json")) if l.startswith("{")][-1]
-                T = int(bj["fused"]["steps_per_launch"])
-            except Exception:
-                pass
-            named["vanilla_fused"] = dict(v, kernel=kn, steps_per_launch=T, valu_insts_per_wave_per_step=v["valu_insts_per_wave"] / float(T))
+        # the time-fused kernels by their FULL template argument list <T, NS, NM, NC, FULL, PREDICT, FUSED, PAD, NOISE, SHARED>: the
+        # prefix "...0, false, false, true" matches the Noiseless AND the AWGN instantiation since round 5, and the last one won
+        # (r05g priced the Noiseless leg with the AWGN kernel's 290 019 VALU per wave: frac 1.43)
+        for name, full in (("vanilla_fused", "vanilla_reg_kernel<double, 6, 3, 0, false, false, true, false, false, false>"),
+                           ("vanilla_fused_awgn", "vanilla_reg_kernel<double, 6, 3, 0, false, false, true, false, true, false>")):
+            if full in kn:
+                T = 100   # bench.py's --fused-steps default since round 4
+                try:
+                    full_doc = os.path.join(DST, "bench_full_under_rocprof.json")
+                    if os.path.exists(full_doc):
+                        bj = json.load(open(full_doc))
+                    else:
+                        bj = [json.loads(l) for l in open(os.path.join(DST, "bench_under_rocprof.json")) if l.startswith("{")][-1]
+                    T = int(bj["fused"]["steps_per_launch"])
+                except Exception:
+                    pass
+                named[name] = dict(v, kernel=kn, steps_per_launch=T, valu_insts_per_wave_per_step=v["valu_insts_per_wave"] / float(T))
         if "mc_kernel<double, 4, 2" in kn:
             named["mc"] = dict(v, kernel=kn, steps_per_launch=1086)
         if "chisq_kernel" in kn:

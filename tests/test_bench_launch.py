@@ -20,9 +20,26 @@ def _run(args, timeout=900):
 
 
 def _json_line(stdout):
+    """The ONE stdout line: the compact headline object (gokalman_amd/benchline.py), bounded in size."""
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, stdout
+    assert len(lines[0]) <= 8192, len(lines[0])
     return json.loads(lines[0])
+
+
+def _run_full(args, tmp_path, tag):
+    """Runs bench.py with --full-out into tmp_path; returns (compact line, full document, CompletedProcess)."""
+    full = str(tmp_path / ("bench_full_%s.json" % tag))
+    r = _run(args + ["--full-out", full])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["full"] == full
+    with open(full) as fh:
+        doc = json.load(fh)
+    # the line is the document's headline: same figures, nothing re-measured
+    assert line["value"] == doc["value"] and line["ms_per_step"] == doc["ms_per_step"] and line["n_gpus"] == doc["n_gpus"]
+    assert abs(line["roofline"]["frac"] - doc["roofline"]["frac"]) < 1e-8
+    return line, doc, r
 
 
 def test_more_ranks_than_gpus_is_refused_not_downgraded():
@@ -49,11 +66,10 @@ SMALL = ["--steps", "30", "--warmup", "5", "--filters", "65536", "--fused-steps"
 
 
 @pytest.mark.gpu
-def test_two_ranks_self_launched_over_gloo_on_one_gpu():
-    one = _json_line(_run(["--gpus", "1"] + SMALL).stdout)
-    r = _run(["--gpus", "2", "--dist-backend", "gloo"] + SMALL)
-    assert r.returncode == 0, r.stderr[-2000:]
-    two = _json_line(r.stdout)
+def test_two_ranks_self_launched_over_gloo_on_one_gpu(tmp_path):
+    line1, one, _ = _run_full(["--gpus", "1"] + SMALL, tmp_path, "one")
+    line2, two, _ = _run_full(["--gpus", "2", "--dist-backend", "gloo"] + SMALL, tmp_path, "two")
+    assert line2["ranks"]["launched"] == 2 and line2["legs"]["vanilla_12x6"]["parity_ok"] and line1["parity"]["ok"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["ranks"]["launched"] == 2 and two["ranks"]["rccl_ranks_seen"] == 2
     assert len(two["ranks"]["per_rank_ms_per_step"]) == 2
@@ -97,10 +113,18 @@ def test_two_ranks_self_launched_over_gloo_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_line_roofline_is_physical():
-    out = _json_line(_run(["--steps", "50", "--warmup", "5", "--ooc-filters", "0", "--mc-runs", "0", "--hybrid-filters", "0",
-                           "--srif-filters", "0", "--no-cpu-baseline"]).stdout)
+def test_bench_line_roofline_is_physical(tmp_path):
+    """Default sizes (every fraction in the line is quoted at them); EVERY roofline object of the full document and every leg of
+    the compact line carries 0 < frac <= 1 (task 2: the fused leg said 1.43)."""
+    from gokalman_amd import benchline
+    line, out, _ = _run_full(["--steps", "50", "--warmup", "5", "--ooc-filters", "0", "--mc-total", "0", "--no-cpu-baseline"], tmp_path, "phys")
+    assert benchline.fraction_violations(out) == [] and benchline.fraction_violations(line) == []
     assert 0.0 < out["extra"]["squareroot"]["roofline"]["frac"] <= 1.0   # config C on the default 1M filters
+    assert 0.55 < out["fused"]["roofline"]["frac"] <= 1.0 and out["fused"]["roofline"]["bound"] == "valu_issue"
+    for leg in ("mc", "chisq", "hybrid_ekf", "squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6",
+                "vanilla_10x4", "vanilla_16x8", "srif_fp32"):
+        assert 0.0 < out["extra"][leg]["roofline"]["frac"] <= 1.0, leg
+        assert 0.0 < line["legs"][leg]["frac"] <= 1.0, leg
     roof = out["roofline"]
     assert 0.0 < roof["frac"] <= 1.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
@@ -112,12 +136,10 @@ def test_bench_line_roofline_is_physical():
 
 
 @pytest.mark.gpu
-def test_rccl_collectives_run_on_one_rank():
+def test_rccl_collectives_run_on_one_rank(tmp_path):
     """No multi-GPU box in the test loop: at least the RCCL code path itself (communicator set-up with device_id, device
     tensors in all_gather / all_reduce / barrier, the Monte-Carlo statistics reduction) runs, with one rank."""
-    r = _run(["--gpus", "1", "--init-dist", "--dist-backend", "nccl"] + SMALL)
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = _json_line(r.stdout)
+    _, out, r = _run_full(["--gpus", "1", "--init-dist", "--dist-backend", "nccl"] + SMALL, tmp_path, "rccl")
     assert out["n_gpus"] == 1 and out["ranks"]["backend"] == "nccl" and out["ranks"]["rccl_ranks_seen"] == 1
     assert "RCCL" in out["extra"]["mc"]["collective"]
     assert out["ranks"]["filter_steps_counted"] == 65536 * 30
