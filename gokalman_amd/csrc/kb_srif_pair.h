@@ -359,7 +359,9 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
         // (Batch::srif_leftover) until a drained stream shows a launch in which nobody failed
         const bool left = __any(err != 0 && inb);
         if (lane == 0) {
-            a.srif_dense[2 * tile + half] = left ? 1u : 0u;
+            // every part bit of the word: fp32 at 14 / 16 states runs Predict() (and p = 7, 8) on kb_srif_split.h, which reads ONE BIT PER
+            // PART of this word (a bare 1 left the part of slots 16..31 looking triangular to the next Predict())
+            a.srif_dense[2 * tile + half] = left ? 0xFFFFFFFFu : 0u;
             if (left) __hip_atomic_store(a.srif_dense_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

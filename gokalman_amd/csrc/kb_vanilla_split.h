@@ -511,7 +511,11 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
     auto ldg_if = [&](bool need, const T *ubase, int field, int rt, int c, unsigned off, unsigned off_alt, bool keep = false) {   // need: wave-uniform; keep: the value is read again later (default policy)
         if constexpr (!GEN) return need ? ((L == 8 || keep) ? *(ep(ubase, rt, c) + off) : ldg(ubase, rt, c, off)) : T(0);
         else {
+#ifdef KB_FENCE_POSITIVE_CONTROL   // (the fence's positive control, never in the library: the round-4 kind of bug -- a stand-in that leaves the LAST tile's block)
+            const auto pe_ = ep(ubase, need ? rt : field + a.L.mo_elems - c, c) + (need ? off : off_alt);
+#else
             const auto pe_ = ep(ubase, need ? rt : field - c, c) + (need ? off : off_alt);
+#endif
             const T v = (L == 8 || keep) ? *pe_ : __builtin_nontemporal_load(pe_);
             return need ? v : T(0);
         }

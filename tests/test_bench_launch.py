@@ -67,7 +67,13 @@ SMALL = ["--steps", "30", "--warmup", "5", "--filters", "65536", "--fused-steps"
 
 @pytest.mark.gpu
 def test_two_ranks_self_launched_over_gloo_on_one_gpu(tmp_path):
-    line1, one, _ = _run_full(["--gpus", "1"] + SMALL, tmp_path, "one")
+    # (the one-rank job initialises torch.distributed over RCCL: communicator set-up with device_id, device tensors in all_gather /
+    # all_reduce / barrier, the Monte-Carlo statistics reduction -- no multi-GPU box in the test loop, so at least the RCCL code path
+    # itself runs, with one rank; until round 6 a third bench launch of its own)
+    line1, one, _ = _run_full(["--gpus", "1", "--init-dist", "--dist-backend", "nccl"] + SMALL, tmp_path, "one")
+    assert one["n_gpus"] == 1 and one["ranks"]["backend"] == "nccl" and one["ranks"]["rccl_ranks_seen"] == 1
+    assert "RCCL" in one["extra"]["mc"]["collective"]
+    assert one["ranks"]["filter_steps_counted"] == 65536 * 30
     line2, two, _ = _run_full(["--gpus", "2", "--dist-backend", "gloo"] + SMALL, tmp_path, "two")
     assert line2["ranks"]["launched"] == 2 and line2["legs"]["vanilla_12x6"]["parity_ok"] and line1["parity"]["ok"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
@@ -120,10 +126,20 @@ def test_bench_line_roofline_is_physical(tmp_path):
     line, out, _ = _run_full(["--steps", "50", "--warmup", "5", "--ooc-filters", "0", "--mc-total", "0", "--no-cpu-baseline"], tmp_path, "phys")
     assert benchline.fraction_violations(out) == [] and benchline.fraction_violations(line) == []
     assert 0.0 < out["extra"]["squareroot"]["roofline"]["frac"] <= 1.0   # config C on the default 1M filters
-    assert 0.55 < out["fused"]["roofline"]["frac"] <= 1.0 and out["fused"]["roofline"]["bound"] == "valu_issue"
+    fr = out["fused"]["roofline"]
+    assert fr["bound"] == "valu_issue"
+    if fr["source"]["matches_sources"]:   # the VALU counts of profiles/valu_latest.json were measured on these very kernel sources
+        assert 0.55 < fr["frac"] <= 1.0
+        assert 0.55 < out["fused"]["awgn"]["roofline"]["frac"] <= 1.0
+    else:                                 # ... or no figure at all: never a stale count against a new kernel
+        assert fr["frac"] is None and "roofline" not in out["fused"]["awgn"]
     for leg in ("mc", "chisq", "hybrid_ekf", "squareroot", "shared_model", "vanilla_12x6", "squareroot_12x6", "information_12x6",
                 "vanilla_10x4", "vanilla_16x8", "srif_fp32"):
-        assert 0.0 < out["extra"][leg]["roofline"]["frac"] <= 1.0, leg
+        roof = out["extra"][leg].get("roofline")
+        if roof is None:   # issue-bound legs (mc, chisq) quote a VALU count only while it was measured on these kernel sources
+            assert leg in ("mc", "chisq") and not fr["source"]["matches_sources"], leg
+            continue
+        assert 0.0 < roof["frac"] <= 1.0, leg
         assert 0.0 < line["legs"][leg]["frac"] <= 1.0, leg
     roof = out["roofline"]
     assert 0.0 < roof["frac"] <= 1.0
@@ -133,13 +149,3 @@ def test_bench_line_roofline_is_physical(tmp_path):
     assert roof["bytes_convention"]["moved_bytes_per_filter_step"] == 1104
     assert "traffic_source" in roof
     assert 0.0 < roof["dram_frac_lower_bound"] < roof["frac"] and "Infinity-Cache" in roof["side"]
-
-
-@pytest.mark.gpu
-def test_rccl_collectives_run_on_one_rank(tmp_path):
-    """No multi-GPU box in the test loop: at least the RCCL code path itself (communicator set-up with device_id, device
-    tensors in all_gather / all_reduce / barrier, the Monte-Carlo statistics reduction) runs, with one rank."""
-    _, out, r = _run_full(["--gpus", "1", "--init-dist", "--dist-backend", "nccl"] + SMALL, tmp_path, "rccl")
-    assert out["n_gpus"] == 1 and out["ranks"]["backend"] == "nccl" and out["ranks"]["rccl_ranks_seen"] == 1
-    assert "RCCL" in out["extra"]["mc"]["collective"]
-    assert out["ranks"]["filter_steps_counted"] == 65536 * 30

@@ -11,7 +11,6 @@ import gokalman_amd as ga
 from gokalman_amd import _capi as k
 from oracle import oracle as orc
 from tests import jerkcar as jc
-from tests.achieved import within
 
 pytestmark = pytest.mark.gpu
 PRINT_TOL = 5.1e-7
@@ -34,12 +33,13 @@ def _run(name, kk, full):
         return float(np.linalg.norm(a - r) / den) if den > 0 else float(np.linalg.norm(a))
 
     def row():
-        x, P = b.get(k.STATE, 1, 1)[0], b.get(k.COVAR, 1, 1)[0]
+        xs = b.get(k.STATE)
+        x, P = xs[1], b.get(k.COVAR, 1, 1)[0]
         worst["off"] = max(worst["off"], jc.off_block_max(P, kk))
         worst["x"] = max(worst["x"], rel(x, f.state()))
         worst["P"] = max(worst["P"], rel(P, f.covariance()))
         # the three filters of the batch are the same filter (one model, broadcast)
-        worst["spread"] = max(worst["spread"], float(np.max(np.abs(b.get(k.STATE) - x))))
+        worst["spread"] = max(worst["spread"], float(np.max(np.abs(xs - x))))
         return jc.export_rows_blocks(x, P, kk)
 
     def upd(y, u):
@@ -47,12 +47,18 @@ def _run(name, kk, full):
         assert f.update(y, u) == orc.OK
         if full:
             worst["Pm"] = max(worst["Pm"], rel(est.pred_covariance()[1], f.pred_covariance()))
-            worst["y"] = max(worst["y"], float(np.max(np.abs(est.measurement()[1] - f.measurement()))))
+            # yhat = H x- (+ the innovation): relative to the scale of the products it sums, |H|_F |x|_2 -- the 1e-9 rule of every
+            # other member; relative to |yhat| itself it would measure the cancellation in H x-, not the kernel
+            scale = float(np.linalg.norm(cur["H"]) * np.linalg.norm(f.state()))
+            worst["y"] = max(worst["y"], float(np.linalg.norm(est.measurement()[1] - f.measurement())) / max(scale, 1e-300))
             if not info:   # InformationEstimate has no gain
                 worst["K"] = max(worst["K"], rel(est.gain()[1], f.gain()))
 
+    cur = {"H": np.asarray(H0, dtype=np.float64)}
+
     def set_h(H):
         b.set_measurement_matrix(H); f.set_measurement_matrix(H)
+        cur["H"] = np.asarray(H, dtype=np.float64)
 
     def set_noise(Q, R):
         b.set_noise(Q, R); f.set_noise(Q, R)
@@ -72,7 +78,7 @@ def test_embedded_jerkcar_on_the_split_kernels_equals_reference_csv(name, kk, fu
     exp = jc.load_expected(name)
     assert got.shape == (2001, kk, 12)
     err = max(float(np.max(np.abs(got[:, blk] - exp))) for blk in range(kk))
-    print("embedded x%d %s%s: max |gpu - csv| %.3e; vs oracle (worst step of 2000, rel-Frobenius) x %.2e P %.2e P- %.2e K %.2e yhat(abs) %.2e; "
+    print("embedded x%d %s%s: max |gpu - csv| %.3e; vs oracle (worst step of 2000, rel-Frobenius) x %.2e P %.2e P- %.2e K %.2e yhat(rel |H||x|) %.2e; "
           "off-block |P| %.2e; spread over the batch %.1e"
           % (kk, name, " FULL" if full else "", err, worst["x"], worst["P"], worst["Pm"], worst["K"], worst["y"], worst["off"], worst["spread"]))
     assert err <= PRINT_TOL
@@ -88,7 +94,7 @@ def test_embedded_jerkcar_on_the_split_kernels_equals_reference_csv(name, kk, fu
         if full:
             assert worst["Pm"] <= 1e-9 and worst["K"] <= 1e-9
     if full:
-        assert within(worst["y"], 1e-7)
+        assert worst["y"] <= 1e-9
     assert worst["spread"] == 0.0
     # blocks never mix: whatever order the sums run in, the products with the zero blocks are exact zeros
     assert worst["off"] == 0.0

@@ -171,3 +171,34 @@ def test_srif_split_batch_equals_its_chunks_bit_for_bit():
     for t in range(steps):
         f.prepare(Phi[t, N - 1], Ht[t, N - 1]); assert f.update_nl(real[t, N - 1], comp[t, N - 1]) == orc.OK
     assert synth.rel_frobenius(Rm[N - 1:], f.raw_mat()[None]) <= TOL
+
+
+@pytest.mark.parametrize("n,p,bad_filter", [(14, 4, 20), (16, 6, 52), (14, 4, 3)])
+def test_srif_f32_predict_behind_a_failed_update_on_the_two_lane_kernel(n, p, bad_filter):
+    """fp32 at 14 / 16 states mixes two kernels on one batch -- Predict() runs on kb_srif_split.h, Update (p <= 6) on the
+    two-lane kernels -- and both keep their dense-R marks in Batch::d_srif_dense.  Predict, an Update in which a filter of slots
+    16..31 / 48..63 fails (it keeps its dense RBar), Predict again (must read that filter's FULL R), Update: against the oracle."""
+    rng = np.random.default_rng(777 + n + bad_filter)
+    N, steps = 200, 6
+    x0, P0, R, Phi, Ht, real, comp = _inputs(rng, N, n, p, steps)
+    fails = {1: [bad_filter], 4: [bad_filter + 64]}
+    for t, lst in fails.items():
+        for i in lst:
+            Phi[t, i, 1, :] = 0.0
+    b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=k.F32)
+    b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+    fs = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(N)]
+    Phi32, Ht32 = Phi.astype(np.float32).astype(np.float64), Ht.astype(np.float32).astype(np.float64)
+    real32, comp32 = real.astype(np.float32).astype(np.float64), comp.astype(np.float32).astype(np.float64)
+    predicts = (0, 2, 3)   # Predict, failed Update, Predict, Predict, Update (another failure, dense), Update
+    for t in range(steps):
+        b.prepare(Phi[t], Ht[t])
+        b.predict_nl() if t in predicts else b.update_nl(real[t], comp[t])
+        for i, f in enumerate(fs):
+            f.prepare(Phi32[t, i], Ht32[t, i])
+            rc = f.predict_nl() if t in predicts else f.update_nl(real32[t, i], comp32[t, i])
+            assert rc == (orc.ERR_SINGULAR if i in fails.get(t, []) else orc.OK)
+        eR = synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs]))
+        eb = synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs]))
+        assert eR <= 2e-5 and eb <= 2e-5, (t, eR, eb)
+    assert sorted(np.nonzero(b.status())[0].tolist()) == sorted([bad_filter, bad_filter + 64])
