@@ -270,14 +270,10 @@ def _leg_parity(ga, k, synth, leg):
         fs = [orc.Filter.hybrid(x0[i], P0[i], None, R[i], p) for i in range(N)]
         for f in fs:
             f.enable_ekf()
-    # D(ii) as SURVEY 8d specifies it (R = 1e-6 against P0 = 10) is ILL-CONDITIONED: a second oracle run whose Phi is perturbed in
-    # the last place shows how far two correct fp64 evaluations of it drift apart (~1e-5 after 20 steps); the engine is held to a
-    # small multiple of that, and to 1e-9 where the problem allows it
-    fs2 = []
-    if not fp32:
-        fs2 = [orc.Filter.hybrid(x0[i], P0[i], None, R[i], p) for i in range(N)]
-        for f in fs2:
-            f.enable_ekf()
+    # D(ii) as SURVEY 8d specifies it (R = 1e-6 against P0 = 10) is ILL-CONDITIONED: two correct fp64 evaluations of it drift ~1e-5 apart
+    # on the worst filter.  The GATE of this leg is therefore the arbiter above fp64 (tests/golden/generated/hybrid_ekf_bench_6x2_hp.npz,
+    # 60-digit restatement of hybrid.go:104-204 by tests/golden/make_highprec.py): engine error against the exact result <= 4 x the
+    # oracle's error against it (`_hybrid_arbiter`); the 4096-filter distance to the oracle is reported next to it
     eye = torch.eye(n, dtype=tdt, device="cuda").reshape(n * n, 1)
     nerr = 0
     for t in range(T):
@@ -294,11 +290,6 @@ def _leg_parity(ga, k, synth, leg):
         for i, f in enumerate(fs):
             f.prepare(Ph[i], Hh[i])
             nerr += f.update_nl(rh[i], ch[i]) != orc.OK
-        if fs2:
-            Pp = np.nextafter(Ph, np.where(rng.random(Ph.shape) < 0.5, -np.inf, np.inf))   # every entry of Phi moved by one ulp
-            for i, f in enumerate(fs2):
-                f.prepare(Pp[i], Hh[i])
-                f.update_nl(rh[i], ch[i])
     if fp32:
         eR = synth.rel_frobenius(b.get(k.RAW_MAT), np.array([f.raw_mat() for f in fs]))
         eb = synth.rel_frobenius(b.get(k.RAW_VEC), np.array([f.raw_vec() for f in fs]))
@@ -307,14 +298,42 @@ def _leg_parity(ga, k, synth, leg):
     else:
         xo, Po = np.array([f.state() for f in fs]), np.array([f.covariance() for f in fs])
         ex, eP = synth.rel_frobenius(b.get(k.STATE), xo), synth.rel_frobenius(b.get(k.COVAR), Po)
-        cx = synth.rel_frobenius(np.array([f.state() for f in fs2]), xo)
-        cP = synth.rel_frobenius(np.array([f.covariance() for f in fs2]), Po)
-        tx, tP = max(1e-9, 8 * cx), max(1e-9, 8 * cP)
+        arb = _hybrid_arbiter(ga, k)
         out.update({"max_rel_frobenius_state": ex, "max_rel_frobenius_covariance": eP,
-                    "oracle_vs_oracle_with_phi_moved_by_one_ulp": {"state": cx, "covariance": cP},
-                    "tolerance": {"state": tx, "covariance": tP, "rule": "max(1e-9, 8 x the drift of the oracle itself under a one-ulp change of Phi)"},
-                    "ok": bool(ex <= tx and eP <= tP and nerr == 0 and not b.status().any())})
+                    "note": "4096 filters against the oracle: reported, not the gate (ill-conditioned: both are fp64 evaluations)",
+                    "arbiter": arb, "tolerance": arb["rule"],
+                    "ok": bool(arb["ok"] and ex <= 1e-3 and eP <= 1e-3 and nerr == 0 and not b.status().any())})
     return out
+
+
+def _hybrid_arbiter(ga, k):
+    """configs[3] D(ii) against the exact result: 64 filters x 20 steps of the bench generator's problem, engine (kb_prepare_dev +
+    kb_update_nl_dev, the entry points the leg times) and oracle against tests/golden/generated/hybrid_ekf_bench_6x2_hp.npz."""
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    from tests import highprec as hp
+    z = hp.load("hybrid_ekf_bench_6x2")
+    T, N = z["Phi"].shape[:2]
+    n, p = 6, 2
+    b = ga.FilterBatch(k.HYBRID, n, p, 0, N)
+    b.set(k.X, z["x0"], 1); b.set(k.P, z["P0"], 2); b.set(k.R, z["R"], 2, p_rows=p); b.init(); b.enable_ekf()
+    ex, eP = np.zeros((T, N)), np.zeros((T, N))
+    for t in range(T):
+        dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (z["Phi"][t].reshape(N, -1).T, z["Ht"][t].reshape(N, -1).T, z["real"][t].T, z["comp"][t].T)]
+        torch.cuda.synchronize()
+        k.check(k.lib().kb_prepare_dev(b._h, dev[0].data_ptr(), dev[1].data_ptr(), N))
+        k.check(k.lib().kb_update_nl_dev(b._h, dev[2].data_ptr(), dev[3].data_ptr(), N))
+        b.synchronize()
+        ex[t], eP[t] = hp.rel_err(b.get(k.STATE), z["x"][t]), hp.rel_err(b.get(k.COVAR), z["P"][t])
+    xo, Po = hp.oracle_hybrid(orc, z)
+    ox = np.array([hp.rel_err(xo[t], z["x"][t]) for t in range(T)])
+    oP = np.array([hp.rel_err(Po[t], z["P"][t]) for t in range(T)])
+    ok = hp.passes(ex.max(axis=0), ox.max(axis=0)) and hp.passes(eP.max(axis=0), oP.max(axis=0)) and not b.status().any()
+    return {"filters": N, "steps": T, "exact": "tests/golden/generated/hybrid_ekf_bench_6x2_hp.npz (mpmath, 60 digits)",
+            "engine_vs_exact": {"state": hp.summary(ex.max(axis=0)), "covariance": hp.summary(eP.max(axis=0))},
+            "oracle_vs_exact": {"state": hp.summary(ox.max(axis=0)), "covariance": hp.summary(oP.max(axis=0))},
+            "rule": "engine error <= %g x oracle error + %g, worst and median filter (worst step of each)" % (hp.FACTOR, hp.FLOOR), "ok": bool(ok)}
 
 
 SRIF_F32_TOL = 2e-5   # tests/test_srif_gpu.py uses the same figure (achieved: ~1.3e-6 on R, ~2.7e-6 on b)
