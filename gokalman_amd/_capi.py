@@ -27,6 +27,7 @@ SIGNATURES = {
     "kb_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i64, _i, _i, C.c_uint]),
     "kb_destroy": (None, [_vp]),
     "kb_last_error": (C.c_char_p, []),
+    "kb_last_kernel": (C.c_char_p, [C.c_void_p]),
     "kb_version": (C.c_char_p, []),
     "kb_device_count": (_i, []),
     "kb_set": (_i, [_vp, _i, _dp, _i64, _i, _i]),

@@ -443,6 +443,10 @@ class FilterBatch:
     def meas_dim(self):
         return int(k.lib().kb_meas_dim(self._h))
 
+    def last_kernel(self):
+        """The kernel instantiation(s) that served the last step of this batch (kb_last_kernel: a debugging / reporting aid)."""
+        return k.lib().kb_last_kernel(self._h).decode("ascii", "replace")
+
     def stream(self):
         return int(k.lib().kb_stream(self._h) or 0)
 

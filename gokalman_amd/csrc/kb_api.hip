@@ -11,6 +11,8 @@
 
 #include <chrono>
 
+#include <cxxabi.h>
+
 #include "kb_internal.h"
 
 namespace kb {
@@ -268,15 +270,30 @@ void fill_step_args(const Batch &b, StepArgs &a) {
     a.bn_proc = b.d_bn_proc; a.bn_meas = b.d_bn_meas; a.bn_p = b.bn_p;
 }
 
+// ---- kb_last_kernel: which instantiation(s) served the last step (KB_LAUNCH, kb_internal.h) ----------------------------------------
+static thread_local const std::type_info *g_noted[KB_MAX_NOTED];
+static thread_local int g_nnoted = 0;
+void note_kernel(const std::type_info &tag) { if (g_nnoted < KB_MAX_NOTED) g_noted[g_nnoted++] = &tag; }
+void begin_kernel_record() { g_nnoted = 0; }
+void end_kernel_record(Batch &b) {
+    b.n_last_kernels = g_nnoted;
+    for (int i = 0; i < g_nnoted; i++) b.last_kernels[i] = g_noted[i];
+}
+
 static int launch_step(Batch &b, const StepArgs &a, bool fused) {
+    begin_kernel_record();
+    int rc;
     switch (b.kind) {
     case KB_VANILLA:
-    case KB_VANILLA_PREDICT: return launch_vanilla(b, a, fused);
-    case KB_SQUAREROOT: return launch_squareroot(b, a, fused);
-    case KB_INFORMATION: return launch_information(b, a);
+    case KB_VANILLA_PREDICT: rc = launch_vanilla(b, a, fused); break;
+    case KB_SQUAREROOT: rc = launch_squareroot(b, a, fused); break;
+    case KB_INFORMATION: rc = launch_information(b, a); break;
+    default:
+        set_error("kind %d has no LDKF update", b.kind);
+        return KB_ERR_UNSUPPORTED;
     }
-    set_error("kind %d has no LDKF update", b.kind);
-    return KB_ERR_UNSUPPORTED;
+    end_kernel_record(b);
+    return rc;
 }
 
 // host [N][rows] -> AoSoA staging block with `rows` elements per filter
@@ -317,6 +334,28 @@ using namespace kb;
 extern "C" {
 
 const char *kb_last_error(void) { return g_err; }
+
+// "vanilla_reg_kernel<double, 6, 3, 0, false, false, false, false, false, false>" (two kernels of one step joined by " + "), "" before
+// the first step.  The string lives in the handle until the next call of this function on it.
+const char *kb_last_kernel(kb_batch *b) {
+    if (!b) return "";
+    b->last_kernel_text.clear();
+    for (int i = 0; i < b->n_last_kernels; i++) {
+        int st = 0;
+        char *d = abi::__cxa_demangle(b->last_kernels[i]->name(), nullptr, nullptr, &st);
+        std::string t = (st == 0 && d) ? d : b->last_kernels[i]->name();
+        free(d);
+        // "kb::KernelTag<&(void kb::NAME<ARGS>(kb::StepArgs))>" -> "NAME<ARGS>"
+        const size_t v = t.find("(void kb::");
+        if (v != std::string::npos) t = t.substr(v + 10);
+        const size_t e = t.rfind(">(");
+        if (e != std::string::npos) t = t.substr(0, e + 1);
+        else { const size_t e2 = t.rfind("("); if (e2 != std::string::npos) t = t.substr(0, e2); }
+        if (i) b->last_kernel_text += " + ";
+        b->last_kernel_text += t;
+    }
+    return b->last_kernel_text.c_str();
+}
 const char *kb_version(void) { return "gokalman_amd 0.1 (gfx950)"; }
 
 int kb_device_count(void) {

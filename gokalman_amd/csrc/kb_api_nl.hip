@@ -20,8 +20,10 @@ static int ready_nl(kb_batch *b) {
 }
 
 static int launch_nl(kb_batch *b, const StepArgs &a) {
-    if (b->kind == KB_BATCH_LS) return launch_batch_ls(*b, a);
-    return b->kind == KB_SRIF ? launch_srif(*b, a) : launch_hybrid(*b, a);
+    begin_kernel_record();
+    const int rc = b->kind == KB_BATCH_LS ? launch_batch_ls(*b, a) : (b->kind == KB_SRIF ? launch_srif(*b, a) : launch_hybrid(*b, a));
+    end_kernel_record(*b);
+    return rc;
 }
 
 extern "C" {

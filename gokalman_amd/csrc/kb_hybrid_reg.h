@@ -311,10 +311,10 @@ static inline bool hybrid_try(const Batch &b, const StepArgs &a) {
     const dim3 grid((unsigned)((a.ntiles + HYB_WPB - 1) / HYB_WPB)), block(64 * HYB_WPB);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const bool sncp = a.snc || a.predict;
-#define KB_H(E_, F_) do { if (sncp) { if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true, true, PAD>), grid, block, 0, b.stream, a); \
-                                      else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false, true, PAD>), grid, block, 0, b.stream, a); } \
-                          else if (a.ext_phi) hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, true, false, PAD>), grid, block, 0, b.stream, a); \
-                          else hipLaunchKernelGGL((hybrid_reg_kernel<T, NS, NM, E_, F_, false, false, PAD>), grid, block, 0, b.stream, a); } while (0)
+#define KB_H(E_, F_) do { if (sncp) { if (a.ext_phi) KB_LAUNCH((hybrid_reg_kernel<T, NS, NM, E_, F_, true, true, PAD>), grid, block, 0, b.stream, a); \
+                                      else KB_LAUNCH((hybrid_reg_kernel<T, NS, NM, E_, F_, false, true, PAD>), grid, block, 0, b.stream, a); } \
+                          else if (a.ext_phi) KB_LAUNCH((hybrid_reg_kernel<T, NS, NM, E_, F_, true, false, PAD>), grid, block, 0, b.stream, a); \
+                          else KB_LAUNCH((hybrid_reg_kernel<T, NS, NM, E_, F_, false, false, PAD>), grid, block, 0, b.stream, a); } while (0)
     if (a.ekf) { if (full) KB_H(true, true); else KB_H(true, false); }
     else       { if (full) KB_H(false, true); else KB_H(false, false); }
 #undef KB_H

@@ -9,13 +9,13 @@ static void hyb_go(const Batch &b, const StepArgs &a) {
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
     if (a.predict) {   // Predict() (hybrid.go:125-143): {xBar (CKF) or 0 (EKF), PBar}; the six-measurement instantiations carry any p <= 6
         if constexpr (NM >= 6) {
-            if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 0, L, true, true, true, false, false, false, true>), grid, block, 0, b.stream, a);
-            else hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 0, L, true, false, true, false, false, false, true>), grid, block, 0, b.stream, a);
+            if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 0, L, true, true, true, false, false, false, true>), grid, block, 0, b.stream, a);
+            else KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 0, L, true, false, true, false, false, false, true>), grid, block, 0, b.stream, a);
         }
         return;
     }
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 0, L, true, true, false, false, false, false, true>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 0, L, true, false, false, false, false, false, true>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 0, L, true, true, false, false, false, false, true>), grid, block, 0, b.stream, a);
+    else KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 0, L, true, false, false, false, false, false, true>), grid, block, 0, b.stream, a);
 }
 
 bool launch_hybrid_split8(const Batch &b, const StepArgs &a) {

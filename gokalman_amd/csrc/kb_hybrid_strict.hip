@@ -285,8 +285,8 @@ template <typename T, int NS, int NM>
 static bool try_hybrid_strict(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || a.pmax != NM || (a.snc && a.L.nq > 3)) return false;
     const dim3 grid((unsigned)a.ntiles), block(64);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((hybrid_strict_kernel<T, NS, NM, true>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((hybrid_strict_kernel<T, NS, NM, false>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((hybrid_strict_kernel<T, NS, NM, true>), grid, block, 0, b.stream, a);
+    else KB_LAUNCH((hybrid_strict_kernel<T, NS, NM, false>), grid, block, 0, b.stream, a);
     return true;
 }
 

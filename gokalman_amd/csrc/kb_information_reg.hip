@@ -358,9 +358,9 @@ static bool info_variant(const StepArgs &a, bool &full, bool &noise) {
 }
 #define KB_INFO_GO(SC_, PAD_)                                                                                                        \
     do {                                                                                                                             \
-        if (!full) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, false, false, SHARED>), grid, block, 0, b.stream, a); \
-        else if (!noise) hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, false, SHARED>), grid, block, 0, b.stream, a); \
-        else hipLaunchKernelGGL((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, true, SHARED>), grid, block, 0, b.stream, a);      \
+        if (!full) KB_LAUNCH((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, false, false, SHARED>), grid, block, 0, b.stream, a); \
+        else if (!noise) KB_LAUNCH((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, false, SHARED>), grid, block, 0, b.stream, a); \
+        else KB_LAUNCH((information_reg_kernel<T, NS, NM, NC, SC_, PAD_, true, true, SHARED>), grid, block, 0, b.stream, a);      \
     } while (0)
 
 template <typename T, int NS, int NM, int NC = 0, bool SHARED = false>

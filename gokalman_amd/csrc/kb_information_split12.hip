@@ -12,11 +12,11 @@ bool launch_information_split(const Batch &b, const StepArgs &a) {
     if (a.flags & KB_FLAG_FULL_ESTIMATE) return launch_information_split_full(b, a);   // kb_information_split12f.hip
     if (launch_information_split8(b, a)) return true;
     if (a.n == 12 && a.p == 6 && m == 0)
-        hipLaunchKernelGGL((information_split_kernel<double, 12, 6, 0, 4, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
+        KB_LAUNCH((information_split_kernel<double, 12, 6, 0, 4, false>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     else if (a.n <= 12)
-        hipLaunchKernelGGL((information_split_kernel<double, 12, 8, 2, 4, true>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
+        KB_LAUNCH((information_split_kernel<double, 12, 8, 2, 4, true>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     else
-        hipLaunchKernelGGL((information_split_kernel<double, 16, 8, 2, 8, true>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
+        KB_LAUNCH((information_split_kernel<double, 16, 8, 2, 8, true>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
     return true;
 }
 

@@ -6,7 +6,7 @@ namespace kb {
 
 bool launch_information_split8(const Batch &b, const StepArgs &a) {
     if (a.n > 8 || a.p > 4) return false;
-    hipLaunchKernelGGL((information_split_kernel<double, 8, 4, 2, 4, true>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
+    KB_LAUNCH((information_split_kernel<double, 8, 4, 2, 4, true>), dim3((unsigned)(a.ntiles * 4)), dim3(64), 0, b.stream, a);
     return true;
 }
 

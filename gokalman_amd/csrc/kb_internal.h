@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <typeinfo>
 
 #include "../../include/gokalman_amd.h"
 #include "kb_device.h"
@@ -42,6 +43,9 @@ struct Batch {
     void *d_est = nullptr;
     void *d_model = nullptr;
     uint32_t *d_status = nullptr;
+    const std::type_info *last_kernels[4] = {nullptr, nullptr, nullptr, nullptr};   // KB_LAUNCH / kb_last_kernel
+    int n_last_kernels = 0;
+    std::string last_kernel_text;
     // kf.step per filter.  The reference returns from a failed Update BEFORE `kf.step++` (vanilla.go:164-167 / :207-215 against
     // :218; srif.go:112-114; hybrid.go:150-152): such a filter's step counter -- the index of its BatchNoise vectors and the k of
     // its error messages -- falls one behind the number of Update calls.  lag[i] = calls that failed for filter i that way;
@@ -103,6 +107,16 @@ int hip_fail(hipError_t e, const char *what);
 // block is rounded up to the 2 MB the driver maps and handed out so that it ENDS where the mapping ends, and a kernel that reads or
 // writes behind its last tile (a padded shape's stand-in element, a tail tile's masked lane) takes a memory fault instead of going unseen.
 hipError_t dev_alloc(void **p, size_t bytes);
+
+// Which kernel(s) served the last step of a handle (kb_last_kernel, a debugging / reporting aid: scripts/dispatch_table.py walks kind x n x
+// p x noise x flags with it).  Every STEP-kernel launch goes through KB_LAUNCH, which notes the instantiation -- as the type_info of
+// KernelTag<&kernel<...>>, demangled only when somebody asks -- in a per-thread record that launch_step / launch_nl move into the Batch.
+template <auto K> struct KernelTag {};
+constexpr int KB_MAX_NOTED = 4;
+void note_kernel(const std::type_info &tag);
+void begin_kernel_record();
+void end_kernel_record(struct Batch &b);
+#define KB_LAUNCH(kern, ...) do { ::kb::note_kernel(typeid(::kb::KernelTag<&kern>)); hipLaunchKernelGGL(kern, __VA_ARGS__); } while (0)
 hipError_t dev_free(void *p);
 #define KB_HIP(call)                                                          \
     do {                                                                      \

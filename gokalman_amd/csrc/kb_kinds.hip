@@ -560,13 +560,13 @@ __global__ void __launch_bounds__(64) batch_ls_gen_kernel(const StepArgs a) {
         const dim3 grid((unsigned)a.ntiles), block(64);                                                      \
         const HeavyScope hs(b, dm > 8);   /* LD = 16: scratch-heavy, see kb_internal.h */                     \
         if (b.dtype == KB_F64) {                                                                             \
-            if (dm <= 4) hipLaunchKernelGGL((KERNEL<double, 4>), grid, block, 0, hs.stream, a);              \
-            else if (dm <= 8) hipLaunchKernelGGL((KERNEL<double, 8>), grid, block, 0, hs.stream, a);         \
-            else hipLaunchKernelGGL((KERNEL<double, 16>), grid, block, 0, hs.stream, a);                     \
+            if (dm <= 4) KB_LAUNCH((KERNEL<double, 4>), grid, block, 0, hs.stream, a);              \
+            else if (dm <= 8) KB_LAUNCH((KERNEL<double, 8>), grid, block, 0, hs.stream, a);         \
+            else KB_LAUNCH((KERNEL<double, 16>), grid, block, 0, hs.stream, a);                     \
         } else {                                                                                             \
-            if (dm <= 4) hipLaunchKernelGGL((KERNEL<float, 4>), grid, block, 0, hs.stream, a);               \
-            else if (dm <= 8) hipLaunchKernelGGL((KERNEL<float, 8>), grid, block, 0, hs.stream, a);          \
-            else hipLaunchKernelGGL((KERNEL<float, 16>), grid, block, 0, hs.stream, a);                      \
+            if (dm <= 4) KB_LAUNCH((KERNEL<float, 4>), grid, block, 0, hs.stream, a);               \
+            else if (dm <= 8) KB_LAUNCH((KERNEL<float, 8>), grid, block, 0, hs.stream, a);          \
+            else KB_LAUNCH((KERNEL<float, 16>), grid, block, 0, hs.stream, a);                      \
         }                                                                                                    \
         KB_HIP(hipGetLastError());                                                                           \
     } while (0)

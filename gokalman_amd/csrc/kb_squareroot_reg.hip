@@ -337,8 +337,8 @@ static bool sqrt_try(const Batch &b, const StepArgs &a) {
     if (SHARED && a.mo_ts != 0) return false;
     if (a.noise_kind != (NOISE ? KB_NOISE_AWGN : KB_NOISE_NOISELESS)) return false;
     const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, false, NOISE, SHARED>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, false, NOISE, SHARED>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((squareroot_reg_kernel<T, NS, NM, NC, true, false, NOISE, SHARED>), grid, block, 0, b.stream, a);
+    else KB_LAUNCH((squareroot_reg_kernel<T, NS, NM, NC, false, false, NOISE, SHARED>), grid, block, 0, b.stream, a);
     return true;
 }
 
@@ -350,8 +350,8 @@ static bool sqrt_try_pad(const Batch &b, const StepArgs &a) {
     if (SHARED && a.mo_ts != 0) return false;
     if (a.noise_kind != (NOISE ? KB_NOISE_AWGN : KB_NOISE_NOISELESS)) return false;
     const dim3 grid((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), block(64 * SQRT_WPB);
-    if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, true, true, NOISE, SHARED>), grid, block, 0, b.stream, a);
-    else hipLaunchKernelGGL((squareroot_reg_kernel<T, NS, NM, NC, false, true, NOISE, SHARED>), grid, block, 0, b.stream, a);
+    if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((squareroot_reg_kernel<T, NS, NM, NC, true, true, NOISE, SHARED>), grid, block, 0, b.stream, a);
+    else KB_LAUNCH((squareroot_reg_kernel<T, NS, NM, NC, false, true, NOISE, SHARED>), grid, block, 0, b.stream, a);
     return true;
 }
 
@@ -364,7 +364,7 @@ bool squareroot_fused_ok(const Batch &b, const StepArgs &a) {
 int launch_squareroot(const Batch &b, const StepArgs &a, bool fused) {
     if (a.flags & KB_FLAG_STATEMENT_KERNELS) return launch_squareroot_gen(b, a);
     if (fused && squareroot_fused_ok(b, a)) {
-        hipLaunchKernelGGL((squareroot_reg_kernel<double, 6, 3, 0, false, false, false, false, true>), dim3((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), dim3(64 * SQRT_WPB), 0, b.stream, a);
+        KB_LAUNCH((squareroot_reg_kernel<double, 6, 3, 0, false, false, false, false, true>), dim3((unsigned)((a.ntiles + SQRT_WPB - 1) / SQRT_WPB)), dim3(64 * SQRT_WPB), 0, b.stream, a);
         KB_HIP(hipGetLastError());
         return KB_OK;
     }

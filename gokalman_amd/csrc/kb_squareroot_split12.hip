@@ -9,12 +9,12 @@ bool launch_squareroot_split12(const Batch &b, const StepArgs &a) {
     if (a.noise_kind != KB_NOISE_NOISELESS && a.noise_kind != KB_NOISE_AWGN) return false;
     const dim3 grid((unsigned)(a.ntiles * 4)), block(64);
     if (a.n == 12 && a.p == 6 && m == 0 && a.noise_kind == KB_NOISE_NOISELESS) {
-        if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_split_kernel<double, 12, 6, 0, 4, false, true>), grid, block, 0, b.stream, a);
-        else hipLaunchKernelGGL((squareroot_split_kernel<double, 12, 6, 0, 4, false, false>), grid, block, 0, b.stream, a);
+        if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((squareroot_split_kernel<double, 12, 6, 0, 4, false, true>), grid, block, 0, b.stream, a);
+        else KB_LAUNCH((squareroot_split_kernel<double, 12, 6, 0, 4, false, false>), grid, block, 0, b.stream, a);
         return true;
     }
     if (launch_squareroot_split12_plain(b, a)) return true;
-    hipLaunchKernelGGL((squareroot_split_kernel<double, 12, 8, 2, 4, true, false>), grid, block, 0, b.stream, a);
+    KB_LAUNCH((squareroot_split_kernel<double, 12, 8, 2, 4, true, false>), grid, block, 0, b.stream, a);
     return true;
 }
 

@@ -10,13 +10,13 @@ static void sq_plain(const Batch &b, const StepArgs &a) {
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
     if (a.noise_kind == KB_NOISE_AWGN) {   // (p <= 6 only: the caller sends p = 7, 8 with noise to the run-time-everything kernel)
         if constexpr (NM <= 6) {
-            if (a.flags & KB_FLAG_FULL_ESTIMATE) hipLaunchKernelGGL((squareroot_split_kernel<double, NS, NM, 2, L, true, true, false, true>), grid, block, 0, b.stream, a);
-            else hipLaunchKernelGGL((squareroot_split_kernel<double, NS, NM, 2, L, true, false, false, true>), grid, block, 0, b.stream, a);
+            if (a.flags & KB_FLAG_FULL_ESTIMATE) KB_LAUNCH((squareroot_split_kernel<double, NS, NM, 2, L, true, true, false, true>), grid, block, 0, b.stream, a);
+            else KB_LAUNCH((squareroot_split_kernel<double, NS, NM, 2, L, true, false, false, true>), grid, block, 0, b.stream, a);
         }
     } else if (a.flags & KB_FLAG_FULL_ESTIMATE) {
-        if constexpr (NM <= 6) hipLaunchKernelGGL((squareroot_split_kernel<double, NS, NM, 2, L, true, true, false>), grid, block, 0, b.stream, a);
+        if constexpr (NM <= 6) KB_LAUNCH((squareroot_split_kernel<double, NS, NM, 2, L, true, true, false>), grid, block, 0, b.stream, a);
     } else {
-        hipLaunchKernelGGL((squareroot_split_kernel<double, NS, NM, 2, L, true, false, false>), grid, block, 0, b.stream, a);
+        KB_LAUNCH((squareroot_split_kernel<double, NS, NM, 2, L, true, false, false>), grid, block, 0, b.stream, a);
     }
 }
 

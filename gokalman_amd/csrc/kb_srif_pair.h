@@ -704,8 +704,8 @@ static bool srif_pair_launch(const Batch &b, const StepArgs &a) {
     const dim3 dgrid((unsigned)(2 * a.ntiles)), dblock(64);
 #define KB_P(F_, E_)                                                                                                                         \
     do {                                                                                                                                     \
-        if (a.srif_tri) hipLaunchKernelGGL((srif_pair_kernel<T, NS, NM, F_, E_, PADM>), grid, block, 0, b.stream, a);                             \
-        if (!a.srif_tri || a.srif_leftover) hipLaunchKernelGGL((srif_pair_dense_kernel<T, NS, NM, F_, E_, PADM>), dgrid, dblock, 0, b.stream, a); \
+        if (a.srif_tri) KB_LAUNCH((srif_pair_kernel<T, NS, NM, F_, E_, PADM>), grid, block, 0, b.stream, a);                             \
+        if (!a.srif_tri || a.srif_leftover) KB_LAUNCH((srif_pair_dense_kernel<T, NS, NM, F_, E_, PADM>), dgrid, dblock, 0, b.stream, a); \
     } while (0)
     if constexpr (NS > 12) { if (ext) KB_P(true, true); else KB_P(true, false); }
     else {

@@ -191,7 +191,7 @@ static bool srif_try_predict(const Batch &b, const StepArgs &a) {
     if (a.n != NS || !a.predict) return false;   // (the time update does not see the measurement: any p)
     const dim3 grid = tile_grid(a.ntiles), block(256);
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0, ext = a.ext_phi != nullptr;
-#define KB_T(F_, E_) hipLaunchKernelGGL((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a)
+#define KB_T(F_, E_) KB_LAUNCH((srif_time_kernel<T, NS, F_, E_>), grid, block, 0, b.stream, a)
     if (full) { if (ext) KB_T(true, true); else KB_T(true, false); }
     else      { if (ext) KB_T(false, true); else KB_T(false, false); }
 #undef KB_T

@@ -683,7 +683,7 @@ __global__ void __launch_bounds__(64, (N <= 8 && NM <= 4) ? 3 : 2) srif_split_ke
 template <typename T, int N, int NM>
 static void srif_split_launch(const Batch &b, const StepArgs &a) {
     constexpr int L = (N <= 12 || sizeof(T) == 4) ? 4 : 8;   // (fp32 at 13..16 states, A/B: eight lanes 307 us at 13/2 and 376 at 16/8 against 250 / 311 on four)
-    hipLaunchKernelGGL((srif_split_kernel<T, N, NM, L>), dim3((unsigned)(a.ntiles * L)), dim3(64), 0, b.stream, a);
+    KB_LAUNCH((srif_split_kernel<T, N, NM, L>), dim3((unsigned)(a.ntiles * L)), dim3(64), 0, b.stream, a);
 }
 // one translation unit per group of state dimensions (kb_srif_split_*.hip): p <= 4, p <= 6 and p <= 8 instantiations of each
 #define KB_SRIF_SPLIT_TU(N_)                                                                                              \

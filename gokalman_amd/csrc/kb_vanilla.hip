@@ -266,9 +266,9 @@ static int launch_vanilla_t(const Batch &b, const StepArgs &a, bool fused) {
         const int d = a.n > a.p ? (a.n > a.m ? a.n : a.m) : (a.p > a.m ? a.p : a.m);
         const dim3 grid((unsigned)a.ntiles), block(64);
         const HeavyScope hs(b, d > 8);   // LD = 16: scratch-heavy, see kb_internal.h
-        if (d <= 4) hipLaunchKernelGGL((vanilla_gen_kernel<T, 4>), grid, block, 0, hs.stream, a);
-        else if (d <= 8) hipLaunchKernelGGL((vanilla_gen_kernel<T, 8>), grid, block, 0, hs.stream, a);
-        else hipLaunchKernelGGL((vanilla_gen_kernel<T, 16>), grid, block, 0, hs.stream, a);
+        if (d <= 4) KB_LAUNCH((vanilla_gen_kernel<T, 4>), grid, block, 0, hs.stream, a);
+        else if (d <= 8) KB_LAUNCH((vanilla_gen_kernel<T, 8>), grid, block, 0, hs.stream, a);
+        else KB_LAUNCH((vanilla_gen_kernel<T, 16>), grid, block, 0, hs.stream, a);
     }
     KB_HIP(hipGetLastError());
     return KB_OK;

@@ -11,7 +11,7 @@ namespace kb {
 bool launch_vanilla_noise_fused(const Batch &b, const StepArgs &a) {
     if (!vanilla_noise_fused_ok(b, a)) return false;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
-    hipLaunchKernelGGL((vanilla_reg_kernel<double, 6, 3, 0, false, false, true, false, true, false>), grid, block, 0, b.stream, a);
+    KB_LAUNCH((vanilla_reg_kernel<double, 6, 3, 0, false, false, true, false, true, false>), grid, block, 0, b.stream, a);
     return true;
 }
 

@@ -583,7 +583,7 @@ static inline bool try_reg(const Batch &b, const StepArgs &a, bool fused) {
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
 #define KB_GO(FULL_, PRED_, FUSED_) \
-    hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_, false, NOISE, SHARED>), grid, block, 0, b.stream, a)
+    KB_LAUNCH((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, FUSED_, false, NOISE, SHARED>), grid, block, 0, b.stream, a)
     if constexpr (WITH_FUSED) {
         if (fused) {
             if (a.predict) { if (full) KB_GO(true, true, true); else KB_GO(false, true, true); }
@@ -606,7 +606,7 @@ static inline bool try_pad(const Batch &b, const StepArgs &a) {
     if ((a.noise_kind != KB_NOISE_NOISELESS) != NOISE) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)((a.ntiles + KB_VANILLA_WPB - 1) / KB_VANILLA_WPB)), block(KB_VANILLA_WPB * 64);
-#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true, NOISE, SHARED>), grid, block, 0, b.stream, a)
+#define KB_GO(FULL_, PRED_) KB_LAUNCH((vanilla_reg_kernel<T, NS, NM, NC, FULL_, PRED_, false, true, NOISE, SHARED>), grid, block, 0, b.stream, a)
     if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
     else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
 #undef KB_GO
@@ -630,6 +630,7 @@ bool launch_vanilla_shared(const Batch &b, const StepArgs &a);
 // one filter split over L lanes (kb_vanilla_split.h): n <= 12, p <= 8, m <= 2 (kb_vanilla_split12.hip), fp64, one step per launch
 bool launch_vanilla_split12(const Batch &b, const StepArgs &a);
 bool launch_vanilla_split16(const Batch &b, const StepArgs &a);   // 13..16 states: eight lanes per filter
+bool launch_vanilla_split12_noise(const Batch &b, const StepArgs &a);   // kb_vanilla_split12n.hip: exact 12 / 6 / 0 with AWGN / BatchNoise
 bool launch_vanilla_split12_plain(const Batch &b, const StepArgs &a);   // kb_vanilla_split12p.hip / 16p.hip: padded shapes, Noiseless, state only
 bool launch_vanilla_split16_plain(const Batch &b, const StepArgs &a);
 

@@ -438,7 +438,7 @@ constexpr int split_lds_total() {
 // HYB: the HybridKF measurement update (hybrid.go:104-204; CKF or EKF by StepArgs::ekf, no SNC, no Predict()) -- the same algebra on
 // Phi, Htilde, R of the model block (kb_prepare packs them there), no Q, the measurement as (real - computed), xBar = 0 for the EKF;
 // the Estimate's measurement is the real observation and it carries the prefit residual (es_dobs).
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN, bool NOISET = false, bool HYB = false>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool RT = GEN, int NOISET = 0, bool HYB = false>
 __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int64_t gw, T *lds) {
     static_assert(NS % L == 0, "rows are dealt out cyclically");
     constexpr int FPW = 64 / L, RP = NS / L, TR = tri(NS), TM = tri(NM);
@@ -762,7 +762,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         }
     }
 
-    // ---- Noise (RT, or NOISET: AWGN at compile time; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
+    // ---- Noise (RT, or NOISET at compile time: 1 AWGN, 2 BatchNoise; noise.go:67-164): Process(k) into x- (vanilla.go:146), Measurement(k) into yhat (:157), Process(k) again
     // into x+ (:195), k = kf.step of THIS filter.  The normals of a draw are the filter's (kb_vanilla_reg.h draw_normals: Philox keyed
     // by the filter index), formed by each of its L lanes; the lane applies its own rows of chol(Q) (read from the model block: the
     // constructor's factor) to them.
@@ -775,7 +775,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
         if (NOISET || a.noise_kind != KB_NOISE_NOISELESS) {
             const uint64_t gfi = (uint64_t)(a.first_filter + fi);
             const uint32_t stepno = (uint32_t)a.step0 - (active ? a.lag[fi] : 0u);   // kf.step of this filter
-            if (NOISET || a.noise_kind == KB_NOISE_AWGN) {
+            if (NOISET == 1 || (NOISET == 0 && a.noise_kind == KB_NOISE_AWGN)) {
                 // The NV standard normals of a draw are the FILTER's (Philox keyed by the filter index, two per Box-Muller block).  Its L
                 // lanes share the work: lane q forms blocks q, q + L, ... -- the same instructions in every lane, a different counter --
                 // and the vector is gathered through LDS (the first NV slots: F, which sat there, is consumed): a quarter / an eighth of
@@ -840,7 +840,7 @@ __device__ __forceinline__ void vanilla_split_part(const StepArgs &a, const int6
                     }
                     KB_SB();
                 }
-            } else if constexpr (RT) {   // BatchNoise: the recorded vectors of step k (noise.go:72-86)
+            } else if constexpr (RT || NOISET == 2) {   // BatchNoise: the recorded vectors of step k (noise.go:72-86)
                 const T *bp = (const T *)a.bn_proc + (int64_t)stepno * rn;
 #pragma unroll
                 for (int r = 0; r < RP; r++) {
@@ -1440,7 +1440,7 @@ __device__ __forceinline__ int64_t split_part_of_block(unsigned b, unsigned nblo
 
 // One-wave workgroups (they share nothing, and a finished wave frees its slot and its LDS at once).  PERSIST: the grid is one
 // workgroup per wave slot of the device and each walks over the parts gw = blockIdx, blockIdx + gridDim, ...
-template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, bool NOISET = false, bool HYB = false>
+template <typename T, int NS, int NM, int NC, int L, bool GEN, bool FULLT, bool PREDT, bool PERSIST = false, bool RT = GEN, int NOISET = 0, bool HYB = false>
 // (Hybrid at 12 / 8 on ONE wave per SIMD without scratch was measured against two waves with 132 B: 1.65 against 1.59 ms per 1M-filter step)
 __global__ void __launch_bounds__(64, (((RT || (NM > 6 && !split_hsplit<NM, L>())) && L == 4) ? 1 : ((int)sizeof(T) * split_lds_total<T, NS, NM, L, RT, FULLT>() * 8 <= 160 * 1024 ? 2 : 1))) vanilla_split_kernel(const StepArgs a) {
     __shared__ __attribute__((aligned(16))) T lds[split_lds_total<T, NS, NM, L, RT, FULLT>()];

@@ -10,7 +10,7 @@ static bool split_exact(const Batch &b, const StepArgs &a) {
     if (a.n != NS || a.p != NM || (a.need_ctrl ? a.m : 0) != NC || a.noise_kind != KB_NOISE_NOISELESS || a.predict) return false;   // (pure predictors: the run-time-everything kernel)
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
-#define KB_GO(F_, P_) hipLaunchKernelGGL((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_>), grid, block, 0, b.stream, a)
+#define KB_GO(F_, P_) KB_LAUNCH((vanilla_split_kernel<T, NS, NM, NC, L, false, F_, P_>), grid, block, 0, b.stream, a)
     if (full) KB_GO(true, false); else KB_GO(false, false);
 #undef KB_GO
     return true;
@@ -18,14 +18,10 @@ static bool split_exact(const Batch &b, const StepArgs &a) {
 
 bool launch_vanilla_split16(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n > 16 || a.p > 8 || (a.need_ctrl ? a.m : 0) > 2) return false;
-    // BatchNoise reports ZERO noise matrices (noise.go:89-98): once the measurements have pinned the state down, P is amplified
-    // rounding noise and only the reference's own order of operations reproduces its digits (kb_vanilla_reg.h).  The split kernel
-    // evaluates the Joseph form in the distributed order, so these batches take the statement-order kernel (as the SquareRoot and
-    // Information split launchers already decide).
-    if (a.noise_kind == KB_NOISE_BATCH) return false;
+    // (BatchNoise runs here since round 6: kb_vanilla_split12.hip)
     if (split_exact<double, 16, 8, 0, 8>(b, a)) return true;
     if (launch_vanilla_split16_plain(b, a)) return true;
-    hipLaunchKernelGGL((vanilla_split_kernel<double, 16, 8, 2, 8, true, false, false>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
+    KB_LAUNCH((vanilla_split_kernel<double, 16, 8, 2, 8, true, false, false>), dim3((unsigned)(a.ntiles * 8)), dim3(64), 0, b.stream, a);
     return true;
 }
 

@@ -8,12 +8,12 @@ template <int NS, int NM, int L>
 static void split_plain(const Batch &b, const StepArgs &a) {
     const dim3 grid((unsigned)(a.ntiles * L)), block(64);
     if (a.noise_kind == KB_NOISE_AWGN) {
-        if (a.flags & KB_FLAG_FULL_ESTIMATE) { if constexpr (NM <= 6) hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false, true>), grid, block, 0, b.stream, a); }
-        else hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, false, false, false, false, true>), grid, block, 0, b.stream, a);
+        if (a.flags & KB_FLAG_FULL_ESTIMATE) { if constexpr (NM <= 6) KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false, true>), grid, block, 0, b.stream, a); }
+        else KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 2, L, true, false, false, false, false, true>), grid, block, 0, b.stream, a);
     } else if (a.flags & KB_FLAG_FULL_ESTIMATE) {
-        hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false>), grid, block, 0, b.stream, a);
+        KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 2, L, true, true, false, false, false>), grid, block, 0, b.stream, a);
     } else {
-        hipLaunchKernelGGL((vanilla_split_kernel<double, NS, NM, 2, L, true, false, false, false, false>), grid, block, 0, b.stream, a);
+        KB_LAUNCH((vanilla_split_kernel<double, NS, NM, 2, L, true, false, false, false, false>), grid, block, 0, b.stream, a);
     }
 }
 

@@ -252,7 +252,7 @@ static bool try_strict(const Batch &b, const StepArgs &a) {
     if (a.n > NS || a.p > NM || m > NC || (NC == 0) != (m == 0)) return false;
     const bool full = (a.flags & KB_FLAG_FULL_ESTIMATE) != 0;
     const dim3 grid((unsigned)a.ntiles), block(64);
-#define KB_GO(FULL_, PRED_) hipLaunchKernelGGL((vanilla_strict_kernel<T, NS, NM, NC, FULL_, PRED_>), grid, block, 0, b.stream, a)
+#define KB_GO(FULL_, PRED_) KB_LAUNCH((vanilla_strict_kernel<T, NS, NM, NC, FULL_, PRED_>), grid, block, 0, b.stream, a)
     if (a.predict) { if (full) KB_GO(true, true); else KB_GO(false, true); }
     else           { if (full) KB_GO(true, false); else KB_GO(false, false); }
 #undef KB_GO

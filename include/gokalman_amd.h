@@ -120,6 +120,12 @@ void kb_destroy(kb_batch *b);
 const char *kb_last_error(void);
 const char *kb_version(void);
 int kb_device_count(void);
+/* Debugging / reporting aid, no counterpart in the reference (kalman.go:35-72 has one Update per filter type; here (kind, n, p, noise, flags)
+ * choose among ~150 kernel instantiations): the instantiation(s) the LAST step of this handle was served by, e.g.
+ * "vanilla_split_kernel<double, 12, 6, 0, 4, false, false, false>"; two kernels of one step are joined by " + "; "" before the first
+ * step.  The string belongs to the handle and is valid until the next kb_last_kernel call on it.  scripts/dispatch_table.py walks the
+ * envelope with it (profiles/dispatch_table.md). */
+const char *kb_last_kernel(kb_batch *b);
 
 /* ---- model / initial conditions ------------------------------------------- */
 /* Host -> device upload of one input field.  `count` = 1 with broadcast != 0
