@@ -820,7 +820,7 @@ def main():
                                  "filters_total": world * M, "steps": K6, "value": world * M * K6 / v_s,
                                  "unit": "filter-update steps/s (whole job)", "kernel_ms": vms,
                                  "roofline": rl.hbm_roofline(vms, M, rl.algorithmic_bytes("vanilla", 12, 6), rl.moved_bytes("vanilla", 12, 6),
-                                                             *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 12, 6, 0, 4, false, false, false")),
+                                                             *rl.load_traffic(ROOT, "vanilla_split_kernel<double, 12, 6, 0, 4, false, false, false, false, false, 0")),
                                  "filters_with_error_status": vbad}
         del vb, yq
         # ... and SquareRoot at the same size (kb_squareroot_split.h: the Householder panels distributed by columns over four lanes)
