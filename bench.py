@@ -769,8 +769,8 @@ def main():
                                                            *rl.load_traffic(ROOT, "squareroot_reg_kernel<double, 6, 3, 0, false")),
                                "filters_with_error_status": qbad}
         if args.fused_steps > 0 and rank == 0:
-            # config C with the caller loop inside one launch (round 5): x, S and the model resident over T steps; NOT bit-identical to T launches
-            # (FASTDIV Newton reciprocals, held to 1e-12 of them and to 1e-9 of the oracle: `parity` below)
+            # config C with the caller loop inside one launch (round 5): x, S and the model resident over T steps; Newton reciprocals, so not
+            # PROMISED to be T launches' bits (held to 1e-12 of them and to 1e-9 of the oracle: `parity` below; achieved since round 6: the same bits)
             T = args.fused_steps
             yT = yq.unsqueeze(0).repeat(T, 1, 1).contiguous()   # [T][p][M] (the same measurement every step: throughput only)
             sq.update_steps_dev(yT.data_ptr(), M, T)

@@ -43,11 +43,15 @@ struct ActD {  // Delta: sqrtR^T is upper triangular, so rows k+1..NM-1 of its c
 // FUSED (round 5): the caller loop `for k { kf.Update(y_k) }` inside one launch (kb_update_steps_dev): x, S and the model (F, H, chol Q,
 // chol R: 81 doubles at 6 / 3) stay in registers over a.nsteps steps, one wave per SIMD; the one-step kernel's source in a loop, with the
 // divisions of the two factorisations and of the 3 x 3 inverse replaced by Newton-refined reciprocals (the kernel is bound by instruction
-// issue: 13.9 -> 15.4 G filter-steps/s, bench.py extra.squareroot.fused).  NOT the one-step kernel's bits: even with the same divisions,
-// T = 1 was bit-identical to one launch for every filter but from the second step on a few filters per thousand ended one last place
-// apart (the two instantiations are contracted into FMAs by the same rules, not in the same context; hiding the inverse's identity from
-// the optimiser did not move it).  Held to 1e-12 against T launches and to the oracle like them (tests/test_kinds_gpu.py).
+// issue: 13.9 -> 15.4 G filter-steps/s, bench.py extra.squareroot.fused).  Not PROMISED to be the one-step kernel's bits (a Newton-refined
+// reciprocal is within an ulp of the quotient, not always equal to it) and held to 1e-12 against T launches and to the oracle like them
+// (tests/test_kinds_gpu.py) -- but since round 6 it IS bit-identical on every batch tried (1000 filters x 6 steps, scripts/diag_sqrt_fused.py):
+// the last-place differences of round 5 came from the compiler contracting `u0 a + x y` in sqr_r() one way round in the one-step
+// instantiation and the other way round in this one; sqr_r now spells its fmas out (kb_static.h).
 // Noiseless, state only, no control.
+#ifndef KB_SQRT_FUSED_FASTDIV
+#define KB_SQRT_FUSED_FASTDIV 1   // (0: diagnostic builds, scripts/diag_sqrt_fused.py -- the time-fused kernel with the one-step kernel's divisions)
+#endif
 template <typename T, int NS, int NM, int NC, bool FULL, bool PAD = false, bool NOISE = false, bool SHARED = false, bool FUSED = false>
 __global__ void __launch_bounds__(64 * SQRT_WPB, (FUSED ? 1 : sqrt_waves<T, NS, NM, FULL, PAD>())) squareroot_reg_kernel(const StepArgs a) {
     static_assert(!FUSED || (!FULL && !PAD && !NOISE && !SHARED && NC == 0), "the time-fused variant: Noiseless, state only, exact shape");
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (FUSED ? 1 : sqrt_waves<T, NS, 
     for (int i = 0; i < NS; i++)
 #pragma unroll
         for (int j = 0; j < NS; j++) C[(NS + i) * NS + j] = (j >= i && j < rn) ? (FUSED ? LQres[symi(i, j)] : ldmo(mo, a.L.mo_LQ + symi(i, j))) : T(0);  // sqrtQ^T[i][j] = L[j][i]
-    sqr_r<T, 2 * NS, NS, ActC<NS>, FUSED>(C);
+    sqr_r<T, 2 * NS, NS, ActC<NS>, FUSED && KB_SQRT_FUSED_FASTDIV>(C);
     __builtin_amdgcn_sched_barrier(0);  // H, chol(R) loads and the Delta panel stay below the C phase
     // Sm[i][j] = C[i*NS+j], j >= i
     T H[NM * NS];
@@ -199,14 +203,14 @@ __global__ void __launch_bounds__(64 * SQRT_WPB, (FUSED ? 1 : sqrt_waves<T, NS, 
 #pragma unroll
     for (int r = 0; r < NM; r++) pin(Hxm[r]);
     __builtin_amdgcn_sched_barrier(0);
-    sqr_r<T, DD, DD, ActD<NM>, FUSED>(D);
+    sqr_r<T, DD, DD, ActD<NM>, FUSED && KB_SQRT_FUSED_FASTDIV>(D);
     // :225-252 Syy = UD[:p,:p]^T, W = UD[:p,p:]^T, K = W Syy^-1 (general inverse, error ignored)
     T Syy[NM * NM], SyyI[NM * NM], K[NS * NM];
 #pragma unroll
     for (int i = 0; i < NM; i++)
 #pragma unroll
         for (int j = 0; j < NM; j++) Syy[i * NM + j] = (j <= i) ? D[j * DD + i] : T(0);
-    inverse_lu<T, NM, FUSED>(Syy, SyyI, rp);
+    inverse_lu<T, NM, FUSED && KB_SQRT_FUSED_FASTDIV>(Syy, SyyI, rp);
 #pragma unroll
     for (int i = 0; i < NS; i++)
 #pragma unroll

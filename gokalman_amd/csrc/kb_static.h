@@ -54,13 +54,17 @@ struct AllRowsActive {
 // which is bound by instruction issue and does not promise the one-step kernel's bits anyway.
 template <typename T, int M, int N, typename ACT = AllRowsActive, bool FASTDIV = false>
 __device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
+    // Every multiply-add below is an EXPLICIT fma: under -ffp-contract=fast the compiler is free to contract `u0 a + x y` either way round,
+    // and it chose differently in two instantiations of the same kernel (the one-step and the time-fused SquareRoot kernel ended a last place
+    // apart from the second step on; found in round 6 by bisecting `#pragma clang fp contract(off)` over the blocks of the step: with it
+    // in THIS function alone the two agree bit for bit -- scripts/diag_sqrt_fused.py, profiles/NOTES.md).  Spelled out, there is no choice left.
     constexpr int KMAX = M < N ? M : N;
 #pragma unroll
     for (int i = 0; i < KMAX; i++) {
         T xnorm2 = T(0);
 #pragma unroll
         for (int r = i + 1; r < M; r++)
-            if (ACT::active(i, r)) xnorm2 += a[r * N + i] * a[r * N + i];
+            if (ACT::active(i, r)) xnorm2 = __builtin_fma(a[r * N + i], a[r * N + i], xnorm2);
         // Dlarfg: beta = -sign(alpha) * dlapy2(alpha, xnorm).  dlapy2 only guards against overflow of the squares;
         // the panels here are covariance square roots, so the plain sqrt of the sum is used (one rounding apart).
         // The reflector is applied in its unnormalised form H = I + f u u^T, u = (alpha - beta, x),
@@ -68,7 +72,7 @@ __device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
         // tau = (beta - alpha) / beta) with one division per column instead of two and no scaling pass.
         const bool refl = (M - i > 1) && (xnorm2 != T(0));
         const T alpha = a[i * N + i];
-        const T beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+        const T beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xnorm2)), alpha);
         const T u0 = alpha - beta;
         const T f = refl ? (FASTDIV ? recip(beta * u0) : T(1) / (beta * u0)) : T(0);
         a[i * N + i] = refl ? beta : alpha;
@@ -77,12 +81,12 @@ __device__ __forceinline__ void sqr_r(T (&a)[M * N]) {
             T s = u0 * a[i * N + c];
 #pragma unroll
             for (int r = i + 1; r < M; r++)
-                if (ACT::active(i, r)) s += a[r * N + i] * a[r * N + c];
+                if (ACT::active(i, r)) s = __builtin_fma(a[r * N + i], a[r * N + c], s);
             const T fs = f * s;
-            a[i * N + c] += fs * u0;
+            a[i * N + c] = __builtin_fma(fs, u0, a[i * N + c]);
 #pragma unroll
             for (int r = i + 1; r < M; r++)
-                if (ACT::active(i, r)) a[r * N + c] += fs * a[r * N + i];
+                if (ACT::active(i, r)) a[r * N + c] = __builtin_fma(fs, a[r * N + i], a[r * N + c]);
         }
     }
 }

@@ -187,7 +187,8 @@ int kb_update_dev(kb_batch *b, const void *meas, int64_t ld_meas,
  * one is: it keeps the one-step kernel's operations).  The Noiseless Vanilla kernel evaluates the Joseph form as
  * P+ = AP - (AP H^T - K R) K^T with AP = P- - K (P- H^T)^T and divides by Newton-refined reciprocals, where the per-step kernel
  * keeps the reference's order of operations (vanilla.go:197-205) and IEEE division; the SquareRoot kernel replaces the divisions of
- * the two factorisations by Newton-refined reciprocals (2.5e-15 from T launches).  All are held to the oracle at 1e-9
+ * the two factorisations by Newton-refined reciprocals (a reciprocal within an ulp of the quotient: not promised to be T launches' bits,
+ * held to 1e-12 of them; in every batch tried since round 6 the bits ARE the same).  All are held to the oracle at 1e-9
  * (tests/test_kinds_gpu.py, bench.py `fused.parity`); on degenerate problems (zero noise matrices) use the per-step call. */
 int kb_update_steps_dev(kb_batch *b, const void *meas, int64_t ld_meas,
                         const void *ctrl, int64_t ld_ctrl, int nsteps);

@@ -796,8 +796,9 @@ def test_update_steps_dev_equals_single_steps(kind, flags, n, p, noise):
         assert b.step() == steps and not b.status().any()
         res.append((b.get(k.STATE), b.get(k.COVAR)))
     if kind == k.SQUAREROOT and n == 6 and p == 3 and noise == k.NOISE_NOISELESS:
-        # the time-fused SquareRoot kernel (round 5): the one-step kernel's source in a loop; a few filters per thousand and step end one
-        # last place apart (csrc/kb_squareroot_reg.hip), so: the same to 1e-12, and most filters the same bits
+        # the time-fused SquareRoot kernel (round 5): the one-step kernel's source in a loop with Newton reciprocals (within an ulp of the
+        # quotient), so the PROMISE is 1e-12.  Round 5 saw a few filters per thousand a last place apart; round 6 found the cause (the
+        # compiler contracted sqr_r()'s `u0 a + x y` differently in the two instantiations) and spelled the fmas out: the same bits since
         ex, eP = synth.rel_frobenius(res[0][0], res[1][0]), synth.rel_frobenius(res[0][1], res[1][1])
         same = np.mean(np.all(res[0][0] == res[1][0], axis=1))
         print("fused SquareRoot against %d launches: state %.2e covariance %.2e, %.1f %% of the filters bit-identical" % (steps, ex, eP, 100 * same))
