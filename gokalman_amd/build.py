@@ -68,45 +68,81 @@ def _compile(src, force):
             same_cmd = open(cmdf).read() == " ".join(cmd)
         except OSError:
             same_cmd = False
-        if deps and same_cmd and all(os.path.exists(d) and os.path.getmtime(d) < os.path.getmtime(obj) for d in deps):
+        if deps and same_cmd and all(os.path.exists(d) and os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
             return obj
     t0 = time.perf_counter()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))
-    with open(cmdf, "w") as fh:
+    with open(cmdf + ".tmp", "w") as fh:   # (written behind the compile, through a rename: an interrupted build leaves no .cmd that vouches for a stale .o)
         fh.write(" ".join(cmd))
+    os.replace(cmdf + ".tmp", cmdf)
     _TIMES[base] = time.perf_counter() - t0
     return obj
 
 
 _TIMES = {}   # seconds per translation unit compiled by this process (printed by --times)
 
-# translation units that take the longest to compile (seconds on this image), for the scheduling order of a build from scratch
-_SLOW = {"kb_srif_pair32g.hip": 82, "kb_srif_pair32c.hip": 66, "kb_srif_pair32e.hip": 63, "kb_srif_pair32f.hip": 59, "kb_srif_pair32b.hip": 48,
-         "kb_srif_pair64.hip": 44, "kb_srif_split_e.hip": 44, "kb_srif_split_f32d.hip": 42, "kb_squareroot_split16p.hip": 41, "kb_srif_split_d.hip": 40,
-         "kb_srif_split_f32c.hip": 35, "kb_srif_split_c.hip": 35, "kb_information_reg.hip": 34, "kb_srif_split_b.hip": 33, "kb_squareroot_split12p.hip": 33,
-         "kb_vanilla_shared.hip": 30}
+# Scheduling order of a build from scratch: longest translation unit first.  The seconds come from the previous build of this tree
+# (csrc/_obj/times.json, written below); without one, from the object / source sizes.
+def _recorded_times():
+    try:
+        import json
+        with open(os.path.join(OBJ, "times.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
 
 
-def _cost(src):
+def _cost(src, rec):
     base = os.path.basename(src)
     obj = os.path.join(OBJ, base + ".o")
-    if base in _SLOW:
-        return _SLOW[base] * 1e6
+    if base in rec:
+        return rec[base] * 1e6
     return os.path.getsize(obj) if os.path.exists(obj) else os.path.getsize(src)
 
 
+STAMP = LIB + ".srchash"   # hash of (kernel sources, headers, flags, KB_EXTRA_DEFS) the library was linked from
+
+
+def _source_stamp():
+    from . import roofline as rl
+    return rl.kernel_source_hash(os.path.dirname(HERE)) + "|" + os.environ.get("KB_EXTRA_DEFS", "")
+
+
 def build(force=False, verbose=False):
+    # The shipped library next to unchanged sources (a checkout that stamps every file alike, a GPU box that got the .so but not
+    # csrc/_obj/): nothing to do -- judged by CONTENT, not by modification times.
+    stamp = _source_stamp()
+    if not force and os.path.exists(LIB):
+        try:
+            if open(STAMP).read() == stamp:
+                if verbose:
+                    print("built", LIB, "(up to date: source hash)")
+                return LIB
+        except OSError:
+            pass
     os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")), key=_cost, reverse=True)   # longest first: the tail of the build is not one late giant
+    rec = _recorded_times()
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")), key=lambda s_: _cost(s_, rec), reverse=True)   # longest first: the tail of the build is not one late giant
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if (force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
-        cmd = [_hipcc(), "-shared", "-fPIC", "-s", "--offload-arch=" + ARCH, "-o", LIB] + objs   # (-s: no host symbol table; the C ABI is in .dynsym, the kernels' names in the code objects)
+        # -s: no host symbol table (the C ABI is in .dynsym, the kernels' names in the code objects); kept out of diagnostic builds
+        # (KB_EXTRA_DEFS / KB_DEBUG_SYMBOLS set), where host backtraces matter
+        strip = [] if (os.environ.get("KB_EXTRA_DEFS") or os.environ.get("KB_DEBUG_SYMBOLS")) else ["-s"]
+        cmd = [_hipcc(), "-shared", "-fPIC"] + strip + ["--offload-arch=" + ARCH, "-o", LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s" % res.stderr[-4000:])
+    if _TIMES:
+        import json
+        rec.update(_TIMES)
+        with open(os.path.join(OBJ, "times.json"), "w") as fh:
+            json.dump(rec, fh)
+    with open(STAMP + ".tmp", "w") as fh:
+        fh.write(stamp)
+    os.replace(STAMP + ".tmp", STAMP)
     if verbose:
         print("built", LIB)
     return LIB

@@ -853,7 +853,9 @@ int launch_chisq(const Batch &tb, const ChiArgs &a, int n, int p, int nc, void *
     // (6,3) with ONE filter fanned out runs the shared-covariance path as well: 10.6 G run-steps/s against 7.5 G on the fused kernel, which
     // holds a whole Vanilla update per lane in 512 registers at one wave per SIMD (256k runs x 200 steps); the smaller fused shapes stay
     // ((4,2): 22.3 G fused against 24.0 G shared at 1M runs x 1086 steps, 21.2 against 16.5 at 256k x 200 -- the serial recursion's share)
-    const bool shared_63 = shared_table && n == 6 && p == 3;
+    // ... from ~128k runs on: the recursion is SERIAL in one workgroup (~10 us per step whatever the ensemble), the fused kernel's step costs
+    // N / 7.5 G -- below ~160k runs the fused kernel is ahead ((4,2): 21.2 G fused against 16.5 G shared at 256k x 200)
+    const bool shared_63 = shared_table && n == 6 && p == 3 && a.N >= (int64_t(1) << 17);
     if (tb.dtype == KB_F64 && !(shared_all && shared_table) && !shared_63)
         ok = chi_try<double, 2, 1>(tb, a, n, p, nc) || chi_try<double, 3, 1>(tb, a, n, p, nc) || chi_try<double, 4, 2>(tb, a, n, p, nc) ||
              chi_try<double, 6, 3>(tb, a, n, p, nc);

@@ -504,8 +504,9 @@ __global__ void __launch_bounds__(KB_VANILLA_WPB * 64, (FUSED || (PAD && sizeof(
 #pragma unroll
         for (int e = 0; e < TR; e++) chk += Pn[e] * T(0);
         if (chk != chk) err |= KB_ST_NONFINITE;
-        if (err_acc) err = 0;  // already frozen: keep the first failure only
-        const bool ok = (err | err_acc) == 0;
+        // a failed step leaves (x, P) and kf.step as they were -- for THAT step only: the next one runs normally, as T calls of the
+        // one-step kernel do (the fused loop used to freeze a filter at its first failure; the fused SquareRoot kernel did not)
+        const bool ok = err == 0;
         err_acc |= err;
         nfail += ok ? 0u : 1u;   // vanilla.go:164-167, :207-215 return before kf.step++ (:218)
 

@@ -838,13 +838,14 @@ def test_shared_model_squareroot_and_information_equal_the_per_filter_batch(kind
     run(2 * steps)
 
 
-@pytest.mark.parametrize("n,p,m", [(12, 6, 0), (9, 3, 1), (16, 8, 2), (7, 2, 0)])
-def test_chisquare_shared_covariance_path_equals_the_per_run_kernel(n, p, m):
+@pytest.mark.parametrize("n,p,m,runs,steps", [(12, 6, 0, 300, 12), (9, 3, 1, 300, 12), (16, 8, 2, 300, 12), (7, 2, 0, 300, 12),
+                                              (6, 3, 0, 300, 12),            # small ensemble at the fused shape: the fused kernel
+                                              (6, 3, 0, 1 << 17, 5)])        # ... from 128k runs on: the shared-covariance path
+def test_chisquare_shared_covariance_path_equals_the_per_run_kernel(n, p, m, runs, steps):
     """NewChiSquare beyond (6,3) (round 5): with ONE filter fanned out the covariance recursion runs once (chisq_cov_kernel) and a lane
     advances only the two states (chisq_shared_kernel); a batch given N per-run copies of the same model takes the per-run kernel
     (chisq_gen_kernel: the whole Update per lane).  Same draws, same sums: the NIS / NEES means agree to rounding."""
     rng = np.random.default_rng(77 * n + p)
-    runs, steps = 300, 12
     F = np.eye(n) + 0.05 * rng.standard_normal((n, n)); H = rng.standard_normal((p, n)); G = 0.3 * rng.standard_normal((n, m)) if m else None
     A = 0.1 * rng.standard_normal((n, n)); Q = A @ A.T + 1e-3 * np.eye(n)
     B = 0.2 * rng.standard_normal((p, p)); R = B @ B.T + 1e-2 * np.eye(p)
@@ -860,3 +861,44 @@ def test_chisquare_shared_covariance_path_equals_the_per_run_kernel(n, p, m):
     (nis_s, nees_s), (nis_g, nees_g) = out
     assert np.all(np.isfinite(nis_s)) and np.all(np.isfinite(nees_s)) and nis_s.min() > 0
     assert np.allclose(nis_s, nis_g, rtol=1e-10) and np.allclose(nees_s, nees_g, rtol=1e-9), (np.max(np.abs(nis_s / nis_g - 1)), np.max(np.abs(nees_s / nees_g - 1)))
+
+
+@pytest.mark.parametrize("kind,noise", [(k.VANILLA, k.NOISE_AWGN), (k.VANILLA, k.NOISE_BATCH), (k.VANILLA, k.NOISE_NOISELESS), (k.SQUAREROOT, k.NOISE_NOISELESS)])
+def test_time_fused_launch_skips_only_the_failed_step_like_single_steps(kind, noise):
+    """a non-finite measurement in the MIDDLE of a fused sequence fails that step for that filter only (vanilla.go:207-215
+    returns before anything is assigned and before kf.step++) -- the next step runs normally, exactly as T calls of kb_update_dev do: same
+    state, same per-filter kf.step, same status (the fused Vanilla loop used to freeze a filter at its first failure)."""
+    import torch
+    N, steps, n, p = 300, 6, 6, 3
+    d = synth.linear_batch(N, n, p, steps, seed=91)
+    yy = d["y"].copy()
+    yy[2, 17, 1] = np.nan; yy[2, 200, 0] = np.inf; yy[4, 17, 2] = np.nan    # filter 17 fails steps 2 and 4, filter 200 step 2
+    y = torch.from_numpy(np.ascontiguousarray(yy.transpose(0, 2, 1))).cuda()
+    Q, R = (np.zeros((n, n)), np.zeros((p, p))) if noise == k.NOISE_BATCH else (d["Q"], d["R"])
+    rng = np.random.default_rng(3)
+    proc, meas = 1e-2 * rng.standard_normal((steps, n)), 1e-2 * rng.standard_normal((steps, p))
+    res = []
+    for fused in (True, False):
+        b = ga.FilterBatch.new_ldkf(kind, d["x0"], d["P0"], d["F"], None, d["H"], Q, R, nfilters=N,
+                                    noise=(k.NOISE_AWGN if noise == k.NOISE_AWGN else k.NOISE_NOISELESS), seed=5)
+        if noise == k.NOISE_BATCH:
+            b.set_batch_noise(proc, meas)
+        if fused:
+            b.update_steps_dev(y.data_ptr(), N, steps)
+        else:
+            for t in range(steps):
+                b.update_dev(y[t].data_ptr(), N)
+        b.synchronize()
+        res.append((b.get(k.STATE), b.get(k.COVAR), b.status().copy(), [b.filter_step(i) for i in (16, 17, 18, 200)]))
+    # (SquareRoot.Update has no error return behind its dimension checks -- squareroot.go:244-247 looks at `err`, not `invErr` -- so
+    # kf.step advances on every call; the engine keeps the last finite (x, S) and flags the filter: both paths alike)
+    assert res[0][3] == res[1][3] == ([steps] * 4 if kind == k.SQUAREROOT else [steps, steps - 2, steps, steps - 1])
+    assert np.array_equal(res[0][2] != 0, res[1][2] != 0) and sorted(np.nonzero(res[0][2])[0].tolist()) == [17, 200]
+    assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][1]).all()
+    if kind == k.VANILLA and noise == k.NOISE_NOISELESS:   # (a different evaluation of the Joseph form: include/gokalman_amd.h)
+        assert synth.rel_frobenius(res[0][0], res[1][0]) <= 1e-9 and synth.rel_frobenius(res[0][1], res[1][1]) <= 1e-9
+    elif kind == k.SQUAREROOT:
+        assert synth.rel_frobenius(res[0][0], res[1][0]) <= 1e-12 and synth.rel_frobenius(res[0][1], res[1][1]) <= 1e-12
+    else:
+        assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
+        assert np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
