@@ -241,6 +241,10 @@ type batchHolder interface{ handle() *batch }
 
 func (kf *ldkf) handle() *batch { return kf.b }
 
+// LastKernel names the kernel instantiation(s) the last Update of this filter ran on (kb_last_kernel: a debugging / reporting aid with
+// no counterpart in kalman.go:35-72).
+func LastKernel(kf batchHolder) string { return C.GoString(C.kb_last_kernel(kf.handle().h)) }
+
 // Update implements LDKF.Update (vanilla.go:128-220, squareroot.go:129-274, information.go:153-227): one launch of the HIP
 // step kernel, then one snapshot.
 func (kf *ldkf) Update(measurement, control *mat64.Vector) (gokalman.Estimate, error) {

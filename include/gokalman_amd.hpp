@@ -362,6 +362,7 @@ class LDKF {
     std::string String(int64_t f = 0) const {
         return "F=" + Formatted(F_, "  ", f) + "\nG=" + Formatted(G_, "  ", f) + "\nH=" + Formatted(H_, "  ", f) + "\n" + noise_.String();
     }
+    std::string LastKernel() const { return kb_last_kernel(b_->handle()); }   // which instantiation(s) served the last step (debugging aid)
     int64_t Step() const { return kb_step(b_->handle()); }
     std::shared_ptr<Batch> batch() const { return b_; }
 

@@ -7,6 +7,8 @@ P0 = 10) there is an answer to "which one is closer to the exact result":
 
   hybrid_update      hybrid.go:104-204      (CKF and EKF; Prepare()d Phi / Htilde per step, no SNC)
   vanilla_update     vanilla.go:128-220     with BatchNoise (noise.go:67-106: recorded vectors, ZERO Q and R matrices)
+  srif_update        srif.go:101-160, :298-340, helper.go:142-172  (time update + whitening + HouseholderTransf: a second, independent
+                                             reading beside the oracle's -- no reference fixture reaches the time update)
   squareroot_update  squareroot.go:129-274  (QR with LAPACK's dlarfg sign convention: with the reference's untransposed Uc the
                                              result DEPENDS on the signs of R's diagonal, so the convention is part of the algorithm)
 
@@ -172,6 +174,83 @@ def squareroot_update(x, S, F, H, sqrtQ, sqrtR, y):
     return xp, SplusT.T
 
 
+def srif_init(x0, P0, R):
+    """srif.go:14-49: I0 = diag(1 / P0_ii), R0 = chol_L(I0), b0 = R0 x0; QUIRK :47: the filter keeps chol_L(R) (sqrtMeasNoise) in the field
+    named sqrtInvNoise -- the inverse formed at :41-44 is discarded."""
+    n = P0.rows
+    I0 = mp.matrix(n, n)
+    for i in range(n):
+        I0[i, i] = 1 / P0[i, i]
+    R0 = mp.cholesky(I0)
+    return R0 * x0, R0, mp.cholesky(R)
+
+
+def householder_transf(A, n, m):
+    """helper.go:142-172, Sign() of :133-138 with its 1e-12 dead band."""
+    for k in range(n):
+        sigma = mp.sqrt(mp.fsum(A[i, k] ** 2 for i in range(k, m + n)))
+        akk = A[k, k]
+        sigma *= mp.mpf(1) if abs(akk) <= mp.mpf("1e-12") else mp.sign(akk)
+        u = [mp.mpf(0)] * (m + n)
+        u[k] = akk + sigma
+        A[k, k] = -sigma
+        for i in range(k + 1, m + n):
+            u[i] = A[i, k]
+        beta = 1 / (sigma * u[k])
+        for j in range(k + 1, n + 1):
+            gamma = mp.fsum(u[i] * A[i, j] for i in range(k, m + n)) * beta
+            for i in range(k, m + n):
+                A[i, j] -= gamma * u[i]
+            for i in range(k + 1, m + n):
+                A[i, k] = mp.mpf(0)
+
+
+def srif_update(b, R, Phi, Ht, L, real, comp):
+    """srif.go:101-160 (Update) with measurementSRIFUpdate :298-340.  Returns (b_k, R_k)."""
+    n, m = b.rows, real.rows
+    invPhi = mp.inverse(Phi)                                 # :111-114
+    RBar = R * invPhi                                        # :115
+    xBar = Phi * (mp.inverse(R) * b)                         # :117-118, State() :223-234
+    bBar = RBar * xBar                                       # :119
+    y = L * (real - comp)                                    # :143-148
+    Hw = L * Ht
+    A = mp.matrix(m + n, n + 1)                              # :309-321
+    for i in range(n):
+        for j in range(n):
+            A[i, j] = RBar[i, j]
+        A[i, n] = bBar[i]
+    for i in range(m):
+        for j in range(n):
+            A[n + i, j] = Hw[i, j]
+        A[n + i, n] = y[i]
+    householder_transf(A, n, m)                              # :323
+    return A[0:n, n:n + 1], A[0:n, 0:n]                      # :326-331
+
+
+def gen_srif(name, n, p, N=32, T=10, seed=77):
+    """config E's problem (bench.py's generator: Phi = I + 1e-2 randn, Htilde = randn, R diagonal 1e-4 .. 1e-2, P0 = diag(10.., 1..)) in
+    fp64 inputs: a SECOND, independent reading of srif.go for the oracle's SRIF (whose time update no reference fixture reaches:
+    srif_test.go needs the external `smd` package) and the exact answer the fp32 kernel's achieved error is quoted against."""
+    rng = np.random.default_rng(seed)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = np.concatenate([np.full(n // 2, 10.0), np.full(n - n // 2, 1.0)])
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((T, N, n, n))
+    Ht = rng.standard_normal((T, N, p, n))
+    real = rng.standard_normal((T, N, p)); comp = real + 1e-2 * rng.standard_normal((T, N, p))
+    # (the fp32 kernels get these very values: rounded to fp32 first, so that fp32 and fp64 runs see the same problem)
+    Phi, Ht, real, comp = [a.astype(np.float32).astype(np.float64) for a in (Phi, Ht, real, comp)]
+    bs, Rs = np.zeros((T, N, n)), np.zeros((T, N, n, n))
+    for i in range(N):
+        b, Rm, L = srif_init(M(x0[i]), M(P0[i]), M(R[i]))
+        for t in range(T):
+            b, Rm = srif_update(b, Rm, M(Phi[t, i]), M(Ht[t, i]), L, M(real[t, i]), M(comp[t, i]))
+            bs[t, i], Rs[t, i] = to_np(b)[:, 0], to_np(Rm)
+    np.savez_compressed(os.path.join(OUT, name + "_hp.npz"), x0=x0, P0=P0, R=R, Phi=Phi, Ht=Ht, real=real, comp=comp, b=bs, Rk=Rs,
+                        digits=np.array(mp.mp.dps))
+    print(name, "done")
+
+
 def rows(a):
     return [M(v) for v in a]
 
@@ -273,6 +352,8 @@ if __name__ == "__main__":
         "hybrid_ekf_bench_6x2": lambda: gen_hybrid("hybrid_ekf_bench_6x2", "bench", True),
         "hybrid_ckf_bench_6x2": lambda: gen_hybrid("hybrid_ckf_bench_6x2", "bench", False),
         "hybrid_ekf_stm_6x2": lambda: gen_hybrid("hybrid_ekf_stm_6x2", "stm", True),
+        "srif_12x6": lambda: gen_srif("srif_12x6", 12, 6),
+        "srif_7x3": lambda: gen_srif("srif_7x3", 7, 3, N=16, T=8),
         "vanilla_batchnoise_6x3": lambda: gen_batchnoise("vanilla_batchnoise_6x3", 6, 3),
         "vanilla_batchnoise_12x6": lambda: gen_batchnoise("vanilla_batchnoise_12x6", 12, 6),
     }

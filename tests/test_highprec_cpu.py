@@ -63,3 +63,23 @@ def test_oracle_error_on_the_ill_conditioned_linear_twin():
         eP = max(hp.rel_err(Ps[t], z["P_" + name][t]).max() for t in range(xs.shape[0]))
         print("ldkf_illcond %s: oracle vs exact x %.2e P %.2e" % (name, ex, eP))
         assert ex <= tol and eP <= tol
+
+
+@pytest.mark.parametrize("name", ["srif_12x6", "srif_7x3"])
+def test_two_independent_readings_of_srif_go_agree(name):
+    """srif.go:101-160 has no reference fixture that runs without the external `smd` package (srif_test.go:11): the oracle's C restatement
+    and the 60-digit Python restatement of tests/golden/make_highprec.py were written independently from the Go source (time update,
+    the chol_L(R) quirk of :47, whitening, HouseholderTransf with Sign()'s dead band) -- on config E's generator they agree to rounding."""
+    z = hp.load(name)
+    T, N = z["Phi"].shape[:2]
+    p = z["real"].shape[2]
+    eb = eR = 0.0
+    for i in range(N):
+        f = orc.Filter.srif(z["x0"][i], z["P0"][i], z["R"][i], p)
+        for t in range(T):
+            f.prepare(z["Phi"][t, i], z["Ht"][t, i])
+            assert f.update_nl(z["real"][t, i], z["comp"][t, i]) == orc.OK
+            eb = max(eb, float(np.linalg.norm(f.raw_vec() - z["b"][t, i]) / np.linalg.norm(z["b"][t, i])))
+            eR = max(eR, float(np.linalg.norm(f.raw_mat() - z["Rk"][t, i]) / np.linalg.norm(z["Rk"][t, i])))
+    print("%s: oracle against the 60-digit restatement: b %.2e R %.2e" % (name, eb, eR))
+    assert eb <= 1e-13 and eR <= 1e-13

@@ -119,3 +119,34 @@ def test_batch_noise_up_to_n_measurements_engine_error_within_4x_the_oracles(nam
     p0 = np.linalg.norm(z["P0"].reshape(N, -1), axis=1)
     _judge("%s %s" % (name, entry), _worst_step(xs, z["x"][:steps]), _worst_step(Ps, z["P"][:steps], p0),
            _worst_step(xo[:steps], z["x"][:steps]), _worst_step(Po[:steps], z["P"][:steps], p0))
+
+
+@pytest.mark.parametrize("name,dtype,bound", [("srif_12x6", k.F64, None), ("srif_7x3", k.F64, None), ("srif_12x6", k.F32, 2e-5), ("srif_7x3", k.F32, 2e-5)])
+def test_srif_against_the_exact_result(name, dtype, bound):
+    """config E's problem against the 60-digit restatement of srif.go:101-160: fp64 kernels (two-lane 12/6, split 7/3) within 4 x the
+    oracle's error; the fp32 kernels' ACHIEVED error against the exact result (inputs are fp32-representable), bound 2e-5."""
+    z = hp.load(name)
+    T, N = z["Phi"].shape[:2]
+    n, p = z["x0"].shape[1], z["real"].shape[2]
+    b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=dtype)
+    b.set(k.X, z["x0"], 1); b.set(k.P, z["P0"], 2); b.set(k.R, z["R"], 2, p_rows=p); b.init()
+    eb, eR = np.zeros((T, N)), np.zeros((T, N))
+    for t in range(T):
+        b.prepare(z["Phi"][t], z["Ht"][t])
+        b.update_nl(z["real"][t], z["comp"][t])
+        eb[t], eR[t] = hp.rel_err(b.get(k.RAW_VEC), z["b"][t]), hp.rel_err(b.get(k.RAW_MAT), z["Rk"][t])
+    assert not b.status().any()
+    print("%s %s on %s: engine vs exact b max %.2e median %.2e, R max %.2e median %.2e" % (name, "fp64" if dtype == k.F64 else "fp32", b.last_kernel(),
+                                                                                           eb.max(), np.median(eb), eR.max(), np.median(eR)))
+    if bound is not None:
+        assert within(float(eb.max()), bound, label="fp32 b") and within(float(eR.max()), bound, label="fp32 R")
+        return
+    ob, oR = np.zeros((T, N)), np.zeros((T, N))
+    for i in range(N):
+        f = orc.Filter.srif(z["x0"][i], z["P0"][i], z["R"][i], p)
+        for t in range(T):
+            f.prepare(z["Phi"][t, i], z["Ht"][t, i])
+            assert f.update_nl(z["real"][t, i], z["comp"][t, i]) == orc.OK
+            ob[t, i] = np.linalg.norm(f.raw_vec() - z["b"][t, i]) / np.linalg.norm(z["b"][t, i])
+            oR[t, i] = np.linalg.norm(f.raw_mat() - z["Rk"][t, i]) / np.linalg.norm(z["Rk"][t, i])
+    _judge("%s fp64" % name, eb.max(axis=0), eR.max(axis=0), ob.max(axis=0), oR.max(axis=0))
