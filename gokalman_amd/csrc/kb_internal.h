@@ -239,6 +239,7 @@ void launch_srif_split_f32_n5(const Batch &b, const StepArgs &a);
 void launch_srif_split_f32_n7(const Batch &b, const StepArgs &a);
 void launch_srif_split_f32_n9(const Batch &b, const StepArgs &a);
 void launch_srif_split_f32_n11(const Batch &b, const StepArgs &a);
+void launch_srif_split_f32_n12(const Batch &b, const StepArgs &a);   // (diagnostic builds only: -DKB_DIAG_SRIF_F32_N12)
 void launch_srif_split_f32_n13(const Batch &b, const StepArgs &a);
 void launch_srif_split_f32_n14(const Batch &b, const StepArgs &a);
 void launch_srif_split_f32_n15(const Batch &b, const StepArgs &a);

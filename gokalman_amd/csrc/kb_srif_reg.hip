@@ -210,6 +210,9 @@ bool srif_split_ok(const Batch &b, const StepArgs &a) {
         // n < 6 (round 4: widened shadow copies, ~2x the bytes: 7/3 116 us, 11/4 258 us), Predict() and p = 7, 8 at 14 / 16 states
         // (round 4: the statement kernel) -- runs the split kernel on four lanes per filter
         if ((a.n & 1) || a.n < 6) return true;
+#ifdef KB_DIAG_SRIF_F32_N12
+        if (a.n == 12 && a.p == 6 && !a.predict && srif_split_all()) return true;
+#endif
         // (p = 7, 8 at the even n up to 12 stays two-lane: 6/8 45 us against 74 on the split kernel, 8/8 57 / 87, 10/8 83 / 159, 12/8 116 / 172)
         return a.n > 12 && (a.predict || a.p > 6);
     }
@@ -227,7 +230,13 @@ static int launch_srif_split(const Batch &b, const StepArgs &a) {
                                       launch_srif_split_n16};
     static const launch_t by_n32[17] = {nullptr, launch_srif_split_f32_n1, launch_srif_split_f32_n2, launch_srif_split_f32_n3, launch_srif_split_f32_n4,
                                         launch_srif_split_f32_n5, nullptr, launch_srif_split_f32_n7, nullptr, launch_srif_split_f32_n9, nullptr,
-                                        launch_srif_split_f32_n11, nullptr, launch_srif_split_f32_n13, launch_srif_split_f32_n14, launch_srif_split_f32_n15,
+                                        launch_srif_split_f32_n11,
+#ifdef KB_DIAG_SRIF_F32_N12
+                                        launch_srif_split_f32_n12,
+#else
+                                        nullptr,
+#endif
+                                        launch_srif_split_f32_n13, launch_srif_split_f32_n14, launch_srif_split_f32_n15,
                                         launch_srif_split_f32_n16};
     (b.dtype == KB_F32 ? by_n32 : by_n)[a.n](b, a);
     KB_HIP(hipGetLastError());

@@ -673,9 +673,15 @@ __device__ __forceinline__ void srif_split_part(const StepArgs &a, const int64_t
 }
 
 template <typename T, int N, int NM, int L>
-__global__ void __launch_bounds__(64, (N <= 8 && NM <= 4) ? 3 : 2) srif_split_kernel(const StepArgs a) {
+#ifndef KB_SRIF_SPLIT_WAVES
+#define KB_SRIF_SPLIT_WAVES ((N <= 8 && NM <= 4) ? 3 : 2)   // (a number: diagnostic builds)
+#endif
+__global__ void __launch_bounds__(64, KB_SRIF_SPLIT_WAVES) srif_split_kernel(const StepArgs a) {
     __shared__ __attribute__((aligned(16))) T lds[srif_split_lds_elems<(N + L - 1) / L * L, NM, L>()];
-    srif_split_part<T, N, NM, L>(a, split_part_of_block<L>(blockIdx.x, gridDim.x), lds);
+    // (a part that is HALF a 128-byte line -- eight lanes in fp64, four in fp32 -- shares every line with its neighbour: the two run on the same XCD,
+    // kb_vanilla_split.h split_part_of_block; round 6: the fp32 kernels read 1.96x their bytes until this applied to them as well)
+    constexpr int PAIRING = (64 / L) * (int)sizeof(T) < 128 ? 8 : 4;
+    srif_split_part<T, N, NM, L>(a, split_part_of_block<PAIRING>(blockIdx.x, gridDim.x), lds);
 }
 
 // fp64: four lanes per filter up to 12 states, eight beyond (LDS: (NS^2 + NS) elements per filter; registers: NS / L rows of 2 NS values).

@@ -6,5 +6,8 @@ namespace kb {
 
 KB_SRIF_SPLIT_TU_F32(9)
 KB_SRIF_SPLIT_TU_F32(11)
+#ifdef KB_DIAG_SRIF_F32_N12   // diagnostic builds only (profiles/NOTES.md round 6): config E on FOUR lanes per filter, against the two-lane kernel
+void launch_srif_split_f32_n12(const Batch &b, const StepArgs &a) { srif_split_launch<float, 12, 6>(b, a); }
+#endif
 
 }  // namespace kb

@@ -273,8 +273,8 @@ if "srifpad" in which:
                 k.check(k.lib().kb_prepare_dev(b._h, Phi.data_ptr(), Ht.data_ptr(), N))
                 k.check(k.lib().kb_update_nl_dev(b._h, real.data_ptr(), comp.data_ptr(), N))
             ms = timed(b, step, K=10 if not flags else 3, warm=3 if not flags else 1)
-            report("SRIF %d/%d %s, %s (prepare_dev + update_nl_dev)" % (n, p, "f32" if "--srif-f32" in sys.argv else "f64", "register kernel" if not flags else nm), N, ms, rl.algorithmic_bytes("srif", n, p), {"errors": int(np.count_nonzero(b.status()))},
-                   moved=rl.moved_bytes("srif", n, p))
+            report("SRIF %d/%d %s, %s (prepare_dev + update_nl_dev)" % (n, p, "f32" if "--srif-f32" in sys.argv else "f64", "register kernel" if not flags else nm), N, ms, rl.algorithmic_bytes("srif", n, p, 4 if "--srif-f32" in sys.argv else 8), {"errors": int(np.count_nonzero(b.status()))},
+                   moved=rl.moved_bytes("srif", n, p, 4 if "--srif-f32" in sys.argv else 8))
             del b
 
 if "hybrid" in which:
