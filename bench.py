@@ -336,6 +336,54 @@ def _hybrid_arbiter(ga, k):
             "rule": "engine error <= %g x oracle error + %g, worst and median filter (worst step of each)" % (hp.FACTOR, hp.FLOOR), "ok": bool(ok)}
 
 
+def _srif_fused_parity(ga, k):
+    """kb_update_nl_steps_dev against T single Prepare + Update calls on the same arrays (4096 filters x 10 steps): the same bits; and the
+    fp32 result against the fp64 oracle within SRIF_F32_TOL."""
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    N, T, n, p = 4096, 10, 12, 6
+    rng = np.random.default_rng(123)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    Phi = (torch.eye(n, dtype=torch.float32, device="cuda").reshape(1, n * n, 1) + 1e-2 * torch.randn(T, n * n, N, dtype=torch.float32, device="cuda", generator=g)).contiguous()
+    Ht = torch.randn(T, p * n, N, dtype=torch.float32, device="cuda", generator=g)
+    real = torch.randn(T, p, N, dtype=torch.float32, device="cuda", generator=g)
+    comp = (real + 1e-2 * torch.randn(T, p, N, dtype=torch.float32, device="cuda", generator=g)).contiguous()
+    torch.cuda.synchronize()
+    outs = []
+    for fused in (True, False):
+        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=k.F32)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        if fused:
+            b.update_nl_steps_dev(Phi.data_ptr(), Ht.data_ptr(), N, n * n * N, p * n * N, real.data_ptr(), comp.data_ptr(), N, p * N, T)
+            kernel = b.last_kernel()
+        else:
+            for t in range(T):
+                k.check(k.lib().kb_prepare_dev(b._h, Phi[t].data_ptr(), Ht[t].data_ptr(), N))
+                k.check(k.lib().kb_update_nl_dev(b._h, real[t].data_ptr(), comp[t].data_ptr(), N))
+        b.synchronize()
+        outs.append((b.get(k.RAW_MAT), b.get(k.RAW_VEC), int(np.count_nonzero(b.status()))))
+    same = bool(np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64)) and np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64)))
+    M = 256
+    fs = [orc.Filter.srif(x0[i], P0[i], R[i], p) for i in range(M)]
+    Ph, Hh = Phi[:, :, :M].double().cpu().numpy(), Ht[:, :, :M].double().cpu().numpy()
+    rh, ch = real[:, :, :M].double().cpu().numpy(), comp[:, :, :M].double().cpu().numpy()
+    nerr = 0
+    for t in range(T):
+        for i, f in enumerate(fs):
+            f.prepare(Ph[t, :, i].reshape(n, n), Hh[t, :, i].reshape(p, n))
+            nerr += f.update_nl(rh[t, :, i], ch[t, :, i]) != orc.OK
+    from gokalman_amd import synth
+    eR = synth.rel_frobenius(outs[0][0][:M], np.array([f.raw_mat() for f in fs]))
+    eb = synth.rel_frobenius(outs[0][1][:M], np.array([f.raw_vec() for f in fs]))
+    return {"filters": N, "steps": T, "kernel": kernel, "bit_identical_to_single_steps": same, "oracle_filters": M, "achieved_max_rel_frobenius_R": eR,
+            "achieved_max_rel_frobenius_b": eb, "tolerance": SRIF_F32_TOL,
+            "ok": bool(same and eR <= SRIF_F32_TOL and eb <= SRIF_F32_TOL and nerr == 0 and outs[0][2] == 0 and "fused" in kernel)}
+
+
 SRIF_F32_TOL = 2e-5   # tests/test_srif_gpu.py uses the same figure (achieved: ~1.3e-6 on R, ~2.7e-6 on b)
 
 
@@ -901,6 +949,28 @@ def main():
                               "roofline": rl.hbm_roofline(rms, M, 576 * 4, rl.moved_bytes("srif_pair", sn, sp, 4),
                                                           *rl.load_traffic(ROOT, "srif_pair_kernel<float, 12, 6, false, true")),
                               "filters_with_error_status": rbad}
+        if args.fused_steps > 0 and rank == 0:
+            # config E with the caller loop `for k { Prepare(Phi_k, Htilde_k); Update(real_k, computed_k) }` inside ONE launch (round 6,
+            # kb_update_nl_steps_dev): distinct Phi / Htilde / observations per step, (b, R) resident in registers between the steps; the
+            # same bits as T single calls (tests/test_srif_gpu.py, and `parity` below)
+            TF = 20
+            gF = torch.Generator(device=dev); gF.manual_seed(13)
+            PhiT = (torch.eye(sn, dtype=torch.float32, device=dev).reshape(1, sn * sn, 1)
+                    + 1e-2 * torch.randn(TF, sn * sn, M, dtype=torch.float32, device=dev, generator=gF)).contiguous()
+            HtT = torch.randn(TF, sp * sn, M, dtype=torch.float32, device=dev, generator=gF)
+            realT = torch.randn(TF, sp, M, dtype=torch.float32, device=dev, generator=gF)
+            compT = realT + 1e-2 * torch.randn(TF, sp, M, dtype=torch.float32, device=dev, generator=gF)
+            torch.cuda.synchronize()
+
+            def fstep():
+                sb.update_nl_steps_dev(PhiT.data_ptr(), HtT.data_ptr(), M, sn * sn * M, sp * sn * M, realT.data_ptr(), compT.data_ptr(), M, sp * M, TF)
+            f_s, fms, fbad = timed_leg(sb, fstep, 10)
+            moved_f = rl.moved_bytes("srif_pair", sn, sp, 4) - 4 * (sn + rl.tri(sn) + sn // 2)   # the own rows of (b, R) are not re-read
+            extra["srif_fp32"]["fused"] = {"config": "the caller loop inside one launch (kb_update_nl_steps_dev): %d steps per launch, distinct Phi / Htilde / observations per step" % TF,
+                                           "steps_per_launch": TF, "ms_per_launch": fms, "kernel_ms": fms / TF, "value": M * TF / (fms * 1e-3),
+                                           "unit": "filter-update steps/s (1 GPU, kb_update_nl_steps_dev)", "filters_with_error_status": fbad,
+                                           "roofline": rl.hbm_roofline(fms / TF, M, 576 * 4, moved_f, None, {"live": False, "analytic": "packed working set less the resident rows of (b, R)"})}
+            del PhiT, HtT, realT, compT
         del sb, Phi, Ht, real, comp
 
     if rank == 0:
@@ -965,6 +1035,8 @@ def main():
                 fused["parity"] = _leg_parity(ga, k, synth, "fused")
             if "squareroot" in extra and "fused" in extra["squareroot"]:
                 extra["squareroot"]["fused"]["parity"] = _leg_parity(ga, k, synth, "squareroot_fused")
+            if "srif_fp32" in extra and "fused" in extra["srif_fp32"]:
+                extra["srif_fp32"]["fused"]["parity"] = _srif_fused_parity(ga, k)
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
             out["cpu_baseline"] = _cpu_baseline(d)
         # the full document goes to a side file; the ONE stdout line is its compact headline (round 5's 22.8 KB line was not parsed)

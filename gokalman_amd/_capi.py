@@ -44,6 +44,7 @@ SIGNATURES = {
     "kb_ekf_enabled": (_i, [_vp]),
     "kb_update_nl": (_i, [_vp, _dp, _i, _dp, _i]),
     "kb_update_nl_dev": (_i, [_vp, _vp, _vp, _i64]),
+    "kb_update_nl_steps_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i]),
     "kb_predict_nl": (_i, [_vp]),
     "kb_smooth_all_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "kb_get": (_i, [_vp, _i, _dp, _i64, _i64]),

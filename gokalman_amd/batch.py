@@ -380,6 +380,11 @@ class FilterBatch:
         k.check(k.lib().kb_update_nl(self._h, _ptr(r), r.shape[1], _ptr(c), c.shape[1]))
         return Estimate(self, snapshot=False)
 
+    def update_nl_steps_dev(self, phi_ptr, htilde_ptr, ld, phi_step, htilde_step, real_ptr, computed_ptr, ld_obs, obs_step, nsteps):
+        """kb_update_nl_steps_dev: nsteps Prepare + Update pairs from one call (planar device arrays, strides in elements)."""
+        k.check(k.lib().kb_update_nl_steps_dev(self._h, C.c_void_p(phi_ptr), C.c_void_p(htilde_ptr), ld, phi_step, htilde_step,
+                                               C.c_void_p(real_ptr), C.c_void_p(computed_ptr), ld_obs, obs_step, nsteps))
+
     def predict_nl(self, snapshot=None):
         if self._wants_snapshot(snapshot):
             return Estimate(self, via=lambda view, first, cnt: k.lib().kb_predict_nl_estimate(self._h, first, cnt, view))

@@ -33,7 +33,7 @@ def _hipcc():
 # `#pragma unroll` (16k cost units) a loop silently stays rolled, its register arrays become scratch arrays
 _PAIR = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]
 _UNROLL = ["-mllvm", "-pragma-unroll-threshold=200000"]
-EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR, "kb_srif_pair32b.hip": _PAIR, "kb_srif_pair32c.hip": _PAIR, "kb_srif_pair32d.hip": _PAIR, "kb_srif_pair32e.hip": _PAIR, "kb_srif_pair32f.hip": _PAIR, "kb_srif_pair32g.hip": _PAIR, 
+EXTRA = {"kb_srif_reg.hip": ["-fno-slp-vectorize"], "kb_srif_pair32.hip": _PAIR, "kb_srif_pair64.hip": _PAIR, "kb_srif_pair32b.hip": _PAIR, "kb_srif_pair32c.hip": _PAIR, "kb_srif_pair32d.hip": _PAIR, "kb_srif_pair32e.hip": _PAIR, "kb_srif_pair32f.hip": _PAIR, "kb_srif_pair32g.hip": _PAIR, "kb_srif_pair32h.hip": _PAIR, 
          "kb_vanilla_split12.hip": _UNROLL, "kb_vanilla_split16.hip": _UNROLL, "kb_vanilla_split12p.hip": _UNROLL, "kb_vanilla_split12n.hip": _UNROLL, "kb_hybrid_split.hip": _UNROLL, "kb_hybrid_split8.hip": _UNROLL, "kb_vanilla_split16p.hip": _UNROLL, "kb_squareroot_split12.hip": _UNROLL, "kb_squareroot_split12p.hip": _UNROLL, "kb_squareroot_split16p.hip": _UNROLL, "kb_squareroot_split16.hip": _UNROLL, "kb_information_split12.hip": _UNROLL, "kb_information_split8.hip": _UNROLL, "kb_information_split12f.hip": _UNROLL,
          "kb_srif_split_a.hip": _UNROLL, "kb_srif_split_b.hip": _UNROLL, "kb_srif_split_c.hip": _UNROLL, "kb_srif_split_d.hip": _UNROLL, "kb_srif_split_e.hip": _UNROLL, "kb_srif_split_f32a.hip": _UNROLL, "kb_srif_split_f32b.hip": _UNROLL, "kb_srif_split_f32c.hip": _UNROLL, "kb_srif_split_f32d.hip": _UNROLL}
 

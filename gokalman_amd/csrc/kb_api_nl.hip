@@ -156,6 +156,48 @@ int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs
     return nl_common(b, a, false);
 }
 
+// The caller loop `for k { kf.Prepare(Phi_k, Htilde_k); kf.Update(real_k, computed_k) }` from one call (round 6).  SRIF 12 / 6 fp32 in the
+// steady state (config E's shape): ONE launch, the own rows of (b, R) resident in registers between the steps (kb_srif_pair.h FUSED);
+// every other batch: nsteps Prepare + Update launches back to back on the handle's stream.
+int kb_update_nl_steps_dev(kb_batch *b, const void *phi, const void *htilde, int64_t ld, int64_t phi_step, int64_t htilde_step,
+                           const void *real_obs, const void *computed_obs, int64_t ld_obs, int64_t obs_step, int nsteps) {
+    int rc = ready_nl(b);
+    if (rc) return rc;
+    if (!phi || !htilde || !real_obs || !computed_obs) { set_error("null argument"); return KB_ERR_INVALID; }
+    if (ld < b->N || ld_obs < b->N) { set_error("ld < N"); return KB_ERR_INVALID; }
+    if (nsteps < 1) { set_error("nsteps must be >= 1"); return KB_ERR_INVALID; }
+    if (b->kind == KB_BATCH_LS) { set_error("BatchKF has no multi-step update"); return KB_ERR_UNSUPPORTED; }
+    const size_t w = b->esize();
+    if (b->kind == KB_SRIF && b->dtype == KB_F32 && b->n == 12 && b->p == 6 && nsteps > 1 && !(b->flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STATEMENT_KERNELS))) {
+        if (b->srif_leftover && hipStreamQuery(b->stream) == hipSuccess) after_sync(*b);
+        if (b->srif_tri && !b->srif_leftover) {
+            StepArgs a;
+            fill_step_args(*b, a);
+            a.ext_phi = phi; a.ext_h = htilde; a.ext_ld = ld; a.ext_phi_step = phi_step; a.ext_h_step = htilde_step;
+            a.y = real_obs; a.y_es = ld_obs; a.y_ts = KB_TILE; a.y_step = obs_step;
+            a.y2 = computed_obs; a.y2_es = ld_obs; a.y2_ts = KB_TILE; a.y2_step = obs_step;
+            a.nsteps = nsteps;
+            begin_kernel_record();
+            const bool done = launch_srif_pair_f32_fused(*b, a);
+            end_kernel_record(*b);
+            if (done) {
+                KB_HIP(hipGetLastError());
+                b->step += nsteps; b->calls += nsteps;
+                b->ext_phi = (const char *)phi + (size_t)(nsteps - 1) * (size_t)phi_step * w;   // what the last Prepare() of the loop left
+                b->ext_h = (const char *)htilde + (size_t)(nsteps - 1) * (size_t)htilde_step * w; b->ext_ld = ld;
+                b->have[KB_F] = b->have[KB_H] = true;
+                b->srif_tri = 1; b->snc = 0; b->locked = 1;
+                return KB_OK;
+            }
+        }
+    }
+    for (int t = 0; t < nsteps; t++) {
+        if ((rc = kb_prepare_dev(b, (const char *)phi + (size_t)t * (size_t)phi_step * w, (const char *)htilde + (size_t)t * (size_t)htilde_step * w, ld))) return rc;
+        if ((rc = kb_update_nl_dev(b, (const char *)real_obs + (size_t)t * (size_t)obs_step * w, (const char *)computed_obs + (size_t)t * (size_t)obs_step * w, ld_obs))) return rc;
+    }
+    return KB_OK;
+}
+
 // Predict(): srif.go:96-98, hybrid.go:99-101
 static int predict_nl_host(kb_batch *b, int64_t first, int64_t count, kb_estimate_view *view) {
     int rc = ready_nl(b);

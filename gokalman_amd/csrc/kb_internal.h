@@ -132,9 +132,10 @@ struct StepArgs {
     int64_t mo_ts;   // elements between the model blocks of consecutive tiles: 64 * L.mo_elems, or 0 when every filter has the SAME model
                      // (all model fields uploaded with broadcast = 1: every wave reads tile 0's block, which stays in the L2)
     const void *y; int64_t y_es, y_ts, y_step;   // element stride, tile stride, step stride (elements)
-    const void *y2; int64_t y2_es, y2_ts;        // NLDKF: computed observation
+    const void *y2; int64_t y2_es, y2_ts, y2_step;   // NLDKF: computed observation
     const void *u; int64_t u_es, u_ts, u_step;
     const void *ext_phi, *ext_h; int64_t ext_ld;   // NLDKF zero-copy model (planar, element e of filter i at ptr[e*ld + i])
+    int64_t ext_phi_step, ext_h_step;              // kb_update_nl_steps_dev: elements between the arrays of consecutive steps
     int64_t N, ntiles;
     int nsteps;
     int stream_state;                            // the state block cannot stay in the Infinity Cache: read / write it non-temporally (kb_vanilla_reg.h)
@@ -247,6 +248,7 @@ void launch_srif_split_f32_n16(const Batch &b, const StepArgs &a);
 Layout make_layout(int kind, int n, int pmax, int m, unsigned flags);   // kb_api.hip
 bool launch_srif_pair_f32(const Batch &b, const StepArgs &a);   // kb_srif_pair32.hip: Update with two lanes per filter; false = shape not covered
 bool launch_srif_pair_f64(const Batch &b, const StepArgs &a);   // kb_srif_pair64.hip
+bool launch_srif_pair_f32_fused(const Batch &b, const StepArgs &a);   // kb_srif_pair32h.hip: config E time-fused (kb_update_nl_steps_dev)
 bool launch_srif_pair_f32b(const Batch &b, const StepArgs &a);  // kb_srif_pair32b.hip / 64b.hip: 8 / 10 states, p = 2 / 4
 bool launch_srif_pair_f32c(const Batch &b, const StepArgs &a);  // kb_srif_pair32c.hip / 64c.hip: 12 states, p = 1 .. 5
 bool launch_srif_pair_f32d(const Batch &b, const StepArgs &a);  // kb_srif_pair32d.hip / 64d.hip: 6, 8, 10 states, p = 5 / 6

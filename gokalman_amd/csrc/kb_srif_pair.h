@@ -128,26 +128,33 @@ struct Panel {
 // PADM: the batch has p = NM - 1 measurements (p = 1 on a two-row, 3 on a four-row, 5 on a six-row instantiation): the missing row is
 // a zero row of Htilde with a zero residual and a unit entry in chol(R) -- its whitened row is zero, the Householder steps add exact
 // zeros for it, so every real entry of the result has the same bits as without the row; loads and Estimate stores skip it.
-template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE, bool PADM = false>
+// FUSED (round 6, kb_update_nl_steps_dev): the caller loop `for k { kf.Prepare(Phi_k, Htilde_k); kf.Update(real_k, computed_k) }` inside one
+// launch, steady state only (!DENSE, !FULL, EXT): step t reads the caller's arrays at t x their step strides, the own rows of (b, R) stay
+// in the panel's registers from one step to the next (they are exactly where the next step would load them) and are still stored every
+// step -- memory stays current, so a step that fails for some filter (its stores are predicated, as ever) makes the whole wave reload
+// at the top of the next one; the same operations in the same order as T single launches: the same bits.
+template <typename T, int NS, int NM, bool FULL, bool EXT, bool DENSE, bool PADM = false, bool FUSED = false>
 __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, int half, int lane, T *lds_lu) {
     static_assert(NS % 2 == 0 && NM % 2 == 0, "rows are split by parity");
+    static_assert(!FUSED || (EXT && !DENSE && !FULL && !PADM), "the time-fused variant: zero-copy operands, steady state, state only");
     constexpr int COLS = NS + 1, HS = NS / 2, HM = NM / 2, SL = HS + HM, ROWE = NS * KB_TILE;
     typedef Panel<T, SL, HS> PN;
     typedef typename PN::V2 V2;
     // Addressing: every base below is wave-uniform (tile / half come from readfirstlane in the kernel), the per-lane part
     // is ONE 32-bit element offset (vf, or vrow for the own rows), so the loads and stores use the scalar-base +
     // 32-bit-vector-offset form: no 64-bit address pair per access (there are ~350 accesses per lane).
-    const unsigned vf = (unsigned)lane & 31u;
+    typedef std::conditional_t<FUSED, unsigned, const unsigned> lane_off;   // (laundered at the top of every FUSED step, below; otherwise constants)
+    lane_off vf = (unsigned)lane & 31u;
     const bool is_hi = lane >= 32;
-    const unsigned vrow = vf + (is_hi ? (unsigned)ROWE : 0u);   // own rows: element NS + 2 s NS + j from here is R[2 s + l][j]
-    const unsigned vl = vf + (is_hi ? (unsigned)KB_TILE : 0u);  // own element of an (even, odd) pair of consecutive elements
+    lane_off vrow = vf + (is_hi ? (unsigned)ROWE : 0u);   // own rows: element NS + 2 s NS + j from here is R[2 s + l][j]
+    lane_off vl = vf + (is_hi ? (unsigned)KB_TILE : 0u);  // own element of an (even, odd) pair of consecutive elements
     const int64_t first = tile * KB_TILE + half * 32;
     const int64_t fi = first + vf;
     const bool inb = fi < a.N;
-    const unsigned vx = inb ? vf : 0u;   // caller's arrays end at N: lanes past it re-read the half-tile's first filter
+    lane_off vx = inb ? vf : 0u;   // caller's arrays end at N: lanes past it re-read the half-tile's first filter
     T *st = (T *)a.state + tile * ((int64_t)KB_TILE * (NS + NS * NS)) + half * 32;
     const T *mo = (const T *)a.model + tile * ((int64_t)KB_TILE * a.L.mo_elems) + half * 32;
-    const T *ephi = EXT ? (const T *)a.ext_phi + first : nullptr;
+    const T *ephi = EXT ? (const T *)a.ext_phi + first : nullptr;   // (FUSED: advanced by the step strides at the end of every step)
     const T *eh = EXT ? (const T *)a.ext_h + first : nullptr;
     const T *yr = (const T *)a.y + tile * a.y_ts + half * 32;
     const T *yc = (const T *)a.y2 + tile * a.y2_ts + half * 32;
@@ -160,495 +167,35 @@ __device__ __forceinline__ void srif_pair_tile(const StepArgs &a, int64_t tile, 
     auto ld_mo = [&](int e) { return __builtin_nontemporal_load(mo + ((unsigned)(e * KB_TILE) + vf)); };
     // element e of Phi for the lower half, element e + 1 for the upper half (its column is the next one); the caller's planar
     // arrays have a run-time element stride, so their addresses are formed as (scalar pointer) + (32-bit lane byte offset)
-    const unsigned vphi = EXT ? vx + (is_hi ? (unsigned)a.ext_ld : 0u) : vl;
-    const unsigned bx = vx * (unsigned)sizeof(T), bphi = vphi * (unsigned)sizeof(T);
+    lane_off vphi = EXT ? vx + (is_hi ? (unsigned)a.ext_ld : 0u) : vl;
+    lane_off bx = vx * (unsigned)sizeof(T), bphi = vphi * (unsigned)sizeof(T);
 
-    unsigned err = 0;
     // own rows of the panel [[RBar bBar], [L Htilde, L y]] (the top part first holds the own rows of R), kept as COLUMN PAIRS
     // (2 c, 2 c + 1) plus the right-hand-side column: the Householder updates run on pairs (v_pk_fma_f32 in fp32: two
     // columns per instruction; in fp64 the same source compiles to two scalar FMAs)
     Panel<T, SL, HS> A;
-    T xprev[NS];
-    T pc[NS * HS];    // Phi, this half's columns: pc[r * HS + cs] = Phi[r][2 cs + l]; factorised in place
-    auto load_phi = [&]() {
-        UniformCursor<T> cur(EXT ? ephi : mo);   // walks Phi two elements at a time
-#pragma unroll
-        for (int r = 0; r < NS; r++)
-#pragma unroll
-            for (int cs = 0; cs < HS; cs++) {
-                if constexpr (EXT) { pc[r * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
-                else pc[r * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_F + r * NS + 2 * cs) * KB_TILE) + vphi));
-            }
-    };
-    // ---- every operand is requested up front: ONE exposed memory latency per wave (the partner wave on the SIMD computes
-    // meanwhile).  ~230 values in flight; the measurement operands (99) stay in registers until the factors of Phi have gone
-    // to LDS, which is what the 256-register budget allows (whitening first would need 39 more accumulators on top).
-    const int rp = PADM ? a.p : NM;
-    T Hc[NM * HS], Lw[tri(NM)], yv[NM];   // Htilde, this half's columns: Hc[m * HS + cs] = Htilde[m][2 cs + l]
-    [[maybe_unused]] T yreal[NM], yown[HM];
-    auto load_meas = [&]() {
-        {
-            UniformCursor<T> cur(EXT ? eh : mo);   // walks Htilde two elements at a time
-#pragma unroll
-            for (int m = 0; m < NM; m++)
-#pragma unroll
-                for (int cs = 0; cs < HS; cs++) {
-                    if (PADM && m >= rp) { Hc[m * HS + cs] = T(0); continue; }
-                    if constexpr (EXT) { Hc[m * HS + cs] = cur.load_nt(bphi); cur.advance(2 * a.ext_ld); }
-                    else Hc[m * HS + cs] = __builtin_nontemporal_load(mo + ((unsigned)((a.L.mo_H + m * NS + 2 * cs) * KB_TILE) + vphi));
-                }
+#ifndef KB_PAIR_FUSED_KEEP
+#define KB_PAIR_FUSED_KEEP 1   // (0: diagnostic -- every fused step reloads its rows: they were written a step ago and sit in the L2)
+#endif
+    [[maybe_unused]] bool reload = true;   // FUSED: the own rows of (b, R) come from memory (first step, or some filter of the wave failed the last one)
+    // The step itself is kb_srif_pair_step.inc, included TWICE: as it stands for the one-step kernels, and inside the loop of the FUSED one.
+    // (A `for` around the one text changed the register allocation of the one-step instantiations although its trip count is a
+    // compile-time 1 there -- 24 B of scratch in the fp64 12/6 kernel; a backward goto left the FUSED kernel with 316 B where the loop has 40.)
+    if constexpr (FUSED) {
+        for (int t = 0; t < a.nsteps; t++) {
+            // Everything an address is formed from is made opaque per step: left alone, loop-invariant code motion hoists the ~350 element
+            // offsets and the loads of chol(R) out of the loop and keeps them alive across it (530 B of scratch per lane)
+            asm volatile("" : "+v"(vf), "+v"(vrow), "+v"(vl), "+v"(vx), "+v"(vphi), "+v"(bx), "+v"(bphi));
+            unsigned long long ps = (unsigned long long)st, pm = (unsigned long long)mo;
+            asm volatile("" : "+s"(ps), "+s"(pm));
+            st = (T *)ps; mo = (const T *)pm;
+#include "kb_srif_pair_step.inc"
+            reload = !KB_PAIR_FUSED_KEEP || __any(err != 0);   // (a failed filter kept its old rows in memory only: the panel holds what the step made of them)
+            ephi += a.ext_phi_step; eh += a.ext_h_step; yr += a.y_step; yc += a.y2_step;
         }
-#pragma unroll
-        for (int c = 0; c < NM; c++)
-#pragma unroll
-            for (int m = 0; m <= c; m++)   // QUIRK srif.go:48: chol_L(R), not its inverse
-                Lw[symi(m, c)] = (PADM && c >= rp) ? (m == c ? T(1) : T(0)) : ld_mo(a.L.mo_LR + symi(m, c));
-        {
-            UniformCursor<T> cr(yr), cc(yc);
-#pragma unroll
-            for (int r = 0; r < NM; r++) {
-                if (PADM && r >= rp) { yv[r] = T(0); if constexpr (FULL) yreal[r] = T(0); continue; }
-                const T re = cr.load_nt(bx), co = cc.load_nt(bx);
-                cr.advance(a.y_es); cc.advance(a.y2_es);
-                yv[r] = re - co;   // srif.go:143-144
-                if constexpr (FULL) yreal[r] = re;
-            }
-        }
-    };
-    // fp64 (one wave per SIMD, nothing else hides its latency): the largest HBM stream, Phi, is requested first -- 3.5 % faster
-    // than with it last; in fp32 the other order is 1 % ahead (b and R, the Infinity-Cache hits State(prev) starts from, arrive earlier)
-    constexpr bool PHI_FIRST = sizeof(T) == 8 && !DENSE;
-    // fp64 steady state: the measurement operands (63 values = 126 registers) are requested only when Phi's registers are free (its
-    // factors are in LDS) and whitened after the RBar solves, whose ~25 us hide that second latency: 1143 -> 986 AGPR copies in the
-    // code, 200 -> 191 us per 256k-filter step (profiles/NOTES.md).  In fp32 (two waves per SIMD, no AGPRs) the same order gains nothing.
-    constexpr bool MEAS_LATE = sizeof(T) == 8 && !DENSE;
-    if constexpr (PHI_FIRST) load_phi();
-    if constexpr (!MEAS_LATE) load_meas();
-    [[maybe_unused]] T bown[HS];   // b of the own rows
-    if constexpr (DENSE) {
-#pragma unroll
-        for (int i = 0; i < NS; i++) xprev[i] = ld_st(i);   // b, in both halves
     } else {
-#pragma unroll
-        for (int s = 0; s < HS; s++) bown[s] = st[(unsigned)(2 * s * KB_TILE) + vl];
+#include "kb_srif_pair_step.inc"
     }
-    [[maybe_unused]] T Rw[DENSE ? NS * NS : 1];
-    if constexpr (DENSE) {
-#pragma unroll
-        for (int e = 0; e < NS * NS; e++) Rw[e] = ld_st(NS + e);
-    } else {
-#pragma unroll
-        for (int s = 0; s < HS; s++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) A.set(s, j, j >= 2 * s ? ld_row(NS + 2 * s * NS + j) : T(0));   // (2 s + 1, 2 s) is a stored zero
-        if constexpr (!PHI_FIRST) load_phi();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- State(prev) = R^-1 b (srif.go:223-234) -------------------------------------------------------------------
-    if constexpr (DENSE) {
-        if (lu_solve_inplace<T, NS, 1>(Rw, xprev)) err |= KB_ST_SINGULAR;   // both halves, redundantly
-        asm volatile("" ::: "memory");   // (cold path) the own rows are read after the 144 registers of Rw are free
-#pragma unroll
-        for (int s = 0; s < HS; s++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) A.set(s, j, ld_row(NS + 2 * s * NS + j));
-        load_phi();
-    } else {
-        // back substitution, column-oriented: as soon as x_i exists (in the half that owns row i) it is handed to the other
-        // half and every remaining own row subtracts its R[r][i] x_i -- the critical path per component is one multiply, one
-        // exchange and one FMA; the reciprocals of the diagonal are formed up front, off that path
-        T rinv[HS], acc[HS];
-#pragma unroll
-        for (int s = 0; s < HS; s++) {
-            const T d = is_hi ? A.get(s, 2 * s + 1) : A.get(s, 2 * s);   // R[2 s + l][2 s + l]
-            if (d == T(0)) err |= KB_ST_SINGULAR;
-            rinv[s] = recip(d);
-            acc[s] = bown[s];
-        }
-#pragma unroll
-        for (int i = NS - 1; i >= 0; i--) {
-            const int si = i / 2, own = i % 2;
-            xprev[i] = from_half(acc[si] * rinv[si], own);   // the other half's product (its row 2 si + 1 - own) is discarded
-#pragma unroll
-            for (int s = 0; s <= si; s++) acc[s] -= A.get(s, i) * xprev[i];   // rows 2 s + l < i; the structural zeros contribute 0
-        }
-    }
-    KB_SRIF_STOP_AT(1, {
-        for (int i = 0; i < NS; i++) sink__ += xprev[i];
-        for (int e = 0; e < NS * HS; e++) sink__ += pc[e];
-        if constexpr (!MEAS_LATE) { for (int e = 0; e < NM * HS; e++) sink__ += Hc[e]; for (int e = 0; e < tri(NM); e++) sink__ += Lw[e]; for (int e = 0; e < NM; e++) sink__ += yv[e]; }
-    })
-    // ---- xBar = Phi State(prev) (srif.go:118): each half sums over its columns ------------------------------------------
-    T xbar[NS];
-    {
-        T xs[HS];
-#pragma unroll
-        for (int cs = 0; cs < HS; cs++) xs[cs] = is_hi ? xprev[2 * cs + 1] : xprev[2 * cs];
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            T part = T(0);
-#pragma unroll
-            for (int cs = 0; cs < HS; cs++) part += pc[i * HS + cs] * xs[cs];
-            xbar[i] = allsum(part);
-        }
-    }
-    // ---- P Phi = L U (srif.go:111-114's Inverse = Dgetrf + ...), the columns split over the halves: the half that owns
-    // column j searches the pivot and forms the multipliers, the other half receives them (one exchange each) and both
-    // update their own columns.  nibble k of perm = original index of the row now in position k.
-    uint64_t perm = 0xFEDCBA9876543210ull;
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-        const int cj = j / 2, oj = j % 2;
-        const bool owner = is_hi == (oj == 1);
-        bool need = false;   // some row below has a larger entry in column j: the bubble below would exchange at least once
-#pragma unroll
-        for (int r = j + 1; r < NS; r++) need = need || fabs(pc[r * HS + cj]) > fabs(pc[j * HS + cj]);
-        if (__any(owner && need)) {   // wave-uniform and rare (one test per column): the exchange code only runs when some lane pivots
-#pragma unroll
-            for (int r = j + 1; r < NS; r++) {
-                const bool sw = owner && fabs(pc[r * HS + cj]) > fabs(pc[j * HS + cj]);
-                const bool s2 = from_half(sw ? 1u : 0u, oj) != 0u;
-#pragma unroll
-                for (int cs = 0; cs < HS; cs++) {   // whole rows: the L part moves with its row (LAPACK dlaswp)
-                    const T t0 = pc[j * HS + cs], t1 = pc[r * HS + cs];
-                    pc[j * HS + cs] = s2 ? t1 : t0;
-                    pc[r * HS + cs] = s2 ? t0 : t1;
-                }
-                const uint64_t x = s2 ? (((perm >> (4 * j)) ^ (perm >> (4 * r))) & 15u) : 0u;
-                perm ^= (x << (4 * j)) | (x << (4 * r));
-            }
-        }
-        const T piv = pc[j * HS + cj];
-        if (owner && piv == T(0)) err |= KB_ST_SINGULAR;
-        const T rp = recip(piv);
-        const T ujc = pc[j * HS + cj];          // upper half, j even: U[j][j + 1], still needed below
-        if (owner) pc[j * HS + cj] = rp;        // the solves multiply by the reciprocal
-#pragma unroll
-        for (int r = j + 1; r < NS; r++) {
-            const T lf = from_half(pc[r * HS + cj] * rp, oj);   // the multiplier, in both halves
-            // slot cj: the owner keeps the multiplier (L); for an even j the upper half's column j + 1 is still active
-            if (oj == 0) pc[r * HS + cj] = is_hi ? pc[r * HS + cj] - lf * ujc : lf;
-            else pc[r * HS + cj] = is_hi ? lf : pc[r * HS + cj];
-#pragma unroll
-            for (int cs = cj + 1; cs < HS; cs++) pc[r * HS + cs] -= lf * pc[j * HS + cs];
-        }
-    }
-    const bool anyswap = __any(perm != 0xFEDCBA9876543210ull);
-    KB_SRIF_STOP_AT(2, {
-        for (int i = 0; i < NS; i++) sink__ += xbar[i];
-        for (int e = 0; e < NS * HS; e++) sink__ += pc[e];
-        for (int s2 = 0; s2 < HS; s2++) for (int j = 0; j < NS; j++) sink__ += A.get(s2, j);
-        if constexpr (!MEAS_LATE) { for (int e = 0; e < NM * HS; e++) sink__ += Hc[e]; for (int e = 0; e < tri(NM); e++) sink__ += Lw[e]; for (int e = 0; e < NM; e++) sink__ += yv[e]; }
-    })
-    // the factors go to LDS, [element][32 filters]: element (r, 2 cs + l) from this lane; the solves below read every
-    // element from both halves (lanes f and 32 + f read the same word: a broadcast, no bank conflict)
-#pragma unroll
-    for (int r = 0; r < NS; r++)
-#pragma unroll
-        for (int cs = 0; cs < HS; cs++) lds_lu[(r * NS + 2 * cs) * 32 + lane] = pc[r * HS + cs];
-    {   // a failure in either half fails the filter
-        unsigned elo, ehi;
-        halves(err, elo, ehi);
-        err = elo | ehi;
-    }
-    const bool ok = inb && err == 0;   // failed: (b, R) stay as they are, srif.go:111-114 returns before any assignment
-    if (err && inb && !is_hi) fail_step(a, fi, err);   // srif.go:112-114 returns before kf.step++
-    if constexpr (DENSE) {
-        // a filter that fails HERE keeps a dense R: its half-tile stays with this kernel (Batch::d_srif_dense; the steady-state kernel
-        // never writes that word, so the two launches of one step cannot both take a half-tile) and the host keeps launching it
-        // (Batch::srif_leftover) until a drained stream shows a launch in which nobody failed
-        const bool left = __any(err != 0 && inb);
-        if (lane == 0) {
-            // every part bit of the word: fp32 at 14 / 16 states runs Predict() (and p = 7, 8) on kb_srif_split.h, which reads ONE BIT PER
-            // PART of this word (a bare 1 left the part of slots 16..31 looking triangular to the next Predict())
-            a.srif_dense[2 * tile + half] = left ? 0xFFFFFFFFu : 0u;
-            if (left) __hip_atomic_store(a.srif_dense_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MEAS_LATE) { load_meas(); __builtin_amdgcn_sched_barrier(0); }
-    // ---- whitened measurement rows (srif.go:146-148): [L Htilde | L y].  Each half forms ALL rows of L Htilde for ITS
-    // columns (Htilde is held column-split like Phi: half the registers, half the loads), then one exchange per pair of
-    // values turns columns-of-all-rows into all-columns-of-the-own-rows.
-    auto whiten = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < HM; t++) {
-#pragma unroll
-        for (int cs = 0; cs < HS; cs++) {
-            T w0 = T(0), w1 = T(0);   // rows 2 t and 2 t + 1, column 2 cs + l
-#pragma unroll
-            for (int m = 0; m <= 2 * t; m++) w0 += Lw[symi(m, 2 * t)] * Hc[m * HS + cs];
-#pragma unroll
-            for (int m = 0; m <= 2 * t + 1; m++) w1 += Lw[symi(m, 2 * t + 1)] * Hc[m * HS + cs];
-            cross(w0, w1);   // lower half: row 2 t, columns 2 cs and 2 cs + 1; upper half: row 2 t + 1, the same columns
-            A.set(HS + t, 2 * cs, w0);
-            A.set(HS + t, 2 * cs + 1, w1);
-        }
-        T s0 = T(0), s1 = T(0);
-#pragma unroll
-        for (int m = 0; m <= 2 * t; m++) s0 += Lw[symi(m, 2 * t)] * yv[m];
-#pragma unroll
-        for (int m = 0; m <= 2 * t + 1; m++) s1 += Lw[symi(m, 2 * t + 1)] * yv[m];
-        A.set(HS + t, NS, is_hi ? s1 : s0);
-        if constexpr (FULL) yown[t] = is_hi ? yreal[2 * t + 1] : yreal[2 * t];
-    }
-    };
-    if constexpr (!MEAS_LATE) whiten();
-
-    if constexpr (!MEAS_LATE) {
-        KB_SRIF_STOP_AT(3, {
-            for (int i = 0; i < NS; i++) sink__ += xbar[i];
-            for (int s2 = 0; s2 < SL; s2++) for (int j = 0; j <= NS; j++) sink__ += A.get(s2, j);
-            for (int e = 0; e < NS * HS; e++) sink__ += pc[e];
-        })
-    }
-    __builtin_amdgcn_sched_barrier(0);   // (!MEAS_LATE) the measurement operands are dead from here on
-    // ---- RBar = R Phi^-1 (srif.go:115) for the own rows: z Phi = R[i,:], i.e. w U = r, v L = w, z[perm_k] = v_k --------
-    // A[s][0..NS) is z for row 2 s + l; columns < 2 s are structural zeros (skipped) unless DENSE
-    // two columns (2 c, 2 c + 1) at a time: the pair subtracts A[s][k2] (U[k2][2 c], U[k2][2 c + 1]) in one packed FMA
-    auto lu2 = [&](int r, int c) { return V2{lds_lu[(r * NS + 2 * c) * 32 + vf], lds_lu[(r * NS + 2 * c + 1) * 32 + vf]}; };
-    if constexpr (sizeof(T) == 8) {
-    // (sfor: compile-time indices, no loop for the optimiser to unroll late -- the panel must be promoted to registers)
-    sfor<0, HS>([&](auto C) __attribute__((always_inline)) {
-        constexpr int c = C;
-        sfor<0, 2 * c>([&](auto K2) __attribute__((always_inline)) {
-            constexpr int k2 = K2;
-            const V2 u = lu2(k2, c);
-            sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
-                constexpr int s = S;
-                if constexpr (DENSE || 2 * s <= k2) A.pair(s, c) = PN::fma2(-PN::splat(A.get(s, k2)), u, A.pair(s, c));
-            });
-        });
-        const V2 d = lu2(2 * c, c);   // (1 / U[2c][2c], U[2c][2c + 1])
-        const T r1 = lds_lu[((2 * c + 1) * NS + 2 * c + 1) * 32 + vf];
-        sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
-            constexpr int s = S;
-            if constexpr (DENSE || s <= c) {
-                const T z0 = A.get(s, 2 * c) * d[0];
-                A.set(s, 2 * c, z0);
-                A.set(s, 2 * c + 1, (A.get(s, 2 * c + 1) - z0 * d[1]) * r1);
-            }
-        });
-    });
-    // v L = w from the last column back; within a pair the (2 c + 1) -> 2 c term comes last
-    sfor<0, HS>([&](auto CR) __attribute__((always_inline)) {
-        constexpr int c = HS - 1 - CR;
-        sfor<2 * c + 2, NS>([&](auto K2) __attribute__((always_inline)) {
-            constexpr int k2 = K2;
-            const V2 lk = lu2(k2, c);
-            sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
-                constexpr int s = S;
-                A.pair(s, c) = PN::fma2(-PN::splat(A.get(s, k2)), lk, A.pair(s, c));
-            });
-        });
-        const T l10 = lds_lu[((2 * c + 1) * NS + 2 * c) * 32 + vf];
-        sfor<0, HS>([&](auto S) __attribute__((always_inline)) {
-            constexpr int s = S;
-            A.set(s, 2 * c, A.get(s, 2 * c) - A.get(s, 2 * c + 1) * l10);
-        });
-    });
-    } else {
-        // fp32: column by column -- the pair form costs the allocator its slack at the 256-register cap (spills on the hot path)
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-#pragma unroll
-            for (int k2 = 0; k2 < j; k2++) {
-                const T ukj = lds_lu[(k2 * NS + j) * 32 + vf];
-#pragma unroll
-                for (int s = 0; s < HS; s++)
-                    if (DENSE || 2 * s <= k2) A.set(s, j, A.get(s, j) - A.get(s, k2) * ukj);
-            }
-            const T rjj = lds_lu[(j * NS + j) * 32 + vf];
-#pragma unroll
-            for (int s = 0; s < HS; s++)
-                if (DENSE || 2 * s <= j) A.set(s, j, A.get(s, j) * rjj);
-        }
-#pragma unroll
-        for (int j = NS - 2; j >= 0; j--) {
-#pragma unroll
-            for (int k2 = j + 1; k2 < NS; k2++) {
-                const T lkj = lds_lu[(k2 * NS + j) * 32 + vf];
-#pragma unroll
-                for (int s = 0; s < HS; s++) A.set(s, j, A.get(s, j) - A.get(s, k2) * lkj);
-            }
-        }
-    }
-    // FULL: RBar leaves for the Estimate INSIDE each branch of the permutation test below.  Behind the join every entry of the panel is
-    // a phi of the two branches, and a consumer of all 72 of them there costs ~50 registers at the kernel's peak (216 B of scratch in
-    // fp32, 532 B in fp64, every y spilled as it arrives: 166 us against 88 us state-only) -- the Householder does not, it takes them
-    // column by column.  Found by bisection (profiles/NOTES.md).
-    auto store_rbar = [&]() __attribute__((always_inline)) {
-        if constexpr (FULL) {
-            if (ok && full_rt) {
-#pragma unroll
-                for (int s = 0; s < HS; s++)
-#pragma unroll
-                    for (int j = 0; j < NS; j++) __builtin_nontemporal_store(A.get(s, j), es + ((unsigned)((a.L.es_ppred + 2 * s * NS + j) * KB_TILE) + vrow));
-            }
-        }
-    };
-    // bBar = RBar xBar (srif.go:119), same products in pivoted order; then the row permutation is undone
-    if (anyswap) {   // cold: some lane pivoted.  Register arrays cannot be indexed per lane: select chains
-        T xp[NS];
-#pragma unroll
-        for (int r = 0; r < NS; r++) {
-            const int pr = pnib(perm, r);
-            T v = T(0);
-#pragma unroll
-            for (int c = 0; c < NS; c++) v = pr == c ? xbar[c] : v;
-            xp[r] = v;
-        }
-#pragma unroll
-        for (int s = 0; s < HS; s++) {
-            T bb = T(0);
-#pragma unroll
-            for (int r = 0; r < NS; r++) bb += A.get(s, r) * xp[r];
-            T row[NS];
-#pragma unroll
-            for (int c = 0; c < NS; c++) {
-                T v = T(0);
-#pragma unroll
-                for (int r = 0; r < NS; r++) v = pnib(perm, r) == c ? A.get(s, r) : v;
-                row[c] = v;
-            }
-#pragma unroll
-            for (int c = 0; c < NS; c++) A.set(s, c, row[c]);
-            A.set(s, NS, bb);
-        }
-        store_rbar();
-    } else {
-#pragma unroll
-        for (int s = 0; s < HS; s++) {
-            T bb = T(0);
-#pragma unroll
-            for (int r = 0; r < NS; r++) bb += A.get(s, r) * xbar[r];
-            A.set(s, NS, bb);
-        }
-        store_rbar();
-    }
-    if constexpr (MEAS_LATE) { __builtin_amdgcn_sched_barrier(0); whiten(); }
-    if constexpr (FULL) {
-        if (ok && full_rt) {
-#pragma unroll
-            for (int t = 0; t < HM; t++) {
-                if (PADM && 2 * t + (is_hi ? 1 : 0) >= rp) continue;   // (the padded row has no slot in the Estimate)
-                __builtin_nontemporal_store(yown[t], es + ((unsigned)((a.L.es_yhat + 2 * t) * KB_TILE) + vl));
-                __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_dobs + 2 * t) * KB_TILE) + vl));
-            }
-        }
-    }
-
-    KB_SRIF_STOP_AT(4, {
-        for (int s2 = 0; s2 < SL; s2++) for (int j = 0; j <= NS; j++) sink__ += A.get(s2, j);
-    })
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- HouseholderTransf (helper.go:142-172) with the rows split over the halves ----------------------------------
-    T chk = T(0);
-#pragma unroll
-    for (int k = 0; k < NS; k++) {
-        const int sk = k / 2, lk = k % 2;
-        // u_i = A[i][k] for the rows i >= k; in slot sk that is both halves when k is even, only the upper half when odd
-        const int ck = k / 2;
-        T colk[SL];   // column k of the own rows (register renaming)
-#pragma unroll
-        for (int s = sk; s < SL; s++) colk[s] = A.get(s, k);
-        const T ask = colk[sk];
-        T part = lk == 0 ? ask * ask : (is_hi ? ask * ask : T(0)), part2 = T(0);   // two chains: the sum is on the critical path of the step
-#pragma unroll
-        for (int s = sk + 1; s < SL; s++) {
-            if ((s - sk) & 1) part2 += colk[s] * colk[s];
-            else part += colk[s] * colk[s];
-        }
-        T sigma = allsum(part + part2);
-        const T akk = from_half(ask, lk);
-        const T sgn = (akk == T(0) || fabs(akk) <= T(1e-12)) ? T(1) : copysign(T(1), akk);   // helper.go:133-138 Sign
-        sigma = root(sigma) * sgn;
-        const T uk = akk + sigma;
-        const T beta = recip(sigma * uk);
-        const T usk = lk == 0 ? (is_hi ? ask : uk) : (is_hi ? uk : T(0));   // u of this lane's row in slot sk
-        // The column pairs to the right of column k: both dot products in one accumulator pair, then ONE exchange for the
-        // two columns: cross() leaves (first column's total | second column's total) in the (lower | upper) half after one
-        // add, a second swap hands both totals to both halves -- 4 instructions for 2 columns; same sums as allsum()
-#pragma unroll
-        for (int c = 0; c < HS; c++) {
-            if (c <= ck) continue;
-            V2 pp = V2{T(0), T(0)};   // the rows below first: they do not wait for sigma
-#pragma unroll
-            for (int s = sk + 1; s < SL; s++) pp = PN::fma2(PN::splat(colk[s]), A.pair(s, c), pp);
-            pp = PN::fma2(PN::splat(usk), A.pair(sk, c), pp);
-            T p0 = pp[0], p1 = pp[1], g0, g1;
-            cross(p0, p1);
-            halves(p0 + p1, g0, g1);
-            const V2 g = V2{g0 * beta, g1 * beta};
-            A.pair(sk, c) = PN::fma2(-g, PN::splat(usk), A.pair(sk, c));
-#pragma unroll
-            for (int s = sk + 1; s < SL; s++) A.pair(s, c) = PN::fma2(-g, PN::splat(colk[s]), A.pair(s, c));
-        }
-        // the odd columns out: the right-hand side always, and column k + 1 (the other half of k's pair) when k is even
-        if (lk == 0) {
-            const int j = k + 1;
-            T p0 = T(0), p1 = T(0);
-#pragma unroll
-            for (int s = sk + 1; s < SL; s++) {
-                p0 += colk[s] * A.get(s, j);
-                p1 += colk[s] * A.b[s];
-            }
-            p0 += usk * A.get(sk, j);
-            p1 += usk * A.b[sk];
-            T g0, g1;
-            cross(p0, p1);
-            halves(p0 + p1, g0, g1);
-            g0 *= beta;
-            g1 *= beta;
-            A.set(sk, j, A.get(sk, j) - g0 * usk);
-            A.b[sk] -= g1 * usk;
-#pragma unroll
-            for (int s = sk + 1; s < SL; s++) {
-                A.set(s, j, A.get(s, j) - g0 * colk[s]);
-                A.b[s] -= g1 * colk[s];
-            }
-        } else {
-            T pj = T(0);
-#pragma unroll
-            for (int s = sk + 1; s < SL; s++) pj += colk[s] * A.b[s];
-            pj += usk * A.b[sk];
-            const T gamma = allsum(pj) * beta;
-            A.b[sk] -= gamma * usk;
-#pragma unroll
-            for (int s = sk + 1; s < SL; s++) A.b[s] -= gamma * colk[s];
-        }
-        A.set(sk, k, lk == 0 ? (is_hi ? T(0) : -sigma) : (is_hi ? -sigma : ask));
-        // row k is final: it leaves the register file from the half that owns it
-#pragma unroll
-        for (int j = k; j < COLS; j++) chk += A.get(sk, j) * T(0);
-        if (ok && is_hi == (lk == 1)) {
-            st[(unsigned)(k * KB_TILE) + vf] = A.b[sk];
-#pragma unroll
-            for (int j = k; j < NS; j++) st[(unsigned)((NS + 2 * sk * NS + j) * KB_TILE) + vrow] = A.get(sk, j);
-        }
-    }
-    if constexpr (FULL) {
-        if (ok && full_rt) {
-#pragma unroll
-            for (int t = 0; t < HM; t++) {
-                if (PADM && 2 * t + (is_hi ? 1 : 0) >= rp) continue;
-                __builtin_nontemporal_store(A.get(HS + t, NS), es + ((unsigned)((a.L.es_innov + 2 * t) * KB_TILE) + vl));
-            }
-        }
-    }
-    if constexpr (DENSE) {
-        if (ok) {   // srif.go:334-337 zeroes the sub-columns; R was dense in memory
-#pragma unroll
-            for (int s = 0; s < HS; s++) {
-#pragma unroll
-                for (int j = 0; j < 2 * s; j++) st[(unsigned)((NS + 2 * s * NS + j) * KB_TILE) + vrow] = T(0);
-                if (is_hi) st[(unsigned)((NS + 2 * s * NS + 2 * s) * KB_TILE) + vrow] = T(0);
-            }
-        }
-    }
-    // a non-finite result is stored as it is (helper.go:142-172 has no guard) and flagged
-    if (ok && chk != chk) atomicOr(a.status + fi, (unsigned)KB_ST_NONFINITE);
 }
 
 template <typename T, int NS>
@@ -693,6 +240,26 @@ __global__ void __launch_bounds__(64, 1) srif_pair_dense_kernel(const StepArgs a
     if (first >= a.N) return;
     if (a.srif_tri && a.srif_dense[gw] == 0u) return;
     srif_pair_tile<T, NS, NM, FULL, EXT, true, PADM>(a, tile, half, lane, lds);
+}
+
+// kb_update_nl_steps_dev: a.nsteps Updates of the steady state in one launch (srif_pair_tile FUSED)
+template <typename T, int NS, int NM>
+__global__ void __launch_bounds__(64, (srif_pair_waves_per_simd<T, NS>())) srif_pair_fused_kernel(const StepArgs a) {
+    __shared__ T lds[NS * NS * 32];
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = blockIdx.x;
+    const int64_t tile = gw >> 1;
+    const int half = (int)(gw & 1);
+    if (tile * KB_TILE + half * 32 >= a.N) return;
+    srif_pair_tile<T, NS, NM, false, true, false, false, true>(a, tile, half, lane, lds);
+}
+
+template <typename T, int NS, int NM>
+static bool srif_pair_launch_fused(const Batch &b, const StepArgs &a) {
+    if (a.n != NS || a.p != NM || a.predict || !a.ext_phi || !a.srif_tri || a.srif_leftover || (a.flags & KB_FLAG_FULL_ESTIMATE)) return false;
+    if (a.ext_ld >= (int64_t(1) << 28)) return false;
+    KB_LAUNCH((srif_pair_fused_kernel<T, NS, NM>), dim3((unsigned)(2 * a.ntiles)), dim3(64), 0, b.stream, a);
+    return true;
 }
 
 template <typename T, int NS, int NM, bool PADM = false>

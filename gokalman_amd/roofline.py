@@ -74,7 +74,7 @@ def kernel_source_hash(root=None):
     from . import build as kb_build
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.h")) +
+    files = sorted(glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.h")) + glob.glob(os.path.join(root, "gokalman_amd", "csrc", "*.inc")) +
                    [os.path.join(root, "include", "gokalman_amd.h")])
     for f in files:
         h.update(os.path.basename(f).encode())

@@ -24,6 +24,7 @@ RULES = [
     (r"^void hybrid_reg_kernel<double, 6, 2, false, false", 0, 2, "config D(ii): Hybrid 6/2"),
     (r"^void srif_pair_kernel<float, 12, 6, false, (true|false), false>", 0, 2, "config E: SRIF 12/6 fp32"),
     (r"^void srif_pair_kernel<double, 12, 6, ", 0, 1, "SRIF 12/6 fp64, two lanes"),
+    (r"^void srif_pair_fused_kernel<float, 12, 6>", 48, 2, "config E time-fused (round 6; 40 B: the loop-carried panel at the 256-register cap)"),
     (r"^void vanilla_split_kernel<double, 12, 6, 0, 4, false, (true|false), (true|false), false, false, 0, false>", 0, 2, "Vanilla 12/6 exact, four lanes"),
     (r"^void vanilla_split_kernel<double, 12, 6, 0, 4, false, (true|false), false, false, false, (1|2), false>", 32, 2, "Vanilla 12/6 exact + AWGN / BatchNoise (round 6; 16-24 B: the noise vectors on top of the exact kernel's 256 registers)"),
     (r"^void vanilla_split_kernel<double, 12, 8, 0, 4, false, ", 0, 2, "Vanilla 12/8 exact, four lanes, S^-1 once per filter"),

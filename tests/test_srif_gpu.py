@@ -269,3 +269,71 @@ def test_srif_odd_states_shadow_follows_every_other_writer_of_the_state(n, p, dt
     b2 = _srif_batch(N, n, p, dtype, x1, P1, R)   # a second handle has its own shadow
     b, keep = b2, b
     run(2 * steps, x1, P1)
+
+
+@pytest.mark.parametrize("N,fail", [(4096, False), (1000, True), (70, True)])
+def test_srif_time_fused_steps_equal_single_steps_bit_for_bit(N, fail):
+    """kb_update_nl_steps_dev (round 6): T Prepare + Update pairs of config E's shape (12 / 6, fp32, zero-copy operands, steady state) in ONE
+    launch, the rows of (b, R) resident in registers between the steps -- the same operations in the same order as T single calls: the same
+    bits, kf.step and the per-step failure semantics included (a filter whose Phi is singular at step k skips that step only; its wave
+    reloads from memory at the next).  Also from a batch that is NOT in the steady state (behind a Predict(): the call falls back to T
+    launches), and for a shape without a fused kernel."""
+    import torch
+    n, p, T = 12, 6, 7
+    rng = np.random.default_rng(31 + N)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+    ld = N + 13                                   # (a leading dimension beyond N: the planar arrays' own)
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((T, N, n, n))
+    if fail:
+        Phi[2, 5, 3, :] = 0.0; Phi[2, N - 1, 0, :] = 0.0; Phi[5, 5, 1, :] = 0.0      # filter 5 fails steps 2 and 5, the last filter step 2
+    Ht = rng.standard_normal((T, N, p, n)); real = rng.standard_normal((T, N, p)); comp = real + 1e-2 * rng.standard_normal((T, N, p))
+
+    def planar(a):                                # [T][N][...] -> device [T][elems][ld] fp32, NaN behind N
+        out = torch.full((T, int(np.prod(a.shape[2:])), ld), float("nan"), dtype=torch.float32)
+        out[:, :, :N] = torch.from_numpy(a.reshape(T, N, -1).transpose(0, 2, 1).astype(np.float32))
+        return out.cuda()
+    dPhi, dH, dre, dco = planar(Phi), planar(Ht), planar(real), planar(comp)
+    torch.cuda.synchronize()
+    res = []
+    for fused in (True, False):
+        b = ga.FilterBatch(k.SRIF, n, p, 0, N, dtype=k.F32)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
+        if fused:
+            b.update_nl_steps_dev(dPhi.data_ptr(), dH.data_ptr(), ld, n * n * ld, p * n * ld, dre.data_ptr(), dco.data_ptr(), ld, p * ld, T)
+            assert "srif_pair_fused_kernel<float, 12, 6>" in b.last_kernel()
+        else:
+            for t in range(T):
+                k.check(k.lib().kb_prepare_dev(b._h, dPhi[t].data_ptr(), dH[t].data_ptr(), ld))
+                k.check(k.lib().kb_update_nl_dev(b._h, dre[t].data_ptr(), dco[t].data_ptr(), ld))
+        b.synchronize()
+        res.append((b.get(k.RAW_MAT), b.get(k.RAW_VEC), b.status().copy(), [b.filter_step(i) for i in (4, 5, 6, N - 1)], b.calls()))
+    assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64)) and np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
+    assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3] == ([T, T - 2, T, T - 1] if fail else [T] * 4) and res[0][4] == res[1][4] == T
+    if not fail:
+        assert not res[0][2].any()
+    else:
+        assert sorted(np.nonzero(res[0][2])[0].tolist()) == [5, N - 1]
+    # not in the steady state (a Predict() pending a dense R), and a shape without a fused kernel: T launches from the one call, same results as the loop
+    for shape, predict_first in (((12, 6), True), ((8, 4), False)):
+        nn, pp = shape
+        outs = []
+        for fused in (True, False):
+            b = ga.FilterBatch(k.SRIF, nn, pp, 0, N, dtype=k.F32)
+            b.set(k.X, x0[:, :nn], 1); b.set(k.P, P0[:, :nn, :nn], 2); b.set(k.R, R[:, :pp, :pp], 2, p_rows=pp); b.init()
+            sub = lambda a, r, c: np.ascontiguousarray(a[:, :, :r, :c]) if a.ndim == 4 else np.ascontiguousarray(a[:, :, :r])
+            qPhi, qH, qre, qco = planar(sub(Phi, nn, nn)), planar(sub(Ht, pp, nn)), planar(sub(real, pp, 0)), planar(sub(comp, pp, 0))
+            torch.cuda.synchronize()
+            if predict_first:
+                k.check(k.lib().kb_prepare_dev(b._h, qPhi[0].data_ptr(), qH[0].data_ptr(), ld)); b.predict_nl(snapshot=False)
+            if fused:
+                b.update_nl_steps_dev(qPhi.data_ptr(), qH.data_ptr(), ld, nn * nn * ld, pp * nn * ld, qre.data_ptr(), qco.data_ptr(), ld, pp * ld, T)
+            else:
+                for t in range(T):
+                    k.check(k.lib().kb_prepare_dev(b._h, qPhi[t].data_ptr(), qH[t].data_ptr(), ld))
+                    k.check(k.lib().kb_update_nl_dev(b._h, qre[t].data_ptr(), qco[t].data_ptr(), ld))
+            b.synchronize()
+            outs.append((b.get(k.RAW_MAT), b.get(k.RAW_VEC), b.status().copy()))
+        assert np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64)) and np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
+        assert np.array_equal(outs[0][2], outs[1][2])
