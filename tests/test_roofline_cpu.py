@@ -21,7 +21,7 @@ def test_counter_documents_are_bound_to_the_kernel_sources(tmp_path):
     for sub in ("gokalman_amd/csrc", "include"):
         os.makedirs(copy / sub, exist_ok=True)
     for f in os.listdir(os.path.join(ROOT, "gokalman_amd", "csrc")):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             shutil.copy(os.path.join(ROOT, "gokalman_amd", "csrc", f), copy / "gokalman_amd" / "csrc" / f)
     shutil.copy(os.path.join(ROOT, "include", "gokalman_amd.h"), copy / "include" / "gokalman_amd.h")
     assert rl.kernel_source_hash(str(copy)) == h
