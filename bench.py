@@ -336,6 +336,54 @@ def _hybrid_arbiter(ga, k):
             "rule": "engine error <= %g x oracle error + %g, worst and median filter (worst step of each)" % (hp.FACTOR, hp.FLOOR), "ok": bool(ok)}
 
 
+def _hybrid_fused_parity(ga, k):
+    """kb_update_nl_steps_dev on the Hybrid EKF 6/2 batch against T single Prepare + Update calls on the same arrays (4096 filters x 10
+    steps): the same bits; and both against the oracle on a well-conditioned variant of the problem (R = 1e-3) at 1e-9."""
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    from gokalman_amd import synth
+    N, T, n, p = 4096, 10, 6, 2
+    rng = np.random.default_rng(321)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10, 10, 10, 1, 1, 1]
+    Rm = np.diag([1e-3, 1e-3])
+    g = torch.Generator(device="cuda"); g.manual_seed(19)
+    Phi = (torch.eye(n, dtype=torch.float64, device="cuda").reshape(1, n * n, 1) + 1e-2 * torch.randn(T, n * n, N, dtype=torch.float64, device="cuda", generator=g)).contiguous()
+    Ht = torch.randn(T, p * n, N, dtype=torch.float64, device="cuda", generator=g)
+    real = torch.randn(T, p, N, dtype=torch.float64, device="cuda", generator=g)
+    comp = (real + 1e-3 * torch.randn(T, p, N, dtype=torch.float64, device="cuda", generator=g)).contiguous()
+    torch.cuda.synchronize()
+    outs = []
+    for fused in (True, False):
+        b = ga.FilterBatch(k.HYBRID, n, p, 0, N)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, Rm, 2, p_rows=p); b.init(); b.enable_ekf()
+        if fused:
+            b.update_nl_steps_dev(Phi.data_ptr(), Ht.data_ptr(), N, n * n * N, p * n * N, real.data_ptr(), comp.data_ptr(), N, p * N, T)
+            kernel = b.last_kernel()
+        else:
+            for t in range(T):
+                k.check(k.lib().kb_prepare_dev(b._h, Phi[t].data_ptr(), Ht[t].data_ptr(), N))
+                k.check(k.lib().kb_update_nl_dev(b._h, real[t].data_ptr(), comp[t].data_ptr(), N))
+        b.synchronize()
+        outs.append((b.get(k.STATE), b.get(k.COVAR), int(np.count_nonzero(b.status()))))
+    same = bool(np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64)) and np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64)))
+    M = 256
+    Ph, Hh = Phi[:, :, :M].cpu().numpy(), Ht[:, :, :M].cpu().numpy()
+    rh, ch = real[:, :, :M].cpu().numpy(), comp[:, :, :M].cpu().numpy()
+    xo, Po, nerr = [], [], 0
+    for i in range(M):
+        f = orc.Filter.hybrid(x0[i], P0[i], None, Rm, p); f.enable_ekf()
+        for t in range(T):
+            f.prepare(Ph[t, :, i].reshape(n, n), Hh[t, :, i].reshape(p, n))
+            nerr += f.update_nl(rh[t, :, i], ch[t, :, i]) != orc.OK
+        xo.append(f.state()); Po.append(f.covariance())
+    ex, eP = synth.rel_frobenius(outs[0][0][:M], np.array(xo)), synth.rel_frobenius(outs[0][1][:M], np.array(Po))
+    return {"filters": N, "steps": T, "kernel": kernel, "bit_identical_to_single_steps": same, "oracle_filters": M, "max_rel_frobenius_state": ex,
+            "max_rel_frobenius_covariance": eP, "tolerance": 1e-9,
+            "ok": bool(same and ex <= 1e-9 and eP <= 1e-9 and nerr == 0 and outs[0][2] == 0 and "fused" in kernel)}
+
+
 def _srif_fused_parity(ga, k):
     """kb_update_nl_steps_dev against T single Prepare + Update calls on the same arrays (4096 filters x 10 steps): the same bits; and the
     fp32 result against the fp64 oracle within SRIF_F32_TOL."""
@@ -735,6 +783,38 @@ def main():
                                "roofline": rl.hbm_roofline(hms, M, rl.algorithmic_bytes("hybrid", hn, hp), rl.moved_bytes("hybrid", hn, hp),
                                                            *rl.load_traffic(ROOT, "hybrid_reg_kernel<double, 6, 2, true, false, true")),
                                "filters_with_error_status": int(hbad.item())}
+        if args.fused_steps > 0 and rank == 0:
+            # D(ii) with the caller loop `for k { Prepare(Phi_k, Htilde_k); Update(real_k, computed_k) }` inside ONE launch (round 6, kb_update_nl_steps_dev,
+            # kb_hybrid_fused.hip): distinct Phi / Htilde / observations per step, x and P resident in registers between the steps; the same bits as T single calls
+            TF = 10
+            PhiT = (torch.eye(hn, dtype=torch.float64, device=dev).reshape(1, hn * hn, 1)
+                    + 1e-2 * torch.randn(TF, hn * hn, M, dtype=torch.float64, device=dev, generator=g)).contiguous()
+            HtT = torch.randn(TF, hp * hn, M, dtype=torch.float64, device=dev, generator=g)
+            realT = torch.randn(TF, hp, M, dtype=torch.float64, device=dev, generator=g)
+            compT = realT + 1e-3 * torch.randn(TF, hp, M, dtype=torch.float64, device=dev, generator=g)
+            torch.cuda.synchronize()
+
+            def hfstep():
+                hb.update_nl_steps_dev(PhiT.data_ptr(), HtT.data_ptr(), M, hn * hn * M, hp * hn * M, realT.data_ptr(), compT.data_ptr(), M, hp * M, TF)
+            warm_clocks()
+            for _ in range(3):
+                hfstep()
+            hb.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(hs)
+            for _ in range(5):
+                hfstep()
+            g1.record(hs)
+            hb.synchronize()
+            hfms = g0.elapsed_time(g1) / 5
+            moved_hf = rl.moved_bytes("hybrid", hn, hp) - 8 * (hn + rl.tri(hn)) - 8 * rl.tri(hp)   # x, P are not re-read, R is read once per launch
+            extra["hybrid_ekf"]["fused"] = {"config": "the caller loop inside one launch (kb_update_nl_steps_dev): %d steps per launch, distinct Phi / Htilde / observations per step" % TF,
+                                            "steps_per_launch": TF, "ms_per_launch": hfms, "kernel_ms": hfms / TF, "value": M * TF / (hfms * 1e-3),
+                                            "unit": "filter-update steps/s (1 GPU, kb_update_nl_steps_dev)", "kernel": hb.last_kernel(),
+                                            "filters_with_error_status": int(np.count_nonzero(hb.status())),
+                                            "roofline": rl.hbm_roofline(hfms / TF, M, rl.algorithmic_bytes("hybrid", hn, hp), moved_hf, None,
+                                                                        {"live": False, "analytic": "packed working set less the resident x, P and R"})}
+            del PhiT, HtT, realT, compT
         del hb, Phi, Ht, real, comp
         # ---- configs[3] D(ii) at its stated size on ONE GPU: world x M filters = 8 388 608 by default, the
         # same generator; the first 4096 filters must come out bit-identical to the same filters run as a 4096-filter batch (a filter's
@@ -1037,6 +1117,8 @@ def main():
                 extra["squareroot"]["fused"]["parity"] = _leg_parity(ga, k, synth, "squareroot_fused")
             if "srif_fp32" in extra and "fused" in extra["srif_fp32"]:
                 extra["srif_fp32"]["fused"]["parity"] = _srif_fused_parity(ga, k)
+            if "hybrid_ekf" in extra and "fused" in extra["hybrid_ekf"]:
+                extra["hybrid_ekf"]["fused"]["parity"] = _hybrid_fused_parity(ga, k)
         if not args.no_cpu_baseline:   # rank 0 of any world size: the host cores are the same ones
             out["cpu_baseline"] = _cpu_baseline(d)
         # the full document goes to a side file; the ONE stdout line is its compact headline (round 5's 22.8 KB line was not parsed)

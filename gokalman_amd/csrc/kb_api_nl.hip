@@ -157,8 +157,8 @@ int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs
 }
 
 // The caller loop `for k { kf.Prepare(Phi_k, Htilde_k); kf.Update(real_k, computed_k) }` from one call (round 6).  SRIF 12 / 6 fp32 in the
-// steady state (config E's shape): ONE launch, the own rows of (b, R) resident in registers between the steps (kb_srif_pair.h FUSED);
-// every other batch: nsteps Prepare + Update launches back to back on the handle's stream.
+// steady state (config E's shape) and HybridKF 6 / 1..3 fp64 (configs[3] D(ii)): ONE launch, the state resident in registers between the
+// steps (kb_srif_pair.h FUSED, kb_hybrid_fused.hip); every other batch: nsteps Prepare + Update launches back to back on the handle's stream.
 int kb_update_nl_steps_dev(kb_batch *b, const void *phi, const void *htilde, int64_t ld, int64_t phi_step, int64_t htilde_step,
                            const void *real_obs, const void *computed_obs, int64_t ld_obs, int64_t obs_step, int nsteps) {
     int rc = ready_nl(b);
@@ -189,6 +189,26 @@ int kb_update_nl_steps_dev(kb_batch *b, const void *phi, const void *htilde, int
                 b->srif_tri = 1; b->snc = 0; b->locked = 1;
                 return KB_OK;
             }
+        }
+    }
+    if (b->kind == KB_HYBRID && b->dtype == KB_F64 && b->n == 6 && b->p >= 1 && b->p <= 3 && nsteps > 1 && !b->snc) {
+        StepArgs a;
+        fill_step_args(*b, a);
+        a.ext_phi = phi; a.ext_h = htilde; a.ext_ld = ld; a.ext_phi_step = phi_step; a.ext_h_step = htilde_step;
+        a.y = real_obs; a.y_es = ld_obs; a.y_ts = KB_TILE; a.y_step = obs_step;
+        a.y2 = computed_obs; a.y2_es = ld_obs; a.y2_ts = KB_TILE; a.y2_step = obs_step;
+        a.nsteps = nsteps; a.predict = 0;
+        begin_kernel_record();
+        const bool done = launch_hybrid_fused(*b, a);
+        end_kernel_record(*b);
+        if (done) {
+            KB_HIP(hipGetLastError());
+            b->step += nsteps; b->calls += nsteps;
+            b->ext_phi = (const char *)phi + (size_t)(nsteps - 1) * (size_t)phi_step * w;
+            b->ext_h = (const char *)htilde + (size_t)(nsteps - 1) * (size_t)htilde_step * w; b->ext_ld = ld;
+            b->have[KB_F] = b->have[KB_H] = true;
+            b->snc = 0; b->locked = 1;
+            return KB_OK;
         }
     }
     for (int t = 0; t < nsteps; t++) {

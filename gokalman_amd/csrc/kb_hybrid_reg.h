@@ -66,207 +66,9 @@ __global__ void __launch_bounds__(64 * HYB_WPB, ((SNCP && FULL) || (PAD && NS > 
     };
     KB_WITH_STATE_POLICY(a, load_state);
     __builtin_amdgcn_sched_barrier(0);
-    // :114-116 PBar = Phi P Phi^T (upper triangle)
-    T Pm[TR];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        T fp[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += F[i * NS + l] * P[symi(l, k)];
-            fp[k] = s;
-        }
-#pragma unroll
-        for (int j = i; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < NS; k++) s += fp[k] * F[j * NS + k];
-            Pm[symi(i, j)] = s;
-        }
-    }
-    if (SNCP && a.snc) {   // :117-123 PBar += Gamma Q Gamma^T (PreparePNT was called for this step; wave-uniform), q <= 3
-        constexpr int NQ = 3;
-        const int q = a.L.nq;
-        T Gm[NS * NQ], Qs[tri(NQ)], GQ[NS * NQ];
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int c = 0; c < NQ; c++) Gm[i * NQ + c] = (c < q && i < rn) ? ldnt(mo, a.L.mo_G + i * q + c) : T(0);
-#pragma unroll
-        for (int c = 0; c < NQ; c++)
-#pragma unroll
-            for (int l = 0; l <= c; l++) Qs[symi(l, c)] = (c < q) ? ldnt(mo, a.L.mo_Q + symi(l, c)) : T(0);
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int c = 0; c < NQ; c++) {
-                T s2 = T(0);
-#pragma unroll
-                for (int l = 0; l < NQ; l++) s2 += Gm[i * NQ + l] * Qs[symi(l, c)];
-                GQ[i * NQ + c] = s2;
-            }
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = i; j < NS; j++) {
-                T s2 = T(0);
-#pragma unroll
-                for (int c = 0; c < NQ; c++) s2 += GQ[i * NQ + c] * Gm[j * NQ + c];
-                Pm[symi(i, j)] += s2;
-            }
-    }
-    [[maybe_unused]] T xb[NS];
-    if constexpr (!EKF) smv<T, NS, NS>(F, x, xb);  // :164-165 xBar = Phi x
-    if (SNCP && a.predict) {   // Predict() (hybrid.go:125-143, wave-uniform): estimate = {xBar (CKF) or the hard-coded zero vector (EKF), PBar}
-        T chk0 = T(0);
-#pragma unroll
-        for (int e = 0; e < TR; e++) chk0 += Pm[e] * T(0);
-        if (chk0 != chk0) { if (active) fail_step(a, tile * KB_TILE + lane, (unsigned)KB_ST_NONFINITE); return; }
-        if (active) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                if (i < rn) { if constexpr (EKF) stt(st, i, T(0)); else stt(st, i, xb[i]); }
-            }
-#pragma unroll
-            for (int j = 0; j < NS; j++)
-#pragma unroll
-                for (int i = 0; i <= j; i++)
-                    if (j < rn) stt(st, rn + symi(i, j), Pm[symi(i, j)]);
-            if constexpr (FULL) {
-                T *es = (T *)a.est + tile * ((int64_t)KB_TILE * a.L.es_elems) + lane;
-#pragma unroll
-                for (int j = 0; j < NS; j++)
-#pragma unroll
-                    for (int i = 0; i <= j; i++)
-                        if (j < rn) stnt(es, a.L.es_ppred + symi(i, j), Pm[symi(i, j)]);
-#pragma unroll
-                for (int i = 0; i < NS; i++)
-#pragma unroll
-                    for (int c = 0; c < NM; c++)
-                        if (i < rn && c < rp) stnt(es, a.L.es_gain + i * a.pmax + c, T(0));
-#pragma unroll
-                for (int r = 0; r < NM; r++)
-                    if (r < rp) { stnt(es, a.L.es_innov + r, T(0)); stnt(es, a.L.es_yhat + r, T(0)); stnt(es, a.L.es_dobs + r, T(0)); }
-            }
-        }
-        return;
-    }
-    if constexpr (SNCP) {
-#pragma unroll
-        for (int r = 0; r < NM; r++)
-#pragma unroll
-            for (int l = 0; l < NS; l++)
-                H[r * NS + l] = (r < rp && l < rn) ? (EXT ? __builtin_nontemporal_load(eh + (int64_t)(r * rn + l) * a.ext_ld) : ldnt(mo, a.L.mo_H + r * rn + l)) : T(0);
-#pragma unroll
-        for (int c = 0; c < NM; c++)
-#pragma unroll
-            for (int r = 0; r <= c; r++) R[symi(r, c)] = (c < rp) ? ldnt(mo, a.L.mo_R + symi(r, c)) : (r == c ? T(1) : T(0));
-    }
-    // :146-153 K = PBar H^T (H PBar H^T + R)^-1
-    T PHt[NS * NM], S[NM * NM], Si[NM * NM], K[NS * NM];
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int c = 0; c < NM; c++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += Pm[symi(i, l)] * H[c * NS + l];
-            PHt[i * NM + c] = s;
-        }
-#pragma unroll
-    for (int r = 0; r < NM; r++)
-#pragma unroll
-        for (int c = 0; c < NM; c++) {
-            T s = T(0);
-#pragma unroll
-            for (int i = 0; i < NS; i++) s += H[r * NS + i] * PHt[i * NM + c];
-            S[r * NM + c] = s + R[symi(r, c)];
-        }
-    unsigned err = inverse_lu<T, NM>(S, Si, rp) ? KB_ST_SINGULAR : 0u;
-    smm_nn<T, NS, NM, NM>(PHt, Si, K);
-    // :156-173
-    T innov[NM], xn[NS];
-#pragma unroll
-    for (int r = 0; r < NM; r++) {
-        if constexpr (SNCP) {
-            real[r] = (active && r < rp) ? __builtin_nontemporal_load(yr + (int64_t)r * a.y_es) : T(0);
-            const T cv = (active && r < rp) ? __builtin_nontemporal_load(yc + (int64_t)r * a.y2_es) : T(0);
-            yv[r] = real[r] - cv;
-        }
-        innov[r] = T(0);
-    }
-    if constexpr (EKF) {
-        smv<T, NS, NM>(K, yv, xn);
-    } else {
-#pragma unroll
-        for (int r = 0; r < NM; r++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += H[r * NS + l] * xb[l];
-            innov[r] = yv[r] - s;
-        }
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            T s = T(0);
-#pragma unroll
-            for (int c = 0; c < NM; c++) s += K[i * NM + c] * innov[c];
-            xn[i] = xb[i] + s;
-        }
-    }
-    // :174-182 Joseph form (upper): K R K^T + A PBar A^T
-    T Pn[TR];
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        T kr[NM];
-#pragma unroll
-        for (int c = 0; c < NM; c++) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < NM; k++) s += K[i * NM + k] * R[symi(k, c)];
-            kr[c] = s;
-        }
-#pragma unroll
-        for (int j = i; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int c = 0; c < NM; c++) s += kr[c] * K[j * NM + c];
-            Pn[symi(i, j)] = s;
-        }
-    }
-    T A[NS * NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int c = 0; c < NM; c++) s += K[i * NM + c] * H[c * NS + j];
-            A[i * NS + j] = (i == j ? T(1) : T(0)) - s;
-        }
-    T chk = T(0);
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-        T ap[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            T s = T(0);
-#pragma unroll
-            for (int l = 0; l < NS; l++) s += A[i * NS + l] * Pm[symi(l, k)];
-            ap[k] = s;
-        }
-#pragma unroll
-        for (int j = i; j < NS; j++) {
-            T s = T(0);
-#pragma unroll
-            for (int k = 0; k < NS; k++) s += ap[k] * A[j * NS + k];
-            Pn[symi(i, j)] = s + Pn[symi(i, j)];
-            chk += Pn[symi(i, j)] * T(0);
-        }
-        chk += xn[i] * T(0);
-    }
-    if (chk != chk) err |= KB_ST_NONFINITE;
+    // (the arithmetic of the step -- PBar .. the non-finite screen -- is kb_hybrid_reg_step.inc: this kernel and the time-fused one of
+    // kb_hybrid_fused.hip compile the SAME text)
+#include "kb_hybrid_reg_step.inc"
     if (active && !err) {
         auto store_state = [&](auto NT) {
             constexpr bool nt = decltype(NT)::value;

@@ -212,6 +212,7 @@ bool launch_hybrid_padded(const Batch &b, const StepArgs &a);    // kb_hybrid_pa
 bool launch_hybrid_padded8(const Batch &b, const StepArgs &a);   // kb_hybrid_pad8.hip: n <= 8 / p <= 4
 bool hybrid_split_ok(const Batch &b, const StepArgs &a);
 bool launch_hybrid_split(const Batch &b, const StepArgs &a);     // kb_hybrid_split.hip: 8 < n <= 16, p <= 6, on the split-lane Vanilla kernel (HYB)
+bool launch_hybrid_fused(const Batch &b, const StepArgs &a);    // kb_hybrid_fused.hip: kb_update_nl_steps_dev, 6 / 1..3 fp64, the caller loop in one launch (round 6)
 bool launch_hybrid_strict(const Batch &b, const StepArgs &a);   // kb_hybrid_strict.hip: KB_FLAG_STRICT_SYMCHECK on registers (6 / 1..3, fp64)
 bool srif_reg_ok(const Batch &b, const StepArgs &a);
 // kb_srif_split_*.hip: fp64, one filter over 4 (n <= 12) / 8 (n <= 16) lanes, the state dimension at compile time, p at run time (kb_srif_split.h)

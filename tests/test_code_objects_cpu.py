@@ -22,6 +22,7 @@ RULES = [
     (r"^void squareroot_reg_kernel<double, 6, 3, 0, false, false, false, false, true>", 0, 1, "SquareRoot 6/3 time-fused"),
     (r"^void information_reg_kernel<double, 6, 3, 0, false, false, false, false, false>", 0, 2, "Information 6/3"),
     (r"^void hybrid_reg_kernel<double, 6, 2, false, false", 0, 2, "config D(ii): Hybrid 6/2"),
+    (r"^void hybrid_fused_kernel<double, 6, (1|2|3), (true|false)>", 0, 2, "config D(ii) time-fused (round 6)"),
     (r"^void srif_pair_kernel<float, 12, 6, false, (true|false), false>", 0, 2, "config E: SRIF 12/6 fp32"),
     (r"^void srif_pair_kernel<double, 12, 6, ", 0, 1, "SRIF 12/6 fp64, two lanes"),
     (r"^void srif_pair_fused_kernel<float, 12, 6>", 48, 2, "config E time-fused (round 6; 40 B: the loop-carried panel at the 256-register cap)"),

@@ -902,3 +902,59 @@ def test_time_fused_launch_skips_only_the_failed_step_like_single_steps(kind, no
     else:
         assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
         assert np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
+
+
+@pytest.mark.parametrize("p,ekf,N", [(2, True, 4096), (2, False, 1000), (1, True, 200), (3, False, 70)])
+def test_hybrid_time_fused_steps_equal_single_steps_bit_for_bit(p, ekf, N):
+    """kb_update_nl_steps_dev on a HybridKF batch (round 6, kb_hybrid_fused.hip): T Prepare + Update pairs of the statOD shapes 6 / 1..3 in ONE
+    launch, x and P resident in registers between the steps -- the arithmetic is the text the one-step kernel compiles
+    (kb_hybrid_reg_step.inc): the same bits as T single calls, with a non-finite observation in the middle of the sequence (that step fails
+    for that filter only: state, kf.step and status as in the loop of single calls), and against the oracle."""
+    import torch
+    n, T = 6, 8
+    rng = np.random.default_rng(100 * p + N)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10, 10, 10, 1, 1, 1]
+    Rm = np.diag(np.full(p, 1e-3))
+    ld = N + 5
+    Phi = np.eye(n) + 1e-2 * rng.standard_normal((T, N, n, n))
+    Ht = rng.standard_normal((T, N, p, n)); real = rng.standard_normal((T, N, p)); comp = real + 1e-3 * rng.standard_normal((T, N, p))
+    real[3, 9, 0] = np.nan; real[5, 9, p - 1] = np.inf; real[3, N - 1, 0] = np.nan      # filter 9 fails steps 3 and 5, the last filter step 3
+
+    def planar(a):
+        out = torch.full((T, int(np.prod(a.shape[2:])), ld), float("nan"), dtype=torch.float64)
+        out[:, :, :N] = torch.from_numpy(a.reshape(T, N, -1).transpose(0, 2, 1).copy())
+        return out.cuda()
+    dPhi, dH, dre, dco = planar(Phi), planar(Ht), planar(real), planar(comp)
+    torch.cuda.synchronize()
+    res = []
+    for fused in (True, False):
+        b = ga.FilterBatch(k.HYBRID, n, p, 0, N)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, Rm, 2, p_rows=p); b.init()
+        if ekf:
+            b.enable_ekf()
+        if fused:
+            b.update_nl_steps_dev(dPhi.data_ptr(), dH.data_ptr(), ld, n * n * ld, p * n * ld, dre.data_ptr(), dco.data_ptr(), ld, p * ld, T)
+            assert "hybrid_fused_kernel<double, 6, %d, %s>" % (p, "true" if ekf else "false") in b.last_kernel()
+        else:
+            for t in range(T):
+                k.check(k.lib().kb_prepare_dev(b._h, dPhi[t].data_ptr(), dH[t].data_ptr(), ld))
+                k.check(k.lib().kb_update_nl_dev(b._h, dre[t].data_ptr(), dco[t].data_ptr(), ld))
+        b.synchronize()
+        res.append((b.get(k.STATE), b.get(k.COVAR), b.status().copy(), [b.filter_step(i) for i in (8, 9, 10, N - 1)], b.calls()))
+    assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64)) and np.array_equal(res[0][1].view(np.uint64), res[1][1].view(np.uint64))
+    assert np.array_equal(res[0][2], res[1][2]) and sorted(np.nonzero(res[0][2])[0].tolist()) == [9, N - 1]
+    assert res[0][3] == res[1][3] == [T, T - 2, T, T - 1] and res[0][4] == res[1][4] == T
+    assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][1]).all()
+    # ... and the oracle on the filters that never failed (first 64)
+    idx = [i for i in range(64) if i != 9]
+    xo, Po = [], []
+    for i in idx:
+        f = orc.Filter.hybrid(x0[i], P0[i], None, Rm, p)
+        if ekf:
+            f.enable_ekf()
+        for t in range(T):
+            f.prepare(Phi[t, i], Ht[t, i])
+            assert f.update_nl(real[t, i], comp[t, i]) == orc.OK
+        xo.append(f.state()); Po.append(f.covariance())
+    assert synth.rel_frobenius(res[0][0][idx], np.array(xo)) <= 1e-9 and synth.rel_frobenius(res[0][1][idx], np.array(Po)) <= 1e-9
