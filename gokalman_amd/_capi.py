@@ -114,6 +114,13 @@ def lib():
             raise RuntimeError(
                 "gokalman_amd: %s is missing -- build the HIP extension first "
                 "(python -m gokalman_amd.build or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 and this library NEEDs the same SONAME.  Loaded after
+        # torch, the library binds torch's copy (the order every test and bench.py had); loaded BEFORE it -- __graft_entry__.build()
+        # followed by smoke() in one process -- the system's copy came first and kb_create then saw no device (round 6).  So: torch first.
+        try:
+            import torch  # noqa: F401
+        except Exception:   # a host without PyTorch (the C++ / Go callers never come through here)
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
