@@ -154,3 +154,63 @@ def test_random_nldkf_call_sequences_match_the_oracle(kind, n, p, dtype, tol, se
     assert within(synth.rel_frobenius(est.state(), np.array(xs)), tol, "state")
     assert within(synth.rel_frobenius(est.covariance(), np.array(Ps)), tol, "covariance")
     assert not b.status().any()
+
+
+@pytest.mark.parametrize("kind,n,p,dtype,seed", [(k.SRIF, 12, 6, k.F32, 1), (k.SRIF, 12, 6, k.F32, 2), (k.HYBRID, 6, 2, k.F64, 3), (k.HYBRID, 6, 3, k.F64, 4),
+                                                 (k.SRIF, 8, 4, k.F64, 5)])
+def test_random_sequences_of_multi_step_single_step_and_predict_calls(kind, n, p, dtype, seed):
+    """kb_update_nl_steps_dev (round 6) inside random call sequences -- multi-step calls of random length, single Prepare + Update pairs,
+    Predict() (after which the SRIF batch is NOT in its steady state: the next multi-step call must fall back to single launches for its
+    first step... or all of them), an occasional singular Phi / non-finite observation -- against a twin batch driven by single calls only:
+    the same bits, status words, per-filter kf.step and call count after every segment.  (8 / 4 fp64 has no fused kernel: the call is T launches.)"""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    N, ld = 150, 160
+    tdt, npdt = (torch.float32, np.float32) if dtype == k.F32 else (torch.float64, np.float64)
+    x0 = rng.standard_normal((N, n))
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * (n // 2) + [1.0] * (n - n // 2)
+    R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
+
+    def new():
+        b = ga.FilterBatch(kind, n, p, 0, N, dtype=dtype)
+        b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R if kind == k.SRIF else R[0], 2, p_rows=p); b.init()
+        if kind == k.HYBRID and seed % 2:
+            b.enable_ekf()
+        return b
+    a, s = new(), new()
+
+    def planar(arr, T):
+        out = torch.full((T, int(np.prod(arr.shape[2:])), ld), float("nan"), dtype=tdt)
+        out[:, :, :N] = torch.from_numpy(arr.reshape(T, N, -1).transpose(0, 2, 1).astype(npdt))
+        return out.cuda()
+    for seg in range(12):
+        what = rng.choice(["multi", "single", "predict"], p=[0.5, 0.3, 0.2])
+        T = int(rng.integers(2, 6)) if what == "multi" else 1
+        Phi = np.eye(n) + 1e-2 * rng.standard_normal((T, N, n, n))
+        Ht = rng.standard_normal((T, N, p, n)); real = rng.standard_normal((T, N, p)); comp = real + 1e-2 * rng.standard_normal((T, N, p))
+        if rng.random() < 0.4:   # somebody fails somewhere in this segment
+            t_bad, f_bad = int(rng.integers(0, T)), int(rng.integers(0, N))
+            if kind == k.SRIF:
+                Phi[t_bad, f_bad, 1, :] = 0.0
+            else:
+                real[t_bad, f_bad, 0] = np.nan
+        dPhi, dH, dre, dco = planar(Phi, T), planar(Ht, T), planar(real, T), planar(comp, T)
+        torch.cuda.synchronize()
+        if what == "predict":
+            for b in (a, s):
+                k.check(k.lib().kb_prepare_dev(b._h, dPhi[0].data_ptr(), dH[0].data_ptr(), ld)); b.predict_nl(snapshot=False)
+        else:
+            if what == "multi":
+                a.update_nl_steps_dev(dPhi.data_ptr(), dH.data_ptr(), ld, n * n * ld, p * n * ld, dre.data_ptr(), dco.data_ptr(), ld, p * ld, T)
+            else:
+                k.check(k.lib().kb_prepare_dev(a._h, dPhi[0].data_ptr(), dH[0].data_ptr(), ld))
+                k.check(k.lib().kb_update_nl_dev(a._h, dre[0].data_ptr(), dco[0].data_ptr(), ld))
+            for t in range(T):
+                k.check(k.lib().kb_prepare_dev(s._h, dPhi[t].data_ptr(), dH[t].data_ptr(), ld))
+                k.check(k.lib().kb_update_nl_dev(s._h, dre[t].data_ptr(), dco[t].data_ptr(), ld))
+        a.synchronize(); s.synchronize()
+        for field in (k.RAW_MAT, k.RAW_VEC) if kind == k.SRIF else (k.STATE, k.COVAR):
+            ga_, gs_ = a.get(field), s.get(field)
+            assert np.array_equal(np.isnan(ga_), np.isnan(gs_)) and np.array_equal(np.nan_to_num(ga_).view(np.uint64), np.nan_to_num(gs_).view(np.uint64)), (seg, what, field)
+        assert np.array_equal(a.status(), s.status()), (seg, what)
+        assert a.calls() == s.calls() and [a.filter_step(i) for i in (0, 7, N - 1)] == [s.filter_step(i) for i in (0, 7, N - 1)], (seg, what)
