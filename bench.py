@@ -859,6 +859,36 @@ def main():
                                                "roofline": rl.hbm_roofline(bms, MT, rl.algorithmic_bytes("hybrid", hn, hp), rl.moved_bytes("hybrid", hn, hp), None, {"analytic": "packed working set"}),
                                                "first_4096_filters_bit_identical_to_a_4096_filter_batch": same,
                                                "filters_with_error_status": int(np.count_nonzero(big.status()))}
+            if args.fused_steps > 0:
+                # ... and with the caller loop inside one launch (kb_update_nl_steps_dev; the 1.8 GB state block is streamed: kb_hybrid_fused.hip takes the
+                # non-temporal arm of the state policy): 4 steps per launch, distinct operands per step
+                TFE = 4
+                PhiE = (torch.eye(hn, dtype=torch.float64, device=dev).reshape(1, hn * hn, 1)
+                        + 1e-2 * torch.randn(TFE, hn * hn, MT, dtype=torch.float64, device=dev, generator=g2)).contiguous()
+                HtE = torch.randn(TFE, hp * hn, MT, dtype=torch.float64, device=dev, generator=g2)
+                realE = torch.randn(TFE, hp, MT, dtype=torch.float64, device=dev, generator=g2)
+                compE = realE + 1e-3 * torch.randn(TFE, hp, MT, dtype=torch.float64, device=dev, generator=g2)
+                torch.cuda.synchronize()
+
+                def efstep():
+                    big.update_nl_steps_dev(PhiE.data_ptr(), HtE.data_ptr(), MT, hn * hn * MT, hp * hn * MT, realE.data_ptr(), compE.data_ptr(), MT, hp * MT, TFE)
+                warm_clocks()
+                efstep(); efstep()
+                big.synchronize()
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record(bs)
+                for _ in range(3):
+                    efstep()
+                c1.record(bs)
+                big.synchronize()
+                efms = c0.elapsed_time(c1) / 3
+                moved_ef = rl.moved_bytes("hybrid", hn, hp) - 8 * (hn + rl.tri(hn)) - 8 * rl.tri(hp)
+                extra["hybrid_ekf"]["ensemble"]["fused"] = {"steps_per_launch": TFE, "ms_per_launch": efms, "kernel_ms": efms / TFE, "value": MT * TFE / (efms * 1e-3),
+                                                            "unit": "filter-update steps/s (1 GPU, kb_update_nl_steps_dev)", "kernel": big.last_kernel(),
+                                                            "filters_with_error_status": int(np.count_nonzero(big.status())),
+                                                            "roofline": rl.hbm_roofline(efms / TFE, MT, rl.algorithmic_bytes("hybrid", hn, hp), moved_ef, None,
+                                                                                        {"live": False, "analytic": "packed working set less the resident x, P and R"})}
+                del PhiE, HtE, realE, compE
             del big, small, PhiT, HtT, realT, compT
             torch.cuda.empty_cache()
 

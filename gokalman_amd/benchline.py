@@ -103,6 +103,8 @@ def headline(doc, full_path=None):
         for sub in ("fused", "ensemble"):
             if isinstance(leg.get(sub), dict):
                 legs[name + "." + sub] = _leg(leg[sub])
+                if isinstance(leg[sub].get("fused"), dict):
+                    legs[name + "." + sub + ".fused"] = _leg(leg[sub]["fused"])
     if legs:
         out["legs"] = legs
     if full_path:

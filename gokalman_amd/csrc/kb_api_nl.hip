@@ -168,7 +168,7 @@ int kb_update_nl_steps_dev(kb_batch *b, const void *phi, const void *htilde, int
     if (nsteps < 1) { set_error("nsteps must be >= 1"); return KB_ERR_INVALID; }
     if (b->kind == KB_BATCH_LS) { set_error("BatchKF has no multi-step update"); return KB_ERR_UNSUPPORTED; }
     const size_t w = b->esize();
-    if (b->kind == KB_SRIF && b->dtype == KB_F32 && b->n == 12 && b->p == 6 && nsteps > 1 && !(b->flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STATEMENT_KERNELS))) {
+    if (b->kind == KB_SRIF && b->dtype == KB_F32 && ((b->n == 12 && b->p == 6) || (b->n == 6 && b->p == 2)) && nsteps > 1 && !(b->flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STATEMENT_KERNELS))) {
         if (b->srif_leftover && hipStreamQuery(b->stream) == hipSuccess) after_sync(*b);
         if (b->srif_tri && !b->srif_leftover) {
             StepArgs a;

@@ -55,22 +55,30 @@ __global__ void __launch_bounds__(64, 2) hybrid_fused_kernel(const StepArgs a) {
             yv[r] = real[r] - cv;
         }
         if (reload) {   // the first step, or some filter of this wave failed the last one (its registers hold what the failed step made of them)
+            auto load_state = [&](auto NT) {   // cache policy of the state block: kb_vanilla_reg.h (a block beyond the Infinity Cache is streamed)
+                constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-            for (int i = 0; i < NS; i++) x[i] = ldp<false>(st, i);
+                for (int i = 0; i < NS; i++) x[i] = ldp<nt>(st, i);
 #pragma unroll
-            for (int j = 0; j < NS; j++)
+                for (int j = 0; j < NS; j++)
 #pragma unroll
-                for (int i = 0; i <= j; i++) P[symi(i, j)] = ldp<false>(st, rn + symi(i, j));
+                    for (int i = 0; i <= j; i++) P[symi(i, j)] = ldp<nt>(st, rn + symi(i, j));
+            };
+            KB_WITH_STATE_POLICY(a, load_state);
         }
         __builtin_amdgcn_sched_barrier(0);
 #include "kb_hybrid_reg_step.inc"
         if (active && !err) {
+            auto store_state = [&](auto NT) {
+                constexpr bool nt = decltype(NT)::value;
 #pragma unroll
-            for (int i = 0; i < NS; i++) stp<false>(st, i, xn[i]);
+                for (int i = 0; i < NS; i++) stp<nt>(st, i, xn[i]);
 #pragma unroll
-            for (int j = 0; j < NS; j++)
+                for (int j = 0; j < NS; j++)
 #pragma unroll
-                for (int i = 0; i <= j; i++) stp<false>(st, rn + symi(i, j), Pn[symi(i, j)]);
+                    for (int i = 0; i <= j; i++) stp<nt>(st, rn + symi(i, j), Pn[symi(i, j)]);
+            };
+            KB_WITH_STATE_POLICY(a, store_state);
         }
         if (active && err) fail_step(a, fi, err);   // hybrid.go:150-152 returns before kf.step++
 #pragma unroll
@@ -94,7 +102,6 @@ static bool fused_try(const Batch &b, const StepArgs &a) {
 bool launch_hybrid_fused(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F64 || a.n != 6 || !a.ext_phi || a.snc || a.predict) return false;
     if (a.flags & (KB_FLAG_FULL_ESTIMATE | KB_FLAG_STRICT_SYMCHECK | KB_FLAG_STATEMENT_KERNELS)) return false;
-    if (a.stream_state) return false;   // (a state block beyond the Infinity Cache is streamed non-temporally by the one-step kernels: not rebuilt here)
     return fused_try<2>(b, a) || fused_try<1>(b, a) || fused_try<3>(b, a);
 }
 

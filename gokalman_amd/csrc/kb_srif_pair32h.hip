@@ -6,7 +6,7 @@ namespace kb {
 
 bool launch_srif_pair_f32_fused(const Batch &b, const StepArgs &a) {
     if (b.dtype != KB_F32) return false;
-    return srif_pair_launch_fused<float, 12, 6>(b, a);
+    return srif_pair_launch_fused<float, 12, 6>(b, a) || srif_pair_launch_fused<float, 6, 2>(b, a);   // (6 / 2: the reference's own SRIF shape, srif_test.go / examples/statOD)
 }
 
 }  // namespace kb

@@ -207,7 +207,7 @@ int kb_update_nl(kb_batch *b, const double *real_obs, int real_rows, const doubl
 int kb_update_nl_dev(kb_batch *b, const void *real_obs, const void *computed_obs, int64_t ld);
 /* The caller loop `for k { kf.Prepare(Phi_k, Htilde_k); kf.Update(real_k, computed_k) }` (srif.go:82-92, hybrid.go:78-95) from ONE call:
  * step t reads the planar device arrays (layouts of kb_prepare_dev / kb_update_nl_dev) at phi + t * phi_step, htilde + t * htilde_step,
- * real_obs / computed_obs + t * obs_step (strides in ELEMENTS of the batch's dtype).  SRIF 12 / 6 fp32 in the steady state (no Predict()
+ * real_obs / computed_obs + t * obs_step (strides in ELEMENTS of the batch's dtype).  SRIF 12 / 6 and 6 / 2 fp32 in the steady state (no Predict()
  * pending) and HybridKF 6 / 1..3 fp64 (CKF and EKF, no SNC pending), state-only outputs, run time-fused kernels -- ONE launch, the state
  * resident in registers from step to step, the same operations in the same order as nsteps single calls: the same bits, kf.step and
  * the per-filter failure semantics included; every other batch runs nsteps Prepare + Update launches back to back on the handle's

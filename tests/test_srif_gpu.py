@@ -273,16 +273,25 @@ def test_srif_odd_states_shadow_follows_every_other_writer_of_the_state(n, p, dt
 
 @pytest.mark.parametrize("N,fail", [(4096, False), (1000, True), (70, True)])
 def test_srif_time_fused_steps_equal_single_steps_bit_for_bit(N, fail):
+    _fused_against_single_steps(N, fail, 12, 6)
+
+
+@pytest.mark.parametrize("N,fail", [(1000, True), (130, False)])
+def test_srif_time_fused_6x2_the_references_own_shape(N, fail):
+    _fused_against_single_steps(N, fail, 6, 2)
+
+
+def _fused_against_single_steps(N, fail, n, p):
     """kb_update_nl_steps_dev (round 6): T Prepare + Update pairs of config E's shape (12 / 6, fp32, zero-copy operands, steady state) in ONE
     launch, the rows of (b, R) resident in registers between the steps -- the same operations in the same order as T single calls: the same
     bits, kf.step and the per-step failure semantics included (a filter whose Phi is singular at step k skips that step only; its wave
     reloads from memory at the next).  Also from a batch that is NOT in the steady state (behind a Predict(): the call falls back to T
     launches), and for a shape without a fused kernel."""
     import torch
-    n, p, T = 12, 6, 7
+    T = 7
     rng = np.random.default_rng(31 + N)
     x0 = rng.standard_normal((N, n))
-    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * 6 + [1.0] * 6
+    P0 = np.zeros((N, n, n)); P0[:, np.arange(n), np.arange(n)] = [10.0] * (n // 2) + [1.0] * (n // 2)
     R = np.zeros((N, p, p)); R[:, np.arange(p), np.arange(p)] = np.exp(rng.uniform(np.log(1e-4), np.log(1e-2), size=(N, p)))
     ld = N + 13                                   # (a leading dimension beyond N: the planar arrays' own)
     Phi = np.eye(n) + 1e-2 * rng.standard_normal((T, N, n, n))
@@ -302,7 +311,7 @@ def test_srif_time_fused_steps_equal_single_steps_bit_for_bit(N, fail):
         b.set(k.X, x0, 1); b.set(k.P, P0, 2); b.set(k.R, R, 2, p_rows=p); b.init()
         if fused:
             b.update_nl_steps_dev(dPhi.data_ptr(), dH.data_ptr(), ld, n * n * ld, p * n * ld, dre.data_ptr(), dco.data_ptr(), ld, p * ld, T)
-            assert "srif_pair_fused_kernel<float, 12, 6>" in b.last_kernel()
+            assert "srif_pair_fused_kernel<float, %d, %d>" % (n, p) in b.last_kernel()
         else:
             for t in range(T):
                 k.check(k.lib().kb_prepare_dev(b._h, dPhi[t].data_ptr(), dH[t].data_ptr(), ld))
@@ -316,6 +325,8 @@ def test_srif_time_fused_steps_equal_single_steps_bit_for_bit(N, fail):
     else:
         assert sorted(np.nonzero(res[0][2])[0].tolist()) == [5, N - 1]
     # not in the steady state (a Predict() pending a dense R), and a shape without a fused kernel: T launches from the one call, same results as the loop
+    if n != 12:
+        return
     for shape, predict_first in (((12, 6), True), ((8, 4), False)):
         nn, pp = shape
         outs = []
