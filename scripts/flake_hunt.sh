@@ -11,8 +11,8 @@ for i in $(seq 1 $runs); do
   rc=$?
   if [ $rc -ne 0 ]; then
     fails=$((fails+1))
-    echo "run $i rc=$rc rows=$(wc -l < /tmp/fh.out)"; tail -c 400 /tmp/fh.err
-    core=$(ls -t /tmp/core* 2>/dev/null | head -1)
+    echo "run $i rc=$rc rows=$(wc -l < /tmp/fh.out)"; tail -c 3000 /tmp/fh.err
+    core=""
     if [ -n "$core" ]; then /opt/rocm/bin/rocgdb -batch -ex "bt 25" -ex "info sharedlibrary" /tmp/gokalman_amd_jerkcar_host $core 2>&1 | grep -v "^\[New\|^warning" | head -60; rm -f /tmp/core*; fi
   fi
 done
